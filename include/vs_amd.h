@@ -1,0 +1,216 @@
+/*
+ * vs_amd.h -- C ABI of libvs_amd.so: the MI355X (gfx950) alignment + warp engine.
+ *
+ * This is the drop-in boundary for the catid/video_stabilizer hot path.  Each entry point
+ * names the reference interface it replaces (paths under the reference checkout).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Return: 0 = ok (or a documented positive value),
+ *     negative = error; vs_last_error() returns a thread-local message.  No exceptions cross.
+ *   - `mem` says where the caller's buffers live: VS_MEM_HOST (the library stages them through
+ *     device memory and synchronises; used by parity tests and one-off calls) or VS_MEM_DEVICE
+ *     (device pointers; the call only enqueues work on `stream` and returns -- no sync).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Images are row-major; strides are in ELEMENTS.  "planar (tx,ty,c)" tables are laid out
+ *     like the reference's Halide buffers: element (x,y,c) at c*tx*ty + y*tx + x.
+ *   - The caller owns every buffer it passes.  Handles own their device memory and one HIP
+ *     stream; a handle is single-threaded, distinct handles are independent.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ */
+#ifndef VS_AMD_H
+#define VS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_OK 0
+#define VS_ERR_ARG (-1)
+#define VS_ERR_HIP (-2)
+#define VS_ERR_UNSUPPORTED (-3)
+#define VS_ERR_STATE (-4)
+
+enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
+enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR16 = 2 };
+enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1 };
+enum { VS_BORDER_CLAMP = 0, VS_BORDER_CONSTANT = 1 };
+/* how the per-level "keep the best 80 %" subset is chosen (alignment.cpp:460-486) */
+enum {
+    VS_SELECT_STL_HOST = 0,   /* D2H + the host's std::nth_element, literally as the reference */
+    VS_SELECT_DEVICE = 1      /* on-device replica of libstdc++'s introselect: same set, same order */
+};
+
+/* imgproc.hpp:40-46 SimilarityTransform (centre-based, double) */
+typedef struct vs_transform { double A, B, TX, TY; } vs_transform;
+typedef struct vs_point { double x, y; } vs_point;
+
+/* alignment.hpp:5-41 VideoAlignerParams -- same fields, same defaults */
+typedef struct vs_aligner_params {
+    int    phase_correlate;            /* must stay 0 (phase correlation: SURVEY 8f-4, not built) */
+    double phase_correlate_threshold;
+    double threshold;
+    float  smallest_fraction;
+    int    max_iters;
+    int    pyramid_min_width;
+    int    pyramid_min_height;
+    double max_displacement;
+} vs_aligner_params;
+
+/* stabilizer.hpp:13-30 VideoStabilizerParams (+ the two warp knobs this build defines) */
+typedef struct vs_stabilizer_params {
+    vs_aligner_params aligner;
+    int    lag;
+    int    smoother_memory;
+    double lambda;
+    int    enable_smoother;
+    int    crop_pixels;
+    double min_disp, max_disp;
+    double min_decay, max_decay;
+    int    warp_mode;     /* VS_WARP_*   (reference: cv::warpAffine INTER_LINEAR, imgproc.cpp:472) */
+    int    warp_border;   /* VS_BORDER_* (reference: BORDER_CONSTANT black, imgproc.cpp:479-480) */
+} vs_stabilizer_params;
+
+const char* vs_last_error(void);
+const char* vs_version(void);
+/* number of usable HIP devices (0 when there is none; never fails) */
+int vs_device_count(void);
+
+void vs_aligner_params_default(vs_aligner_params* p);
+void vs_stabilizer_params_default(vs_stabilizer_params* p);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side scalar algebra (no device needed)
+ * ------------------------------------------------------------------------------------------ */
+/* SimilarityTransform::inverse / compose / warp / maxCornerDisplacement, imgproc.cpp:333-437 */
+vs_transform vs_transform_inverse(const vs_transform* t);
+vs_transform vs_transform_compose(const vs_transform* t1, const vs_transform* t2);   /* t1 then t2 */
+vs_point     vs_transform_warp(const vs_transform* t, vs_point p);
+vs_point     vs_transform_warp_center(const vs_transform* t, vs_point p, double cx, double cy);
+double       vs_transform_max_corner_displacement(const vs_transform* t, double width, double height);
+/* GradArgMax's tile-size rule, imgproc.cpp:151-162 */
+int vs_tile_size(int w, int h);
+/* centre-based double transform -> the float, upper-left based kernel arguments.
+ * sparse: imgproc.cpp:69-75 / 98-103 (centre w/2,h/2).  warp: imgproc.cpp:125-131 (centre (w-1)/2,(h-1)/2) */
+void vs_ul_params_sparse(const vs_transform* t, int w, int h, float out4[4]);
+void vs_ul_params_warp(const vs_transform* t, int w, int h, float out4[4]);
+/* L1SmootherCenter, smoother.hpp:10-30 / smoother.cpp:67-127 */
+typedef struct vs_smoother vs_smoother;
+vs_smoother* vs_smoother_create(int lag_behind, int lag_ahead, double lambda);
+void vs_smoother_destroy(vs_smoother* s);
+int  vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* out_finalized); /* 1 = finalized */
+void vs_tvl1_smooth(const double* data, int n, double lambda, int iterations, double* out);   /* smoother.cpp:18-65 */
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel level: one entry point per Halide AOT function called from imgproc.cpp
+ * ------------------------------------------------------------------------------------------ */
+/* int pyr_down(in, out)                                   imgproc.cpp:112, generators.cpp:56-92 */
+int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride,
+                uint8_t* out, int ow, int oh, int out_stride, int mem, void* stream);
+/* int grad_xy(in, gx, gy)                                 imgproc.cpp:140, generators.cpp:202-224
+ * gx, gy dense (w*h) */
+int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream);
+/* int grad_argmax_<ts>(gx, gy, local_max_x, local_max_y)  imgproc.cpp:174-195, generators.cpp:260-294
+ * tile_size 1..64; outputs planar (w/ts, h/ts, 2) u16 */
+int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int tile_size,
+                   uint16_t* local_max_x, uint16_t* local_max_y, int mem, void* stream);
+/* int sparse_jac(gx, gy, lmx, lmy, out_x, out_y)          imgproc.cpp:42, generators.cpp:332-386
+ * outputs planar (tx,ty,4) f32 */
+int vs_sparse_jac(const float* gx, const float* gy, int w, int h,
+                  const uint16_t* local_max_x, const uint16_t* local_max_y, int tx, int ty,
+                  float* out_x, float* out_y, int mem, void* stream);
+/* Fused keyframe pass (what the engine runs): grad_xy + grad_argmax + sparse_jac straight from
+ * the u8 image, never materialising the gradient planes.  Same outputs, bit for bit, as the
+ * three calls above (alignment.cpp:237-276). */
+int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int tile_size,
+                      uint16_t* local_max_x, uint16_t* local_max_y, float* jac_x, float* jac_y,
+                      int mem, void* stream);
+/* int sparse_warpdiff(tmpl, key, local_max, A, B, TX, TY, out)   imgproc.cpp:94-104, generators.cpp:646-700 */
+int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride,
+                       const uint16_t* local_max, int tx, int ty,
+                       float A, float B, float TX, float TY, uint16_t* out, int mem, void* stream);
+/* int sparse_ica(tmpl, key, selx, sely, jacx, jacy, A, B, TX, TY, out)  imgproc.cpp:62-76, generators.cpp:429-596
+ * selx/sely planar (n,2) u16; jacx/jacy planar (n,4) f32; out = 4 doubles */
+int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride,
+                  const uint16_t* selx, int nx, const uint16_t* sely, int ny,
+                  const float* jacx, const float* jacy,
+                  float A, float B, float TX, float TY, double* out4, int mem, void* stream);
+/* int image_warp(in, A, B, TX, TY, out)                   imgproc.cpp:131, generators.cpp:126-164 */
+int vs_image_warp(const uint8_t* in, int w, int h, int stride,
+                  float A, float B, float TX, float TY, float* out, int ow, int oh, int mem, void* stream);
+/* bgr_image_warp: the full-frame colour warp (replaces warpBySimilarityTransform's cv::warpAffine,
+ * imgproc.cpp:446-484 / stabilizer.cpp:97-99; the generator itself is absent from the reference,
+ * schedules/bgr_image_warp.schedule.h is its orphan -- SURVEY D2).  `t` is the output->input
+ * sampling map, centre-based about ((w-1)/2,(h-1)/2) as ImageWarp (imgproc.cpp:125-131).
+ * src/dst interleaved with `channels` (1..4) per pixel; bits 8 (uint8_t) or 16 (uint16_t);
+ * store rule floor(v+0.5) saturated to [0,max_value].  n_frames >= 1 frames are processed in one
+ * launch: frame i at src + i*src_frame_stride (elements), transform t[i]. */
+int vs_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits,
+                      const vs_transform* t, int mode, int border, int max_value,
+                      void* dst, int dst_stride, int mem, void* stream);
+int vs_bgr_image_warp_batch(const void* src, size_t src_frame_stride, int n_frames,
+                            int w, int h, int src_stride, int channels, int bits,
+                            const vs_transform* t /* host array, n_frames */, int mode, int border, int max_value,
+                            void* dst, size_t dst_frame_stride, int dst_stride, int mem, void* stream);
+/* same sampling, float output (typed like image_warp); dst interleaved f32 */
+int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits,
+                          const vs_transform* t, int mode, int border,
+                          float* dst, int dst_stride, int mem, void* stream);
+/* cv::cvtColor(BGR2GRAY) stand-in (alignment.cpp:212): (B*3735+G*19235+R*9798+16384)>>15, then >>shift_to_8 */
+int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8,
+                   uint8_t* dst, int dst_stride, int mem, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine level: VideoAligner (alignment.hpp:51-99) and VideoStabilizer (stabilizer.hpp:32-56)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vs_aligner vs_aligner;
+/* per-frame detail of the last align call(s), for parity tests and the per-stage report */
+typedef struct vs_align_info {
+    int32_t status;          /* 1 aligned, 0 not aligned */
+    int32_t fail_reason;     /* 0 ok, 1 first frame, 2 max iterations, 3 over displacement */
+    int32_t fail_level;
+    int32_t levels;
+    int32_t iterations[16];
+    double  condition[16];
+} vs_align_info;
+
+vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);
+void vs_aligner_destroy(vs_aligner* a);
+int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
+/* VideoAligner::AlignNextFrame (alignment.hpp:55-58, alignment.cpp:334-704).
+ * returns 1 aligned / 0 not aligned (first frame, no convergence, over displacement) / <0 error.
+ * `params` may change per call like the reference's third argument (NULL = the creation params). */
+int  vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
+                           const vs_aligner_params* params, vs_transform* out);
+/* Batched form: exactly the results of n successive vs_aligner_align_next calls on this handle
+ * (state carries over between calls), but every stage runs as one launch over all frames /
+ * frame pairs.  frames: n frames, frame i at frames + i*frame_stride (elements).  out[n],
+ * status[n] (1/0 per frame).  Returns the number of aligned frames, or <0 on error. */
+int  vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n,
+                            int w, int h, int stride, int format, int mem,
+                            const vs_aligner_params* params, vs_transform* out, int32_t* status);
+/* detail for frame i of the most recent align_next (i = 0) / align_batch call */
+int  vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info);
+/* device pointers / dims of internal per-level state of the most recent call (parity tests) */
+int  vs_aligner_level_dims(const vs_aligner* a, int level, int* w, int* h, int* tiles_x, int* tiles_y, int* tile_size);
+/* copies out (to host) level images / keypoint tables of frame i of the most recent call */
+int  vs_aligner_read_level_image(const vs_aligner* a, int i, int level, uint8_t* out);
+int  vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set, uint16_t* out);
+int  vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out);
+
+typedef struct vs_stabilizer vs_stabilizer;
+vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params /* NULL = defaults */, int device);
+void vs_stabilizer_destroy(vs_stabilizer* s);
+/* VideoStabilizer::processFrame (stabilizer.hpp:39, stabilizer.cpp:9-117).  frame: interleaved BGR
+ * u8 (VS_FMT_BGR8) or u16 (VS_FMT_BGR16).  out: (w-2*crop)*(h-2*crop)*3 elements, dense.
+ * returns 1 when an output frame was written (0 for the first `lag` frames), <0 on error. */
+int  vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem,
+                           void* out, int* out_w, int* out_h);
+void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+/*
+ * vs_oracle.h -- CPU restatement of the catid/video_stabilizer alignment + warp path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under video_stabilizer_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use
+ * it, and there only as the checker / the reported CPU baseline.
+ *
+ * PARITY STATUS: "parity unpinned" against the real reference.  The reference needs
+ * Halide + OpenCV + Eigen, none of which exist in this image, so it cannot be built or
+ * run here, and its own test (align_test.cpp) holds no numeric golden vectors for any
+ * Halide pipeline.  This restatement is pinned instead by
+ * hand-derived known answers checked against the reference *source text*
+ * (tests/test_oracle_known_answers.py) and it generates the fixtures in tests/golden/.
+ *
+ * Every function cites the reference file:line it follows (paths under /root/reference).
+ * All floating point follows the reference's written evaluation order, compiled with
+ * -ffp-contract=off so no FMA contraction happens.
+ */
+#ifndef VS_ORACLE_H
+#define VS_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* imgproc.hpp:40-46 */
+typedef struct vso_transform { double A, B, TX, TY; } vso_transform;
+typedef struct vso_point { double x, y; } vso_point;
+
+/* alignment.hpp:5-41 (same field order, same defaults via vso_aligner_params_default) */
+typedef struct vso_aligner_params {
+    int    phase_correlate;            /* must be 0: phase correlation is out of scope */
+    double phase_correlate_threshold;
+    double threshold;
+    float  smallest_fraction;
+    int    max_iters;
+    int    pyramid_min_width;
+    int    pyramid_min_height;
+    double max_displacement;
+} vso_aligner_params;
+
+/* stabilizer.hpp:13-30 */
+typedef struct vso_stabilizer_params {
+    vso_aligner_params aligner;
+    int    lag;
+    int    smoother_memory;
+    double lambda;
+    int    enable_smoother;
+    int    crop_pixels;
+    double min_disp, max_disp;
+    double min_decay, max_decay;
+    /* build-defined: how the output frame is resampled */
+    int    warp_mode;    /* VSO_WARP_* */
+    int    warp_border;  /* VSO_BORDER_* */
+} vso_stabilizer_params;
+
+enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1 };
+enum { VSO_BORDER_CLAMP = 0, VSO_BORDER_CONSTANT = 1 };
+enum { VSO_FMT_GRAY8 = 0, VSO_FMT_BGR8 = 1, VSO_FMT_BGR16 = 2 };
+
+void vso_aligner_params_default(vso_aligner_params* p);
+void vso_stabilizer_params_default(vso_stabilizer_params* p);
+
+/* ---- kernels (generators.cpp) -------------------------------------------------------- */
+float vso_lanczos2(float x);                                                /* generators.cpp:31-47 */
+void vso_pyr_down(const uint8_t* in, int w, int h, int in_stride,
+                  uint8_t* out, int ow, int oh, int out_stride);           /* :56-92 */
+void vso_grad_xy(const uint8_t* in, int w, int h, int stride,
+                 float* gx, float* gy);                                    /* :202-224 */
+int  vso_tile_size(int w, int h);                                          /* imgproc.cpp:151-162 */
+void vso_grad_argmax(const float* gx, const float* gy, int w, int h, int tile_size,
+                     uint16_t* lmx, uint16_t* lmy);                        /* :260-294, planar (tx,ty,2) */
+void vso_sparse_jac(const float* gx, const float* gy, int w, int h,
+                    const uint16_t* lmx, const uint16_t* lmy, int tx, int ty,
+                    float* jx, float* jy);                                 /* :332-386, planar (tx,ty,4) */
+/* A,B,TX,TY below are the *kernel* arguments: float, upper-left based */
+void vso_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride,
+                         const uint16_t* lm, int tx, int ty,
+                         float A, float B, float TX, float TY, uint16_t* out);   /* :646-700 */
+void vso_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride,
+                    const uint16_t* selx, int nx, const uint16_t* sely, int ny,
+                    const float* jacx, const float* jacy,
+                    float A, float B, float TX, float TY, double out[4]);        /* :429-596 */
+void vso_image_warp(const uint8_t* in, int w, int h, int stride,
+                    float A, float B, float TX, float TY,
+                    float* out, int ow, int oh);                                 /* :126-164 */
+
+/* ---- wrappers (imgproc.cpp): centre-based double transform -> kernel floats ----------- */
+void vso_ul_params_sparse(const vso_transform* t, int w, int h, float out4[4]);  /* imgproc.cpp:69-75,98-103 */
+void vso_ul_params_warp(const vso_transform* t, int w, int h, float out4[4]);    /* imgproc.cpp:125-131 */
+
+/* bgr_image_warp: build-defined.  src/dst interleaved, `channels` per pixel,
+ * strides in ELEMENTS.  bits = 8 (uint8_t) or 16 (uint16_t).  The transform is the
+ * output->input sampling map, centre-based about ((w-1)/2,(h-1)/2) like ImageWarp.
+ * Integer store rule: floor(v + 0.5f) then saturate to [0, max_value]. */
+void vso_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits,
+                        const vso_transform* t, int mode, int border, int max_value,
+                        void* dst, int dst_stride);
+/* float-typed output (like image_warp), same sampling; dst interleaved float */
+void vso_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits,
+                            const vso_transform* t, int mode, int border,
+                            float* dst, int dst_stride);
+/* BGR->gray, build's documented choice: (B*3735+G*19235+R*9798+16384)>>15 */
+void vso_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8,
+                     uint8_t* dst, int dst_stride);
+
+/* ---- transform algebra (imgproc.cpp:327-437) ------------------------------------------ */
+vso_transform vso_transform_inverse(const vso_transform* t);
+vso_transform vso_transform_compose(const vso_transform* t1, const vso_transform* t2); /* apply t1 then t2 */
+vso_point     vso_transform_warp(const vso_transform* t, vso_point p);
+vso_point     vso_transform_warp_center(const vso_transform* t, vso_point p, double cx, double cy);
+double        vso_transform_max_corner_displacement(const vso_transform* t, double w, double h);
+
+/* ---- selection + 4x4 solve (alignment.cpp:435-583) ------------------------------------- */
+/* std::nth_element on {abs_delta,tile_x,tile_y} exactly as alignment.cpp:438-486 (libstdc++).
+ * Writes the kept tile indices (tile_y*tx+tile_x) in the post-nth_element order. Returns count. */
+int  vso_select_smallest(const uint16_t* warpdiff, int tx, int ty, float fraction, int32_t* out_idx);
+void vso_hessian(const float* jacx, int nx, const float* jacy, int ny, double H[16]); /* :278-332 */
+/* cond / Tikhonov / pseudo-inverse (:555-583).  OpenCV SVD is replaced by a cyclic Jacobi
+ * eigen-solver (H is symmetric PSD).  Returns the condition number. */
+double vso_condition_and_invert(double H[16], double Hinv[16]);
+
+/* ---- L1 smoother (smoother.cpp) --------------------------------------------------------- */
+void vso_tvl1_smooth(const double* data, int n, double lambda, int iterations, double* out); /* :18-65 */
+typedef struct vso_smoother vso_smoother;
+vso_smoother* vso_smoother_create(int lag_behind, int lag_ahead, double lambda);
+void vso_smoother_destroy(vso_smoother*);
+int  vso_smoother_update(vso_smoother*, const vso_transform* meas, vso_transform* out_finalized);
+
+/* ---- VideoAligner (alignment.cpp:149-704) ------------------------------------------------ */
+typedef struct vso_aligner vso_aligner;
+typedef struct vso_align_debug {
+    int levels;
+    int fail_reason;            /* 0 ok, 1 first frame, 2 max iters, 3 over displacement */
+    int fail_level;
+    int iterations[16];
+    int tile_size[16];
+    int selected_x[16], selected_y[16];
+    double condition[16];
+    vso_transform level_transform[16];   /* transform at the end of each level (before TX,TY *= 2) */
+} vso_align_debug;
+
+vso_aligner* vso_aligner_create(void);
+void vso_aligner_destroy(vso_aligner*);
+/* returns 1 aligned, 0 not aligned (first frame / no convergence / over displacement), <0 bad args */
+int  vso_aligner_align_next(vso_aligner*, const void* frame, int w, int h, int stride_elems, int format,
+                            const vso_aligner_params* params, vso_transform* out);
+const vso_align_debug* vso_aligner_debug(const vso_aligner*);
+/* read back internal per-level state for golden fixtures / parity tests */
+int  vso_aligner_level_dims(const vso_aligner*, int level, int* w, int* h, int* tiles_x, int* tiles_y, int* tile_size);
+const uint8_t*  vso_aligner_level_image(const vso_aligner*, int slot, int level);
+const uint16_t* vso_aligner_level_argmax(const vso_aligner*, int level, int set);   /* set 0 = x, 1 = y */
+const float*    vso_aligner_level_jacobian(const vso_aligner*, int level, int set);
+
+/* ---- VideoStabilizer (stabilizer.cpp) ---------------------------------------------------- */
+typedef struct vso_stabilizer vso_stabilizer;
+vso_stabilizer* vso_stabilizer_create(const vso_stabilizer_params*);
+void vso_stabilizer_destroy(vso_stabilizer*);
+/* frame: interleaved BGR u8 (format BGR8) or u16 (BGR16).  out must hold (w-2c)*(h-2c)*3 elements.
+ * returns 1 if an output frame was produced, 0 if not yet, <0 error. */
+int  vso_stabilizer_process(vso_stabilizer*, const void* frame, int w, int h, int stride_elems, int format,
+                            void* out, int* out_w, int* out_h);
+/* last measurement / accumulated correction, for parity of the scalar bookkeeping */
+void vso_stabilizer_state(const vso_stabilizer*, vso_transform* last_meas, vso_transform* accum, int* last_success);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

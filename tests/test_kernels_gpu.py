@@ -1,0 +1,254 @@
+"""GPU parity of every kernel-level C-ABI entry point against the CPU oracle, on seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY 8d): integer, byte and index outputs bit-exact; fp32
+outputs bit-exact too where the kernel keeps the reference's evaluation order (they all do);
+the fp64 sparse_ica sums to 1e-12 relative (tree reduction vs the reference's serial order).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(640, 480), (322, 241), (97, 61), (1920, 1080)]
+
+
+def _img(w, h, seed):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 1, seed=seed, path=[(0.0, 0.0, 0.0, 0.0)], margin=8)
+    return frames[0]
+
+
+def _noise(w, h, seed):
+    return np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(8, 8), (9, 7), (130, 34), (4096, 37)])
+def test_pyr_down_bit_exact(gpu_vs, oracle, w, h):
+    img = _noise(w, h, 1)
+    assert np.array_equal(gpu_vs.pyr_down(img), oracle.pyr_down(img))
+
+
+def test_pyr_down_known_answers(gpu_vs):
+    # impulse responses of the integer form (sum w_i w_j in) >> 8
+    img = np.zeros((32, 32), np.uint8)
+    img[16, 16] = 255
+    out = gpu_vs.pyr_down(img)
+    assert out[8, 8] == 35 and out[8, 7] == 5 and out[8, 9] == 5 and out[7, 8] == 5 and out[9, 8] == 5
+    assert out[7, 7] == 0
+    img = np.zeros((32, 32), np.uint8)
+    img[0, 0] = 255
+    assert gpu_vs.pyr_down(img)[0, 0] == 120
+    assert np.all(gpu_vs.pyr_down(np.full((40, 48), 77, np.uint8)) == 77)
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(5, 3)])
+def test_grad_xy_bit_exact(gpu_vs, oracle, w, h):
+    img = _noise(w, h, 2)
+    gx, gy = gpu_vs.grad_xy(img)
+    ox, oy = oracle.grad_xy(img)
+    assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_grad_argmax_bit_exact(gpu_vs, oracle, w, h):
+    img = _img(w, h, 3)
+    gx, gy = oracle.grad_xy(img)
+    ts, lmx, lmy = gpu_vs.grad_argmax(gx, gy)
+    ots, olx, oly = oracle.grad_argmax(gx, gy)
+    assert ts == ots
+    assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
+
+
+@pytest.mark.parametrize("ts", [2, 4, 7, 20, 33])
+def test_grad_argmax_ties_and_zero_tiles(gpu_vs, oracle, ts):
+    # flat image => all-zero gradients => top-left of every tile; plus planted equal maxima
+    w, h = 10 * ts + 3, 6 * ts + 1
+    gx = np.zeros((h, w), np.float32)
+    gy = np.zeros((h, w), np.float32)
+    gx[ts + 1, 2 * ts + 1] = 5.0
+    gx[ts + 1, 2 * ts] = -5.0          # equal magnitude, smaller x on the same row wins
+    if ts > 2:
+        gy[3 * ts + 2, ts] = 7.0
+        gy[3 * ts + 1, ts + 1] = 7.0   # smaller y wins over smaller x
+    _, lmx, lmy = gpu_vs.grad_argmax(gx, gy, ts)
+    _, olx, oly = oracle.grad_argmax(gx, gy, ts)
+    assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
+    assert lmx[0, 0, 0] == 0 and lmx[1, 0, 0] == 0
+    assert (lmx[0, 1, 2], lmx[1, 1, 2]) == (2 * ts, ts + 1)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+def test_sparse_jac_bit_exact(gpu_vs, oracle, w, h):
+    img = _img(w, h, 4)
+    gx, gy = oracle.grad_xy(img)
+    _, lmx, lmy = oracle.grad_argmax(gx, gy)
+    jx, jy = gpu_vs.sparse_jac(gx, gy, lmx, lmy)
+    ojx, ojy = oracle.sparse_jac(gx, gy, lmx, lmy)
+    assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(120, 67), (60, 33)])
+def test_keyframe_fused_equals_three_stage_oracle(gpu_vs, oracle, w, h):
+    img = _img(w, h, 5)
+    ts, lmx, lmy, jx, jy = gpu_vs.keyframe_fused(img)
+    gx, gy = oracle.grad_xy(img)
+    ots, olx, oly = oracle.grad_argmax(gx, gy)
+    ojx, ojy = oracle.sparse_jac(gx, gy, olx, oly)
+    assert ts == ots
+    assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
+    assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+
+
+def test_keyframe_fused_flat_and_saturated(gpu_vs, oracle):
+    for img in (np.zeros((60, 80), np.uint8), np.full((60, 80), 255, np.uint8),
+                (np.indices((60, 80)).sum(0) % 2 * 255).astype(np.uint8)):
+        ts, lmx, lmy, jx, jy = gpu_vs.keyframe_fused(img)
+        gx, gy = oracle.grad_xy(img)
+        _, olx, oly = oracle.grad_argmax(gx, gy)
+        ojx, ojy = oracle.sparse_jac(gx, gy, olx, oly)
+        assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
+        assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+
+
+TRANSFORMS = [(0, 0, 0, 0), (0.0, 0.0, 3.25, -2.5), (0.01, 0.005, -1.5, 2.75), (-0.02, 0.015, 9.0, -7.0),
+              (0.0, 0.0, 1.0, 1.0), (0.05, -0.04, 40.0, 30.0)]
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (322, 241), (80, 60)])
+@pytest.mark.parametrize("tr", TRANSFORMS)
+def test_sparse_warpdiff_bit_exact(gpu_vs, oracle, w, h, tr):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 2, seed=6, path=[(0, 0, 0, 0), (0.002, -0.001, 1.3, -0.8)], margin=16)
+    gx, gy = oracle.grad_xy(frames[1])
+    _, lmx, lmy = oracle.grad_argmax(gx, gy)
+    for lm in (lmx, lmy):
+        g = gpu_vs.sparse_warpdiff(frames[0], frames[1], lm, gpu_vs.Transform.of(*tr))
+        o = oracle.sparse_warpdiff(frames[0], frames[1], lm, oracle.Transform.of(*tr))
+        assert np.array_equal(g, o)
+
+
+def test_sparse_warpdiff_identity_is_zero(gpu_vs, oracle):
+    # template == keyframe, identity T => every |diff| truncates to 0
+    img = _img(320, 240, 8)
+    gx, gy = oracle.grad_xy(img)
+    _, lmx, _ = oracle.grad_argmax(gx, gy)
+    assert not gpu_vs.sparse_warpdiff(img, img, lmx, gpu_vs.Transform.of()).any()
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (160, 120)])
+@pytest.mark.parametrize("tr", TRANSFORMS[:4])
+def test_sparse_ica_matches_oracle(gpu_vs, oracle, w, h, tr):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 2, seed=9, path=[(0, 0, 0, 0), (0.001, 0.002, -2.2, 1.1)], margin=16)
+    gx, gy = oracle.grad_xy(frames[1])
+    _, lmx, lmy = oracle.grad_argmax(gx, gy)
+    jx, jy = oracle.sparse_jac(gx, gy, lmx, lmy)
+    rng = np.random.default_rng(0)
+    nt = lmx.shape[1] * lmx.shape[2]
+    keep_x = rng.permutation(nt)[: int(nt * 0.8)]
+    keep_y = rng.permutation(nt)[: int(nt * 0.8)]
+    selx = lmx.reshape(2, -1)[:, keep_x]
+    sely = lmy.reshape(2, -1)[:, keep_y]
+    jacx = jx.reshape(4, -1)[:, keep_x]
+    jacy = jy.reshape(4, -1)[:, keep_y]
+    g = gpu_vs.sparse_ica(frames[0], frames[1], selx, sely, jacx, jacy, gpu_vs.Transform.of(*tr))
+    o = oracle.sparse_ica(frames[0], frames[1], selx, sely, jacx, jacy, oracle.Transform.of(*tr))
+    scale = np.abs(o).max() + 1e-30
+    assert np.abs(g - o).max() <= 1e-12 * scale + 1e-9
+
+
+@pytest.mark.parametrize("tr", TRANSFORMS)
+def test_image_warp_bit_exact(gpu_vs, oracle, tr):
+    img = _img(322, 241, 10)
+    g = gpu_vs.image_warp(img, gpu_vs.Transform.of(*tr))
+    o = oracle.image_warp(img, oracle.Transform.of(*tr))
+    assert np.array_equal(g, o)
+
+
+def test_image_warp_integer_shift_known_answer(gpu_vs):
+    # align_test.cpp:358-400 / SURVEY 8c-7: 64x64, white 10x10 square at (20,20), T = (0,0,5,7);
+    # ImageWarp(in, T.inverse()) moves the square by exactly (+5,+7)
+    img = np.zeros((64, 64), np.uint8)
+    img[20:30, 20:30] = 255
+    t = gpu_vs.t_inverse(gpu_vs.Transform.of(0, 0, 5, 7))
+    out = gpu_vs.image_warp(img, t)
+    exp = np.zeros((64, 64), np.float32)
+    exp[27:37, 25:35] = 255
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("border", [0, 1])
+@pytest.mark.parametrize("tr", TRANSFORMS)
+def test_bgr_image_warp_u8_bit_exact(gpu_vs, oracle, mode, border, tr):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(322, 241, 1, seed=11, channels=3, path=[(0, 0, 0, 0)], margin=8)
+    g = gpu_vs.bgr_image_warp(frames[0], gpu_vs.Transform.of(*tr), mode, border)
+    o = oracle.bgr_image_warp(frames[0], oracle.Transform.of(*tr), mode, border)
+    assert np.array_equal(g, o)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bgr_image_warp_f32_and_u16(gpu_vs, oracle, mode):
+    from video_stabilizer_amd import synth
+    tr = (0.01, -0.004, 2.6, -1.7)
+    f8, _ = synth.make_clip(200, 120, 1, seed=12, channels=3, path=[(0, 0, 0, 0)], margin=8)
+    g = gpu_vs.bgr_image_warp(f8[0], gpu_vs.Transform.of(*tr), mode, 0, f32=True)
+    o = oracle.bgr_image_warp(f8[0], oracle.Transform.of(*tr), mode, 0, f32=True)
+    assert np.array_equal(g, o)
+    f16, _ = synth.make_clip(200, 120, 1, seed=13, channels=3, bits=10, path=[(0, 0, 0, 0)], margin=8)
+    assert f16.dtype == np.uint16 and f16.max() > 255
+    g = gpu_vs.bgr_image_warp(f16[0], gpu_vs.Transform.of(*tr), mode, 1, max_value=1023)
+    o = oracle.bgr_image_warp(f16[0], oracle.Transform.of(*tr), mode, 1, max_value=1023)
+    assert np.array_equal(g, o)
+
+
+def test_bgr_image_warp_gray_and_4ch(gpu_vs, oracle):
+    rng = np.random.default_rng(5)
+    tr = (0.003, 0.002, -3.3, 4.4)
+    for c in (1, 2, 4):
+        src = rng.integers(0, 256, (50, 70, c), dtype=np.uint8)
+        g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr))
+        o = oracle.bgr_image_warp(src, oracle.Transform.of(*tr))
+        assert np.array_equal(g, o)
+
+
+def test_bgr_image_warp_batch(gpu_vs, oracle):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(160, 96, 5, seed=14, channels=3, margin=16)
+    ts = [(0.001 * i, -0.002 * i, 1.5 * i, -0.7 * i) for i in range(5)]
+    g = gpu_vs.bgr_image_warp_batch(frames, [gpu_vs.Transform.of(*t) for t in ts])
+    for i in range(5):
+        o = oracle.bgr_image_warp(frames[i], oracle.Transform.of(*ts[i]))
+        assert np.array_equal(g[i], o)
+
+
+def test_bgr_image_warp_identity_is_round_trip(gpu_vs):
+    # size-independent property at the BASELINE 4K size: identity transform, bilinear => output == input;
+    # Lanczos2 at frac 0 has taps {-3.1e-5, 0.999861, -3.1e-5}: within 1 LSB of the input
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)
+    out = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(), gpu_vs.WARP_BILINEAR)
+    assert np.array_equal(out, src)
+    out = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(), gpu_vs.WARP_LANCZOS2)
+    assert np.abs(out.astype(np.int16) - src.astype(np.int16)).max() <= 1
+
+
+def test_bgr_image_warp_integer_shift_4k(gpu_vs):
+    # integer translation, clamp border: bilinear output is the input shifted, exactly
+    rng = np.random.default_rng(8)
+    src = rng.integers(0, 256, (2160, 3840, 3), dtype=np.uint8)
+    out = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(0, 0, 7, -3), gpu_vs.WARP_BILINEAR)
+    assert np.array_equal(out[3:, :-7], src[:-3, 7:])
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+def test_bgr_to_gray_bit_exact(gpu_vs, oracle, bits):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(322, 241, 1, seed=15, channels=3, bits=bits, path=[(0, 0, 0, 0)], margin=8)
+    assert np.array_equal(gpu_vs.bgr_to_gray(frames[0]), oracle.bgr_to_gray(frames[0]))
+
+
+def test_bad_arguments_are_errors(gpu_vs):
+    with pytest.raises(gpu_vs.VsError):
+        gpu_vs.bgr_image_warp(np.zeros((4, 4, 5), np.uint8), gpu_vs.Transform.of())

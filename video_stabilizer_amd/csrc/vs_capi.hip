@@ -1,0 +1,272 @@
+// vs_capi.hip -- kernel-level entry points of the C ABI (include/vs_amd.h).
+// Each mirrors one Halide AOT function the reference's imgproc.cpp calls; see the header for the
+// file:line of the interface it replaces.  VS_MEM_HOST stages through device memory and syncs;
+// VS_MEM_DEVICE only enqueues on the caller's stream.
+#include "vs_internal.hpp"
+#include "vs_kernels.hpp"
+
+#include <vector>
+
+namespace vsi {
+
+bool device_ready() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(VS_ERR_HIP, "no usable HIP device (%s): libvs_amd has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
+int Staged::in(const void* ptr, size_t n, int mem, hipStream_t s) {
+    bytes = n; is_out = false;
+    if (mem == VS_MEM_DEVICE) { dev = const_cast<void*>(ptr); staged = false; return VS_OK; }
+    staged = true; host = const_cast<void*>(ptr);
+    VS_HIP(buf.alloc(n));
+    dev = buf.p;
+    if (n) VS_HIP(hipMemcpyAsync(dev, ptr, n, hipMemcpyHostToDevice, s));
+    return VS_OK;
+}
+int Staged::out(void* ptr, size_t n, int mem) {
+    bytes = n; is_out = true;
+    if (mem == VS_MEM_DEVICE) { dev = ptr; staged = false; return VS_OK; }
+    staged = true; host = ptr;
+    VS_HIP(buf.alloc(n));
+    dev = buf.p;
+    return VS_OK;
+}
+int Staged::finish(hipStream_t s) {
+    if (staged && is_out && bytes) VS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    return VS_OK;
+}
+
+}  // namespace vsi
+
+using vsi::Staged;
+using vsi::set_error;
+
+#define VS_TRY(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
+#define VS_ARG(cond) do { if (!(cond)) return set_error(VS_ERR_ARG, "bad argument: %s (%s)", #cond, __func__); } while (0)
+
+static inline size_t img_span(int w, int h, int stride, int channels) {
+    return (size_t)(h - 1) * stride + (size_t)w * channels;
+}
+static inline int finish_host(int mem, hipStream_t s) {
+    if (mem == VS_MEM_HOST) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+extern "C" {
+
+int vs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride, int mem,
+                void* stream) {
+    VS_ARG(in && out && w > 0 && h > 0 && ow > 0 && oh > 0 && in_stride >= w && out_stride >= ow);
+    VS_ARG(2 * ow <= w + 1 && 2 * oh <= h + 1);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    Staged a, b;
+    VS_TRY(a.in(in, img_span(w, h, in_stride, 1), mem, s));
+    VS_TRY(b.out(out, img_span(ow, oh, out_stride, 1), mem));
+    VS_HIP(vsk::pyr_down(a.as<uint8_t>(), w, h, in_stride, b.as<uint8_t>(), ow, oh, out_stride, 1, 0, 0, s));
+    VS_TRY(b.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream) {
+    VS_ARG(in && gx && gy && w > 0 && h > 0 && stride >= w);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    Staged a, x, y;
+    VS_TRY(a.in(in, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(x.out(gx, (size_t)w * h * 4, mem));
+    VS_TRY(y.out(gy, (size_t)w * h * 4, mem));
+    VS_HIP(vsk::grad_xy(a.as<uint8_t>(), w, h, stride, x.as<float>(), y.as<float>(), s));
+    VS_TRY(x.finish(s));
+    VS_TRY(y.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy, int mem,
+                   void* stream) {
+    VS_ARG(gx && gy && lmx && lmy && w > 0 && h > 0 && ts >= 1 && ts <= 64);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = (size_t)(w / ts) * (h / ts);
+    Staged a, b, x, y;
+    VS_TRY(a.in(gx, (size_t)w * h * 4, mem, s));
+    VS_TRY(b.in(gy, (size_t)w * h * 4, mem, s));
+    VS_TRY(x.out(lmx, nt * 2 * 2, mem));
+    VS_TRY(y.out(lmy, nt * 2 * 2, mem));
+    VS_HIP(vsk::grad_argmax(a.as<float>(), b.as<float>(), w, h, ts, x.as<uint16_t>(), y.as<uint16_t>(), s));
+    VS_TRY(x.finish(s));
+    VS_TRY(y.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy, int tx, int ty,
+                  float* out_x, float* out_y, int mem, void* stream) {
+    VS_ARG(gx && gy && lmx && lmy && out_x && out_y && w > 0 && h > 0 && tx > 0 && ty > 0);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = (size_t)tx * ty;
+    Staged a, b, c, d, x, y;
+    VS_TRY(a.in(gx, (size_t)w * h * 4, mem, s));
+    VS_TRY(b.in(gy, (size_t)w * h * 4, mem, s));
+    VS_TRY(c.in(lmx, nt * 4, mem, s));
+    VS_TRY(d.in(lmy, nt * 4, mem, s));
+    VS_TRY(x.out(out_x, nt * 16, mem));
+    VS_TRY(y.out(out_y, nt * 16, mem));
+    VS_HIP(vsk::sparse_jac(a.as<float>(), b.as<float>(), w, h, c.as<uint16_t>(), d.as<uint16_t>(), (int)nt, x.as<float>(),
+                           y.as<float>(), s));
+    VS_TRY(x.finish(s));
+    VS_TRY(y.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
+                      float* jy, int mem, void* stream) {
+    VS_ARG(in && lmx && lmy && jx && jy && w > 0 && h > 0 && stride >= w && ts >= 1 && ts <= 64);
+    VS_ARG(w <= 65535 && h <= 65535);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = (size_t)(w / ts) * (h / ts);
+    Staged a, x, y, p, q;
+    VS_TRY(a.in(in, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(x.out(lmx, nt * 4, mem));
+    VS_TRY(y.out(lmy, nt * 4, mem));
+    VS_TRY(p.out(jx, nt * 16, mem));
+    VS_TRY(q.out(jy, nt * 16, mem));
+    VS_HIP(vsk::keyframe(a.as<uint8_t>(), w, h, stride, ts, x.as<uint16_t>(), y.as<uint16_t>(), p.as<float>(),
+                         q.as<float>(), 1, 0, 0, 0, s));
+    VS_TRY(x.finish(s)); VS_TRY(y.finish(s)); VS_TRY(p.finish(s)); VS_TRY(q.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm, int tx,
+                       int ty, float A, float B, float TX, float TY, uint16_t* out, int mem, void* stream) {
+    VS_ARG(tmpl && key && lm && out && w > 0 && h > 0 && stride >= w && tx > 0 && ty > 0);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = (size_t)tx * ty;
+    Staged a, b, c, o;
+    VS_TRY(a.in(tmpl, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(b.in(key, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(c.in(lm, nt * 4, mem, s));
+    VS_TRY(o.out(out, nt * 2, mem));
+    VS_HIP(vsk::sparse_warpdiff(a.as<uint8_t>(), b.as<uint8_t>(), w, h, stride, c.as<uint16_t>(), (int)nt, A, B, TX, TY,
+                                o.as<uint16_t>(), s));
+    VS_TRY(o.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
+                  const uint16_t* sely, int ny, const float* jacx, const float* jacy, float A, float B, float TX, float TY,
+                  double* out4, int mem, void* stream) {
+    VS_ARG(tmpl && key && out4 && w > 0 && h > 0 && stride >= w && nx >= 0 && ny >= 0);
+    VS_ARG((nx == 0 || (selx && jacx)) && (ny == 0 || (sely && jacy)));
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    Staged a, b, sx, sy, jx, jy, o;
+    VS_TRY(a.in(tmpl, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(b.in(key, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(sx.in(selx, (size_t)nx * 4, mem, s));
+    VS_TRY(sy.in(sely, (size_t)ny * 4, mem, s));
+    VS_TRY(jx.in(jacx, (size_t)nx * 16, mem, s));
+    VS_TRY(jy.in(jacy, (size_t)ny * 16, mem, s));
+    VS_TRY(o.out(out4, 32, mem));
+    VS_HIP(vsk::sparse_ica(a.as<uint8_t>(), b.as<uint8_t>(), w, h, stride, sx.as<uint16_t>(), nx, sy.as<uint16_t>(), ny,
+                           jx.as<float>(), jy.as<float>(), A, B, TX, TY, o.as<double>(), s));
+    VS_TRY(o.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out, int ow,
+                  int oh, int mem, void* stream) {
+    VS_ARG(in && out && w > 0 && h > 0 && stride >= w && ow > 0 && oh > 0);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    Staged a, o;
+    VS_TRY(a.in(in, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(o.out(out, (size_t)ow * oh * 4, mem));
+    VS_HIP(vsk::image_warp(a.as<uint8_t>(), w, h, stride, A, B, TX, TY, o.as<float>(), ow, oh, s));
+    VS_TRY(o.finish(s));
+    return finish_host(mem, s);
+}
+
+static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
+                           int bits, const vs_transform* t, int mode, int border, int max_value, void* dst,
+                           size_t dst_fs, int dst_stride, bool f32out, int mem, hipStream_t s) {
+    VS_ARG(src && dst && t && n_frames >= 1 && w > 0 && h > 0 && channels >= 1 && channels <= 4);
+    VS_ARG(bits == 8 || bits == 16);
+    VS_ARG(src_stride >= w * channels && dst_stride >= w * channels);
+    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR);
+    VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
+    VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(w, h, dst_stride, channels)));
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    const size_t esz = bits / 8, osz = f32out ? 4 : esz;
+    std::vector<float> P((size_t)n_frames * 4);
+    for (int i = 0; i < n_frames; i++) vs_ul_params_warp(&t[i], w, h, &P[(size_t)i * 4]);
+    // stream-ordered allocation: freed on the stream after the kernel, so a VS_MEM_DEVICE call never syncs
+    float4* pdev = nullptr;
+    VS_HIP(hipMallocAsync((void**)&pdev, P.size() * 4, s));
+    struct Free { float4* p; hipStream_t s; ~Free() { (void)hipFreeAsync(p, s); } } free_params{pdev, s};
+    VS_HIP(hipMemcpyAsync(pdev, P.data(), P.size() * 4, hipMemcpyHostToDevice, s));
+    Staged a, o;
+    const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
+    const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(w, h, dst_stride, channels)) * osz;
+    VS_TRY(a.in(src, in_bytes, mem, s));
+    VS_TRY(o.out(dst, out_bytes, mem));
+    hipError_t e = hipErrorNotSupported;
+    if (bits == 8 && channels == 3 && !f32out && max_value == 255)
+        e = vsk::bgr_warp_u8c3(a.as<uint8_t>(), w, h, src_stride, pdev, mode, border, o.as<uint8_t>(),
+                               dst_stride, n_frames, src_fs, dst_fs, s);
+    if (e == hipErrorNotSupported)
+        e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
+                                  o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, s);
+    VS_HIP(e);
+    VS_TRY(o.finish(s));
+    return finish_host(mem, s);
+}
+
+int vs_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,
+                      int mode, int border, int max_value, void* dst, int dst_stride, int mem, void* stream) {
+    return bgr_warp_common(src, 0, 1, w, h, src_stride, channels, bits, t, mode, border, max_value, dst, 0, dst_stride,
+                           false, mem, (hipStream_t)stream);
+}
+
+int vs_bgr_image_warp_batch(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
+                            int bits, const vs_transform* t, int mode, int border, int max_value, void* dst,
+                            size_t dst_fs, int dst_stride, int mem, void* stream) {
+    return bgr_warp_common(src, src_fs, n_frames, w, h, src_stride, channels, bits, t, mode, border, max_value, dst,
+                           dst_fs, dst_stride, false, mem, (hipStream_t)stream);
+}
+
+int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,
+                          int mode, int border, float* dst, int dst_stride, int mem, void* stream) {
+    return bgr_warp_common(src, 0, 1, w, h, src_stride, channels, bits, t, mode, border, 0, dst, 0, dst_stride, true, mem,
+                           (hipStream_t)stream);
+}
+
+int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst, int dst_stride,
+                   int mem, void* stream) {
+    VS_ARG(src && dst && w > 0 && h > 0 && src_stride >= 3 * w && dst_stride >= w && (bits == 8 || bits == 16));
+    VS_ARG(shift_to_8 >= 0 && shift_to_8 <= 8);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    Staged a, o;
+    VS_TRY(a.in(src, img_span(w, h, src_stride, 3) * (bits / 8), mem, s));
+    VS_TRY(o.out(dst, img_span(w, h, dst_stride, 1), mem));
+    VS_HIP(vsk::bgr_to_gray(a.dev, w, h, src_stride, bits, shift_to_8, o.as<uint8_t>(), dst_stride, 1, 0, 0, s));
+    VS_TRY(o.finish(s));
+    return finish_host(mem, s);
+}
+
+}  // extern "C"

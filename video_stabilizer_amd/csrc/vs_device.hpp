@@ -1,0 +1,250 @@
+// vs_device.hpp -- device-side building blocks shared by the gfx950 kernels.
+//
+// Numerics contract (DESIGN.md "Numerics"): this translation unit is compiled with
+// -ffp-contract=off, so every fp32/fp64 expression below rounds exactly as written -- the
+// evaluation order is the one in the reference's generators.cpp (cited per function).
+// Where a fused multiply-add is wanted for speed it is spelled __builtin_fmaf explicitly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsd {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// generators.cpp:31-47: 6th-order even polynomial, Horner in x*x, zero outside |x| < 2.
+__device__ __forceinline__ float lanczos2(float x) {
+    float x2 = x * x;
+    float v = 0.000858519f;
+    v = -0.0158853f + v * x2;
+    v = 0.128693f + v * x2;
+    v = -0.583468f + v * x2;
+    v = 1.52229f + v * x2;
+    v = -2.05238f + v * x2;
+    v = 0.999861f + v * x2;
+    return fabsf(x) >= 2.0f ? 0.0f : v;
+}
+
+// The four live 1-D weights of the 5-tap window (generators.cpp:482-484 / 684-685).
+// Tap u = 0 sits at distance -2 - frac <= -2, so its weight is exactly 0 for every frac in
+// [0,1]; adding 0*v to the accumulators does not change them, so it is dropped.  Taps 1..4 are
+// kept (tap 4 is 0 only when frac == 0, tap 1 only when frac rounds to 1).
+__device__ __forceinline__ void lanczos_weights4(float frac, float w[4]) {
+    w[0] = lanczos2(-1.0f - frac);
+    w[1] = lanczos2(0.0f - frac);
+    w[2] = lanczos2(1.0f - frac);
+    w[3] = lanczos2(2.0f - frac);
+}
+
+// Lanczos2 sample of a single-channel u8 image with clamp-to-edge addressing:
+// generators.cpp:672-697 (sparse_warpdiff) == :469-498 (sparse_ica).  rx inner, ry outer,
+// separate num / den accumulators from 0, one IEEE divide.
+__device__ __forceinline__ float lanczos_sample_u8(const uint8_t* __restrict__ img, int w, int h, int stride,
+                                                   float Wx, float Wy) {
+    float flx = floorf(Wx), fly = floorf(Wy);
+    float frx = Wx - flx, fry = Wy - fly;
+    float wx[4], wy[4];
+    lanczos_weights4(frx, wx);
+    lanczos_weights4(fry, wy);
+    int ix = (int)flx, iy = (int)fly;
+    int xs[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) xs[r] = clampi(ix + r - 1, 0, w - 1);
+    float num = 0.0f, den = 0.0f;
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+        const uint8_t* row = img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride;
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+            float w2d = wx[rx] * wy[ry];
+            float val = (float)row[xs[rx]];
+            num = num + w2d * val;
+            den = den + w2d;
+        }
+    }
+    return num / den;
+}
+
+// imgproc.cpp:69-75 / 98-103: centre-based double transform -> float kernel arguments.
+// `w*0.5f` is a float in the reference, promoted to double inside the expression.
+__device__ __forceinline__ void ul_params_sparse(const double T[4], int w, int h, float p[4]) {
+    double hw = (double)((float)w * 0.5f), hh = (double)((float)h * 0.5f);
+    p[0] = (float)T[0];
+    p[1] = (float)T[1];
+    p[2] = (float)(T[2] - T[0] * hw + T[1] * hh);
+    p[3] = (float)(T[3] - T[1] * hw - T[0] * hh);
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_down(v, off, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = __shfl_down(v, off, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Sum K doubles over the whole block.  Every thread returns the same total: per-wave shuffle
+// tree, lane 0 of each wave parks its partials in LDS, one barrier, then every thread adds the
+// per-wave partials in wave order.  `lds` needs (blockDim.x/64)*K doubles and must not be in
+// use by anyone else until the NEXT call with a different buffer (callers ping-pong two).
+template <int K>
+__device__ __forceinline__ void block_sum(double v[K], double* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) lds[wave * K + k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = 0.0;
+        for (int wv = 0; wv < nw; wv++) s += lds[wv * K + k];
+        v[k] = s;
+    }
+}
+
+// ---- 4x4 symmetric eigen-solver + conditioned pseudo-inverse --------------------------------
+// alignment.cpp:555-583 uses cv::SVD and Mat::inv(DECOMP_SVD) on the symmetric PSD Hessian.
+// Singular values of such a matrix are its eigenvalues; a cyclic Jacobi sweep (fixed order
+// (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)) delivers them to ~1e-16 relative.
+__device__ __noinline__ void jacobi_eig4(const double* Hin, double* eval, double* V) {
+    double a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[i][j] = Hin[i * 4 + j]; V[i * 4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        double off = 0.0, diag = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            diag += a[i][i] * a[i][i];
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) off += a[i][j] * a[i][j];
+        }
+        if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double apq = a[p][q];
+                if (apq == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
+                    V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) eval[i] = a[i][i];
+}
+
+// cond = smax/(smin+1e-10); cond > 1e6 => H += 1e-6*smax*I (alignment.cpp:561-572);
+// Hinv = V diag(1/w) V^T dropping w <= 2*eps*sum(w) (OpenCV's DECOMP_SVD back-substitution).
+__device__ __noinline__ double condition_and_invert(double* H, double* Hinv) {
+    double ev[4], V[16];
+    jacobi_eig4(H, ev, V);
+    double max_sv = 0.0, min_sv = 1e300;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { double a = fabs(ev[i]); max_sv = fmax(max_sv, a); min_sv = fmin(min_sv, a); }
+    double cond = max_sv / (min_sv + 1e-10);
+    if (cond > 1e6) {
+        double lambda = 1e-6 * max_sv;
+#pragma unroll
+        for (int i = 0; i < 4; i++) H[i * 4 + i] += lambda;
+        jacobi_eig4(H, ev, V);
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) sum += fabs(ev[i]);
+    double thresh = 2.0 * 2.220446049250313e-16 * sum;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (fabs(ev[k]) > thresh) s += V[r * 4 + k] * V[c * 4 + k] / ev[k];
+            Hinv[r * 4 + c] = s;
+        }
+    return cond;
+}
+
+// ---- similarity-transform algebra in fp64 (imgproc.cpp:361-411) ------------------------------
+// compose: apply d first, then t.
+__device__ __forceinline__ void compose(const double d[4], const double t[4], double out[4]) {
+    double p1 = 1.0 + d[0], q1 = d[1], p2 = 1.0 + t[0], q2 = t[1];
+    double A3 = (p2 * p1 - q2 * q1) - 1.0;
+    double B3 = (p2 * q1 + q2 * p1);
+    double TX3 = p2 * d[2] - q2 * d[3] + t[2];
+    double TY3 = q2 * d[2] + p2 * d[3] + t[3];
+    out[0] = A3; out[1] = B3; out[2] = TX3; out[3] = TY3;
+}
+__device__ __forceinline__ void inverse(const double t[4], double out[4]) {
+    double p = 1.0 + t[0], q = t[1];
+    double denom = p * p + q * q;
+    out[0] = (p / denom) - 1.0;
+    out[1] = -q / denom;
+    out[2] = (-p * t[2] - q * t[3]) / denom;
+    out[3] = (q * t[2] - p * t[3]) / denom;
+}
+__device__ __forceinline__ void warp_center(const double t[4], double x, double y, double cx, double cy,
+                                            double& ox, double& oy) {
+    double px = x - cx, py = y - cy;
+    ox = (1 + t[0]) * px - t[1] * py + cx + t[2];
+    oy = t[1] * px + (1 + t[0]) * py + cy + t[3];
+}
+// the four corners (0,0),(w-1,0),(0,h-1),(w-1,h-1) about (w/2,h/2): alignment.cpp:587-593
+__device__ __forceinline__ void warp_corners(const double t[4], int w, int h, double c[8]) {
+    double cx = w * 0.5, cy = h * 0.5;
+    double x1 = (double)((float)w - 1.f), y1 = (double)((float)h - 1.f);
+    warp_center(t, 0.0, 0.0, cx, cy, c[0], c[1]);
+    warp_center(t, x1, 0.0, cx, cy, c[2], c[3]);
+    warp_center(t, 0.0, y1, cx, cy, c[4], c[5]);
+    warp_center(t, x1, y1, cx, cy, c[6], c[7]);
+}
+__device__ __forceinline__ double corner_move(const double a[8], const double b[8]) {
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double dx = a[2 * k] - b[2 * k], dy = a[2 * k + 1] - b[2 * k + 1];
+        m = fmax(m, sqrt(dx * dx + dy * dy));
+    }
+    return m;
+}
+
+}  // namespace vsd

@@ -1,0 +1,801 @@
+// vs_engine.hip -- engine level of the C ABI: VideoAligner (alignment.cpp:149-704) and
+// VideoStabilizer (stabilizer.cpp:9-117) as a device-resident, batched pipeline.
+//
+// Design (DESIGN.md "Engine"):
+//   * Gray pyramids of every frame of a batch live in HBM in one slab: slot s, level l at
+//     pyr + s*pyr_frame + L[l].img_off.  Slot 0 is the carry-over frame of the previous call,
+//     slots 1..n are this call's frames, so every stage is ONE launch over all frames.
+//   * Odd frames (in sequence order) are keyframes (alignment.hpp:65-66): their keypoint tables
+//     (arg-max coordinates + Jacobians, every level) are produced by the fused keyframe kernel.
+//   * Every alignment depends on exactly two consecutive frames, so all frame pairs of a batch are
+//     solved concurrently: per level one warpdiff launch, one selection step, one gather launch and
+//     one persistent Gauss-Newton launch in which a whole workgroup owns a pair and iterates on the
+//     device until it converges / diverges / runs out of iterations -- no host round trip per
+//     iteration (the reference makes one Halide call per iteration, alignment.cpp:600-668).
+//   * The transform algebra inside the loop is fp64 on the device, written exactly as imgproc.cpp.
+#include "vs_internal.hpp"
+#include "vs_kernels.hpp"
+#include "vs_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <thread>
+#include <vector>
+
+using vsi::set_error;
+using namespace vsd;
+
+#define VS_TRY(expr) do { int _r = (expr); if (_r < 0) return _r; } while (0)
+#define VS_ARG(cond) do { if (!(cond)) return set_error(VS_ERR_ARG, "bad argument: %s (%s)", #cond, __func__); } while (0)
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kGnThreads = 1024;
+
+struct LevelDims {
+    int w, h, ts, tx, ty, nt, nsel;
+    size_t img_off;   // bytes from the start of a frame's pyramid
+    size_t lm_off;    // u16 elements from the start of a frame's arg-max table (x-set); y-set follows at +2*nt
+    size_t jac_off;   // f32 elements from the start of a frame's Jacobian table (x-set); y-set at +4*nt
+};
+
+// per-pair solver state, device resident; copied back once per batch
+struct PairState {
+    double T[4];
+    int32_t status;        // 1 running/aligned, 0 failed
+    int32_t fail_reason;   // 2 max iters, 3 over displacement
+    int32_t fail_level;
+    int32_t pad;
+    int32_t iterations[kMaxLevels];
+    double condition[kMaxLevels];
+};
+
+struct PairDesc {
+    int32_t tmpl_slot;   // slot of the even (non-keyframe) frame: ScalePyramid[NonKeyframeIndex]
+    int32_t key_slot;    // slot of the odd (keyframe) frame:      ScalePyramid[KeyframeIndex]
+};
+
+struct GnParams {
+    double threshold, max_displacement;
+    int max_iters;
+};
+
+// ---- batched sparse_warpdiff: generators.cpp:646-700 for every (pair, set) ---------------------
+__global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __restrict__ states,
+                                                           const PairDesc* __restrict__ descs,
+                                                           const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                           size_t img_off, int w, int h,
+                                                           const uint16_t* __restrict__ lm_tab, size_t lm_frame,
+                                                           size_t lm_off, int nt, uint16_t* __restrict__ wd,
+                                                           size_t wd_pair) {
+    const int p = blockIdx.y, set = blockIdx.z;
+    const PairState& st = states[p];
+    if (st.status != 1) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    const PairDesc d = descs[p];
+    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
+    const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
+    const uint16_t* lm = lm_tab + (size_t)d.key_slot * lm_frame + lm_off + (size_t)set * 2 * nt;
+    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
+    float P[4];
+    ul_params_sparse(T, w, h, P);
+    int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
+    float ox = (float)tile_x, oy = (float)tile_y;
+    float Wx = (1.0f + P[0]) * ox - P[1] * oy + P[2];
+    float Wy = P[1] * ox + (1.0f + P[0]) * oy + P[3];
+    float v = lanczos_sample_u8(key, w, h, w, Wx, Wy);
+    float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
+    diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
+    wd[(size_t)p * wd_pair + (size_t)set * nt + i] = (uint16_t)diff;
+}
+
+// ---- gather of the selected keypoints + Jacobians: alignment.cpp:523-546 ------------------------
+// sel layout per pair: selx u16[2*nsel] | sely u16[2*nsel] ; jac layout: jacx f32[4*nsel] | jacy f32[4*nsel]
+__global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __restrict__ states,
+                                                            const PairDesc* __restrict__ descs,
+                                                            const uint16_t* __restrict__ lm_tab, size_t lm_frame,
+                                                            size_t lm_off, const float* __restrict__ jac_tab,
+                                                            size_t jac_frame, size_t jac_off, int nt, int nsel,
+                                                            const int32_t* __restrict__ idx, size_t idx_pair,
+                                                            uint16_t* __restrict__ sel, size_t sel_pair,
+                                                            float* __restrict__ seljac, size_t seljac_pair) {
+    const int p = blockIdx.y, set = blockIdx.z;
+    if (states[p].status != 1) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nsel) return;
+    const PairDesc d = descs[p];
+    const uint16_t* lm = lm_tab + (size_t)d.key_slot * lm_frame + lm_off + (size_t)set * 2 * nt;
+    const float* jac = jac_tab + (size_t)d.key_slot * jac_frame + jac_off + (size_t)set * 4 * nt;
+    const int t = idx[(size_t)p * idx_pair + (size_t)set * nt + j];
+    uint16_t* so = sel + (size_t)p * sel_pair + (size_t)set * 2 * nsel;
+    float* jo = seljac + (size_t)p * seljac_pair + (size_t)set * 4 * nsel;
+    so[j] = lm[t];
+    so[nsel + j] = lm[nt + t];
+#pragma unroll
+    for (int k = 0; k < 4; k++) jo[(size_t)k * nsel + j] = jac[(size_t)k * nt + t];
+}
+
+// ---- persistent Gauss-Newton level solver: alignment.cpp:548-688 --------------------------------
+// One workgroup per frame pair.  H = sum j j^T (fp64) -> cond / Tikhonov / pseudo-inverse once,
+// then up to max_iters iterations of { sparse_ica (generators.cpp:429-596) -> dt = Hinv b ->
+// delta.compose(T) -> corner test }, all without leaving the device.  Every thread carries the
+// (identical) fp64 transform state in registers; the only exchange per iteration is the block sum.
+__global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restrict__ states,
+                                                            const PairDesc* __restrict__ descs,
+                                                            const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                            size_t img_off, int w, int h, int nsel,
+                                                            const uint16_t* __restrict__ sel, size_t sel_pair,
+                                                            const float* __restrict__ seljac, size_t seljac_pair,
+                                                            int level, GnParams gp) {
+    __shared__ double red[2][(kGnThreads / 64) * 10];
+    __shared__ double s_hinv[17];
+    const int p = blockIdx.x;
+    PairState& st = states[p];
+    if (st.status != 1) return;   // uniform for the block
+    const PairDesc d = descs[p];
+    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
+    const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
+    const uint16_t* selx = sel + (size_t)p * sel_pair;
+    const uint16_t* sely = selx + 2 * (size_t)nsel;
+    const float* jacx = seljac + (size_t)p * seljac_pair;
+    const float* jacy = jacx + 4 * (size_t)nsel;
+
+    // Hessian (alignment.cpp:278-332): upper triangle of sum j j^T over both sets, in fp64
+    {
+        double hacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int set = 0; set < 2; set++) {
+            const float* jac = set == 0 ? jacx : jacy;
+            for (int r = threadIdx.x; r < nsel; r += kGnThreads) {
+                double j[4] = {(double)jac[r], (double)jac[nsel + r], (double)jac[2 * (size_t)nsel + r],
+                               (double)jac[3 * (size_t)nsel + r]};
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
+            }
+        }
+        block_sum<10>(hacc, red[0]);
+        if (threadIdx.x < 64) {   // one wave does the 4x4 eigen work; the others wait at the barrier
+            double H[16], Hinv[16];
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = a; b < 4; b++) { H[a * 4 + b] = hacc[k]; H[b * 4 + a] = hacc[k]; k++; }
+            double cond = condition_and_invert(H, Hinv);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) s_hinv[i] = Hinv[i];
+                s_hinv[16] = cond;
+            }
+        }
+        __syncthreads();
+    }
+    // Hinv and the level-start corners are block-uniform: they stay in LDS, not in 48 VGPRs
+    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
+    double c1[8];
+    warp_corners(T, w, h, c1);
+
+    const double scale = 1.0 / w;   // alignment.cpp:629
+    int iters = 0, fail = 0;
+    for (int iter = 0; iter < gp.max_iters; iter++) {
+        iters++;
+        float P[4];
+        ul_params_sparse(T, w, h, P);
+        const float A1 = 1.0f + P[0];
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int set = 0; set < 2; set++) {
+            const uint16_t* sl = set == 0 ? selx : sely;
+            const float* jac = set == 0 ? jacx : jacy;
+            double* a = acc + 4 * set;
+            for (int r = threadIdx.x; r < nsel; r += kGnThreads) {
+                int px = sl[r], py = sl[nsel + r];
+                float ox = (float)px, oy = (float)py;
+                float Wx = A1 * ox - P[1] * oy + P[2];
+                float Wy = P[1] * ox + A1 * oy + P[3];
+                float warped = lanczos_sample_u8(key, w, h, w, Wx, Wy);
+                float tv = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
+                float residual = tv - warped;
+#pragma unroll
+                for (int c = 0; c < 4; c++) a[c] += (double)(jac[(size_t)c * nsel + r] * residual);
+            }
+        }
+        block_sum<8>(acc, red[(iter & 1) ^ 1]);
+        double b[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) b[c] = (acc[c] + acc[4 + c]) * 0.5f;   // generators.cpp:595
+        double dt[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += s_hinv[r * 4 + k] * b[k];
+            dt[r] = s;
+        }
+        double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
+        double Tn[4];
+        compose(delta, T, Tn);   // alignment.cpp:639
+#pragma unroll
+        for (int i = 0; i < 4; i++) T[i] = Tn[i];
+        double c2[8];
+        warp_corners(T, w, h, c2);
+        double disp12 = corner_move(c2, c1);
+#pragma unroll
+        for (int i = 0; i < 8; i++) c1[i] = c2[i];
+        if (disp12 < gp.threshold) break;
+        if (iter >= gp.max_iters - 1) { fail = 2; break; }
+    }
+    if (!fail) {
+        double c0[8];
+        double T0[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};   // state is only rewritten below
+        warp_corners(T0, w, h, c0);
+        double disp01 = corner_move(c0, c1);
+        if (disp01 > gp.max_displacement) fail = 3;
+    }
+    if (!fail && level > 0) { T[2] *= 2.0; T[3] *= 2.0; }   // alignment.cpp:683-687
+    if (threadIdx.x == 0) {
+        st.iterations[level] = iters;
+        st.condition[level] = s_hinv[16];
+        if (fail) { st.status = 0; st.fail_reason = fail; st.fail_level = level; }
+        st.T[0] = T[0]; st.T[1] = T[1]; st.T[2] = T[2]; st.T[3] = T[3];
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// VideoAligner
+// =================================================================================================
+struct vs_aligner {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vs_aligner_params params;
+    int select_mode = VS_SELECT_STL_HOST;
+
+    // sequence state (alignment.hpp:61-70)
+    int W = -1, H = -1, fmt = -1;
+    int levels = 0;
+    LevelDims L[kMaxLevels];
+    long long seq = 0;          // frames consumed since (re)initialisation
+    size_t pyr_frame = 0, lm_frame = 0, jac_frame = 0;   // bytes / u16 elements / f32 elements per slot
+    int nt_max = 0;
+
+    // device storage
+    int cap = 0;                // frames per internal chunk (slots = cap + 1)
+    uint8_t* pyr = nullptr;
+    uint16_t* lm = nullptr;
+    float* jac = nullptr;
+    PairState* states = nullptr;
+    PairDesc* descs = nullptr;
+    uint16_t* wd = nullptr;
+    int32_t* idx = nullptr;
+    uint16_t* sel = nullptr;
+    float* seljac = nullptr;
+    void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area
+    // pinned host mirrors
+    uint16_t* h_wd = nullptr;
+    int32_t* h_idx = nullptr;
+    PairState* h_states = nullptr;
+
+    std::vector<vs_align_info> info;   // last call
+    int last_n = 0;
+
+    ~vs_aligner() { release(); if (stream) (void)hipStreamDestroy(stream); }
+    void release();
+    int configure(int w, int h, int format, const vs_aligner_params& p);
+    int ensure_capacity(int n);
+    int run_chunk(const void* frames, size_t frame_stride, int n, int stride, int mem, const vs_aligner_params& p,
+                  vs_transform* out, int32_t* status, vs_align_info* infos);
+    int select_host(int n_pairs, const LevelDims& l);
+};
+
+void vs_aligner::release() {
+    void* d[] = {pyr, lm, jac, states, descs, wd, idx, sel, seljac, stage};
+    for (void* p : d) if (p) (void)hipFree(p);
+    void* hp[] = {h_wd, h_idx, h_states};
+    for (void* p : hp) if (p) (void)hipHostFree(p);
+    pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; idx = nullptr;
+    sel = nullptr; seljac = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
+    cap = 0;
+}
+
+// alignment.cpp:155-204: (re)initialisation on first use or size change
+int vs_aligner::configure(int w, int h, int format, const vs_aligner_params& p) {
+    int lv = 0, ww = w, hh = h;
+    do { lv++; ww /= 2; hh /= 2; } while (ww >= p.pyramid_min_width && hh >= p.pyramid_min_height);
+    // PhaseLevel = 2 is indexed unconditionally in the reference (alignment.cpp:227): < 3 levels is UB there
+    if (lv < 3 || lv > kMaxLevels)
+        return set_error(VS_ERR_UNSUPPORTED, "%dx%d with pyramid_min %dx%d gives %d pyramid levels; 3..%d supported", w, h,
+                         p.pyramid_min_width, p.pyramid_min_height, lv, kMaxLevels);
+    if (w > 65535 || h > 65535) return set_error(VS_ERR_UNSUPPORTED, "frame larger than 65535 (u16 keypoints)");
+    release();
+    W = w; H = h; fmt = format; levels = lv; seq = 0;
+    size_t img = 0, lmo = 0, jo = 0;
+    nt_max = 0;
+    ww = w; hh = h;
+    for (int i = 0; i < lv; i++) {
+        if (i > 0) { ww /= 2; hh /= 2; }
+        LevelDims& l = L[i];
+        l.w = ww; l.h = hh;
+        l.ts = vs_tile_size(ww, hh);
+        l.tx = ww / l.ts; l.ty = hh / l.ts; l.nt = l.tx * l.ty;
+        l.nsel = (int)static_cast<size_t>((size_t)l.nt * p.smallest_fraction);   // alignment.cpp:464-465
+        l.img_off = img; img += ((size_t)ww * hh + 255) & ~(size_t)255;
+        l.lm_off = lmo; lmo += (size_t)l.nt * 4;     // x-set (2*nt) + y-set (2*nt)
+        l.jac_off = jo; jo += (size_t)l.nt * 8;      // x-set (4*nt) + y-set (4*nt)
+        nt_max = std::max(nt_max, l.nt);
+        if (l.nt < 1) return set_error(VS_ERR_UNSUPPORTED, "level %d (%dx%d) has no tiles", i, ww, hh);
+    }
+    pyr_frame = img; lm_frame = (lmo + 63) & ~(size_t)63; jac_frame = (jo + 63) & ~(size_t)63;
+    return VS_OK;
+}
+
+int vs_aligner::ensure_capacity(int n) {
+    if (n <= cap) return VS_OK;
+    // keep the carry-over frame (slot `cap_old_last`) alive across a regrow: it is always moved to slot 0
+    // at the start of run_chunk, so here it already sits wherever the previous chunk left it; copy it out.
+    const int newcap = n;
+    const size_t slots = (size_t)newcap + 1;
+    uint8_t* npyr = nullptr; uint16_t* nlm = nullptr; float* njac = nullptr;
+    VS_HIP(hipMalloc((void**)&npyr, slots * pyr_frame));
+    VS_HIP(hipMalloc((void**)&nlm, slots * lm_frame * 2));
+    VS_HIP(hipMalloc((void**)&njac, slots * jac_frame * 4));
+    if (pyr && seq > 0) {
+        // previous chunk's last frame is in slot last_n of the old slabs
+        VS_HIP(hipMemcpyAsync(npyr, pyr + (size_t)last_n * pyr_frame, pyr_frame, hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipMemcpyAsync(nlm, lm + (size_t)last_n * lm_frame, lm_frame * 2, hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipMemcpyAsync(njac, jac + (size_t)last_n * jac_frame, jac_frame * 4, hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipStreamSynchronize(stream));
+        last_n = 0;   // carry-over now lives in slot 0 of the new slabs
+    }
+    void* old[] = {pyr, lm, jac, states, descs, wd, idx, sel, seljac};
+    for (void* p : old) if (p) (void)hipFree(p);
+    void* oldh[] = {h_wd, h_idx, h_states};
+    for (void* p : oldh) if (p) (void)hipHostFree(p);
+    pyr = npyr; lm = nlm; jac = njac;
+    VS_HIP(hipMalloc((void**)&states, sizeof(PairState) * newcap));
+    VS_HIP(hipMalloc((void**)&descs, sizeof(PairDesc) * newcap));
+    VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
+    VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
+    VS_HIP(hipMalloc((void**)&sel, (size_t)newcap * 4 * nt_max * sizeof(uint16_t)));
+    VS_HIP(hipMalloc((void**)&seljac, (size_t)newcap * 8 * nt_max * sizeof(float)));
+    VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
+    VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
+    VS_HIP(hipHostMalloc((void**)&h_states, sizeof(PairState) * newcap));
+    cap = newcap;
+    return VS_OK;
+}
+
+// alignment.cpp:435-492: flatten row-major, std::nth_element on abs_delta, keep the first n.
+// This IS the reference's selection (same STL call on the same element type and order), run on the
+// host for every (pair, set) of the batch, spread over a few threads.
+int vs_aligner::select_host(int n_pairs, const LevelDims& l) {
+    struct DeltaPixel { uint16_t abs_delta, tile_x, tile_y; };   // alignment.hpp:84-87
+    const int nt = l.nt, nsel = l.nsel, tx = l.tx;
+    const size_t wd_pair = (size_t)2 * nt_max;
+    auto work = [&](int begin, int end) {
+        std::vector<DeltaPixel> v;
+        for (int job = begin; job < end; job++) {
+            const int p = job >> 1, set = job & 1;
+            if (h_states[p].status != 1) continue;
+            const uint16_t* src = h_wd + (size_t)p * wd_pair + (size_t)set * nt;
+            v.clear();
+            v.reserve(nt);
+            for (int j = 0; j < l.ty; j++)
+                for (int k = 0; k < tx; k++)
+                    v.push_back(DeltaPixel{src[(size_t)j * tx + k], (uint16_t)k, (uint16_t)j});
+            std::nth_element(v.begin(), v.begin() + nsel, v.end(),
+                             [](const DeltaPixel& a, const DeltaPixel& b) { return a.abs_delta < b.abs_delta; });
+            int32_t* dst = h_idx + (size_t)p * wd_pair + (size_t)set * nt;
+            for (int j = 0; j < nsel; j++) dst[j] = (int32_t)v[j].tile_y * tx + v[j].tile_x;
+        }
+    };
+    const int jobs = n_pairs * 2;
+    int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nthreads = std::min(nthreads, std::max(1, jobs / 8));
+    if (nthreads <= 1) {
+        work(0, jobs);
+    } else {
+        std::vector<std::thread> th;
+        const int per = (jobs + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; t++) {
+            int b = t * per, e = std::min(jobs, b + per);
+            if (b < e) th.emplace_back(work, b, e);
+        }
+        for (auto& t : th) t.join();
+    }
+    return VS_OK;
+}
+
+// One chunk (n <= cap frames): the result of n successive AlignNextFrame calls.
+int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int stride, int mem,
+                          const vs_aligner_params& p, vs_transform* out, int32_t* status, vs_align_info* infos) {
+    hipStream_t s = stream;
+    const int ch = fmt == VS_FMT_GRAY8 ? 1 : 3;
+    const size_t esz = fmt == VS_FMT_BGR16 ? 2 : 1;
+
+    // carry-over: the previous call's last frame (pyramid + keyframe tables) moves to slot 0
+    if (seq > 0 && last_n != 0) {
+        VS_HIP(hipMemcpyAsync(pyr, pyr + (size_t)last_n * pyr_frame, pyr_frame, hipMemcpyDeviceToDevice, s));
+        VS_HIP(hipMemcpyAsync(lm, lm + (size_t)last_n * lm_frame, lm_frame * 2, hipMemcpyDeviceToDevice, s));
+        VS_HIP(hipMemcpyAsync(jac, jac + (size_t)last_n * jac_frame, jac_frame * 4, hipMemcpyDeviceToDevice, s));
+    }
+
+    // ---- ComputePyramid (alignment.cpp:149-235) for all n frames ------------------------------
+    const void* dframes = frames;
+    if (mem == VS_MEM_HOST) {
+        const size_t bytes = ((size_t)(n - 1) * frame_stride + (size_t)(H - 1) * stride + (size_t)W * ch) * esz;
+        if (bytes > stage_bytes) {
+            if (stage) (void)hipFree(stage);
+            stage = nullptr; stage_bytes = 0;
+            VS_HIP(hipMalloc(&stage, bytes));
+            stage_bytes = bytes;
+        }
+        VS_HIP(hipMemcpyAsync(stage, frames, bytes, hipMemcpyHostToDevice, s));
+        dframes = stage;
+    }
+    uint8_t* slot1 = pyr + pyr_frame;   // level 0 of slot 1
+    if (fmt == VS_FMT_GRAY8) {
+        for (int i = 0; i < n; i++)
+            VS_HIP(hipMemcpy2DAsync(slot1 + (size_t)i * pyr_frame, W, (const uint8_t*)dframes + (size_t)i * frame_stride,
+                                    stride, W, H, hipMemcpyDeviceToDevice, s));
+    } else {
+        VS_HIP(vsk::bgr_to_gray(dframes, W, H, stride, fmt == VS_FMT_BGR8 ? 8 : 16, fmt == VS_FMT_BGR8 ? 0 : 2, slot1, W, n,
+                                frame_stride, pyr_frame, s));
+    }
+    for (int l = 1; l < levels; l++)
+        VS_HIP(vsk::pyr_down(slot1 + L[l - 1].img_off, L[l - 1].w, L[l - 1].h, L[l - 1].w, slot1 + L[l].img_off, L[l].w,
+                             L[l].h, L[l].w, n, pyr_frame, pyr_frame, s));
+
+    // ---- ComputeKeyFrame (alignment.cpp:237-276) for the odd frames of the sequence -----------
+    // frame i of this chunk has sequence index g = seq + i and sits in slot i + 1
+    const int first_odd = (seq & 1) ? 0 : 1;   // smallest i with (seq + i) odd
+    const int n_odd = first_odd < n ? (n - first_odd + 1) / 2 : 0;
+    if (n_odd > 0) {
+        const size_t so = (size_t)(first_odd + 1);
+        for (int l = 0; l < levels; l++) {
+            uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
+            float* jx = jac + so * jac_frame + L[l].jac_off;
+            VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
+                                 lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
+                                 2 * lm_frame, 2 * jac_frame, s));
+        }
+    }
+
+    // ---- frame pairs --------------------------------------------------------------------------
+    // pair for chunk frame i exists when g = seq + i >= 1: frames (g-1, g) = slots (i, i+1)
+    const int first_pair = seq == 0 ? 1 : 0;
+    const int n_pairs = n - first_pair;
+    for (int i = 0; i < n; i++) {
+        memset(&infos[i], 0, sizeof(vs_align_info));
+        infos[i].levels = levels;
+        out[i] = vs_transform{0, 0, 0, 0};
+        status[i] = 0;
+    }
+    if (first_pair == 1) infos[0].fail_reason = 1;   // alignment.cpp:231-234: very first frame
+    if (n_pairs > 0) {
+        std::vector<PairDesc> hd(n_pairs);
+        for (int q = 0; q < n_pairs; q++) {
+            const int i = first_pair + q;
+            const long long g = seq + i;
+            const int cur = i + 1, prev = i;
+            if (g & 1) { hd[q].key_slot = cur; hd[q].tmpl_slot = prev; }
+            else { hd[q].key_slot = prev; hd[q].tmpl_slot = cur; }
+        }
+        for (int q = 0; q < n_pairs; q++) {
+            memset(&h_states[q], 0, sizeof(PairState));
+            h_states[q].status = 1;
+        }
+        VS_HIP(hipMemcpyAsync(descs, hd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
+        VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
+        VS_HIP(hipStreamSynchronize(s));   // hd goes out of scope; also orders the pinned h_states reuse below
+
+        const size_t wd_pair = (size_t)2 * nt_max, sel_pair = (size_t)4 * nt_max, seljac_pair = (size_t)8 * nt_max;
+        GnParams gp{p.threshold, p.max_displacement, p.max_iters};
+        for (int l = levels - 1; l >= 0; l--) {
+            const LevelDims& ld = L[l];
+            hipLaunchKernelGGL(vs_k_warpdiff_batch, dim3((ld.nt + 255) / 256, n_pairs, 2), dim3(256), 0, s, states, descs, pyr,
+                               pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, ld.nt, wd, wd_pair);
+            VS_HIP(hipGetLastError());
+            if (select_mode == VS_SELECT_STL_HOST) {
+                VS_HIP(hipMemcpyAsync(h_wd, wd, (size_t)n_pairs * wd_pair * 2, hipMemcpyDeviceToHost, s));
+                VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+                VS_HIP(hipStreamSynchronize(s));
+                VS_TRY(select_host(n_pairs, ld));
+                VS_HIP(hipMemcpyAsync(idx, h_idx, (size_t)n_pairs * wd_pair * 4, hipMemcpyHostToDevice, s));
+            } else {
+                return set_error(VS_ERR_UNSUPPORTED, "VS_SELECT_DEVICE is not built yet");
+            }
+            if (ld.nsel > 0) {
+                hipLaunchKernelGGL(vs_k_gather_selected, dim3((ld.nsel + 255) / 256, n_pairs, 2), dim3(256), 0, s, states,
+                                   descs, lm, lm_frame, ld.lm_off, jac, jac_frame, ld.jac_off, ld.nt, ld.nsel, idx, wd_pair,
+                                   sel, sel_pair, seljac, seljac_pair);
+                VS_HIP(hipGetLastError());
+            }
+            hipLaunchKernelGGL(vs_k_gn_level, dim3(n_pairs), dim3(kGnThreads), 0, s, states, descs, pyr, pyr_frame, ld.img_off,
+                               ld.w, ld.h, ld.nsel, sel, sel_pair, seljac, seljac_pair, l, gp);
+            VS_HIP(hipGetLastError());
+        }
+        VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < n_pairs; q++) {
+            const int i = first_pair + q;
+            const PairState& st = h_states[q];
+            vs_align_info& inf = infos[i];
+            inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
+            for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; }
+            if (st.status == 1) {
+                vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
+                if (((seq + i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
+                out[i] = t;
+                status[i] = 1;
+            }
+        }
+    } else {
+        VS_HIP(hipStreamSynchronize(s));
+    }
+    seq += n;
+    last_n = n;
+    return VS_OK;
+}
+
+extern "C" {
+
+vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
+    if (!vsi::device_ready()) return nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        set_error(VS_ERR_ARG, "device %d out of range (%d devices)", device, n);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { set_error(VS_ERR_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+    vs_aligner* a = new vs_aligner();
+    a->device = device;
+    if (params) a->params = *params; else vs_aligner_params_default(&a->params);
+    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error(VS_ERR_HIP, "hipStreamCreate failed");
+        delete a;
+        return nullptr;
+    }
+    return a;
+}
+
+void vs_aligner_destroy(vs_aligner* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    delete a;
+}
+
+int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
+    VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE));
+    a->select_mode = mode;
+    return VS_OK;
+}
+
+int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
+                           int format, int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status) {
+    VS_ARG(a && frames && out && status && n >= 1 && w >= 8 && h >= 8);
+    VS_ARG(format == VS_FMT_GRAY8 || format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
+    const int ch = format == VS_FMT_GRAY8 ? 1 : 3;
+    VS_ARG(stride >= w * ch);
+    VS_ARG(n == 1 || frame_stride >= (size_t)(h - 1) * stride + (size_t)w * ch);
+    const vs_aligner_params& p = params ? *params : a->params;
+    if (p.phase_correlate) return set_error(VS_ERR_UNSUPPORTED, "phase_correlate is not built (off by default in the reference)");
+    VS_ARG(p.max_iters >= 1 && p.smallest_fraction > 0.0f && p.smallest_fraction <= 1.0f);
+    VS_HIP(hipSetDevice(a->device));
+    if (a->W != w || a->H != h || a->fmt != format) VS_TRY(a->configure(w, h, format, p));   // alignment.cpp:155
+    // nsel follows the *current* params like the reference (alignment.cpp:464-465)
+    for (int l = 0; l < a->levels; l++)
+        a->L[l].nsel = (int)static_cast<size_t>((size_t)a->L[l].nt * p.smallest_fraction);
+    a->info.assign(n, vs_align_info{});
+    const size_t esz = format == VS_FMT_BGR16 ? 2 : 1;
+    // chunking bounds device memory: at most ~6 GiB of pyramids per handle
+    const int max_chunk = (int)std::max<size_t>(2, std::min<size_t>(1024, ((size_t)6 << 30) / std::max<size_t>(1, a->pyr_frame)));
+    int aligned = 0;
+    for (int off = 0; off < n; off += max_chunk) {
+        const int m = std::min(max_chunk, n - off);
+        VS_TRY(a->ensure_capacity(m));
+        const uint8_t* base = (const uint8_t*)frames + (size_t)off * frame_stride * esz;
+        VS_TRY(a->run_chunk(base, frame_stride, m, stride, mem, p, out + off, status + off, a->info.data() + off));
+    }
+    for (int i = 0; i < n; i++) aligned += status[i];
+    return aligned;
+}
+
+int vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
+                          const vs_aligner_params* params, vs_transform* out) {
+    int32_t st = 0;
+    int r = vs_aligner_align_batch(a, frame, 0, 1, w, h, stride, format, mem, params, out, &st);
+    if (r < 0) return r;
+    return st;
+}
+
+int vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info) {
+    VS_ARG(a && info && i >= 0 && i < (int)a->info.size());
+    *info = a->info[i];
+    return VS_OK;
+}
+
+int vs_aligner_level_dims(const vs_aligner* a, int level, int* w, int* h, int* tx, int* ty, int* ts) {
+    VS_ARG(a && level >= 0 && level < a->levels);
+    const LevelDims& l = a->L[level];
+    if (w) *w = l.w; if (h) *h = l.h; if (tx) *tx = l.tx; if (ty) *ty = l.ty; if (ts) *ts = l.ts;
+    return VS_OK;
+}
+
+// frame i of the most recent chunk lives in slot i+1 (only valid for calls that fit one chunk)
+int vs_aligner_read_level_image(const vs_aligner* a, int i, int level, uint8_t* out) {
+    VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n);
+    const LevelDims& l = a->L[level];
+    VS_HIP(hipSetDevice(a->device));
+    VS_HIP(hipMemcpy(out, a->pyr + (size_t)(i + 1) * a->pyr_frame + l.img_off, (size_t)l.w * l.h, hipMemcpyDeviceToHost));
+    return VS_OK;
+}
+int vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set, uint16_t* out) {
+    VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
+    const LevelDims& l = a->L[level];
+    VS_HIP(hipSetDevice(a->device));
+    VS_HIP(hipMemcpy(out, a->lm + (size_t)(i + 1) * a->lm_frame + l.lm_off + (size_t)set * 2 * l.nt, (size_t)l.nt * 4,
+                     hipMemcpyDeviceToHost));
+    return VS_OK;
+}
+int vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out) {
+    VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
+    const LevelDims& l = a->L[level];
+    VS_HIP(hipSetDevice(a->device));
+    VS_HIP(hipMemcpy(out, a->jac + (size_t)(i + 1) * a->jac_frame + l.jac_off + (size_t)set * 4 * l.nt, (size_t)l.nt * 16,
+                     hipMemcpyDeviceToHost));
+    return VS_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// VideoStabilizer (stabilizer.cpp:3-117): scalar bookkeeping on the host, frames stay in HBM
+// =================================================================================================
+struct vs_stabilizer {
+    vs_stabilizer_params params;
+    vs_aligner* aligner = nullptr;
+    vs_smoother* smoother = nullptr;
+    int frame_index = 0;
+    std::deque<vs_transform> measurements;
+    std::deque<void*> frames;      // device copies of the buffered input frames (stabilizer.cpp:15)
+    std::vector<void*> pool;       // recycled frame buffers
+    size_t frame_bytes = 0;
+    void* warped = nullptr; size_t warped_bytes = 0;
+    vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
+    int last_success = 0;
+    int w = 0, h = 0, fmt = -1;
+};
+
+extern "C" {
+
+vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int device) {
+    vs_stabilizer_params p;
+    if (params) p = *params; else vs_stabilizer_params_default(&p);
+    vs_aligner* a = vs_aligner_create(&p.aligner, device);
+    if (!a) return nullptr;
+    vs_stabilizer* s = new vs_stabilizer();
+    s->params = p;
+    s->aligner = a;
+    s->smoother = vs_smoother_create(p.lag, p.smoother_memory, p.lambda);   // stabilizer.cpp:4
+    return s;
+}
+
+void vs_stabilizer_destroy(vs_stabilizer* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->aligner->device);
+    for (void* p : s->frames) (void)hipFree(p);
+    for (void* p : s->pool) (void)hipFree(p);
+    if (s->warped) (void)hipFree(s->warped);
+    vs_smoother_destroy(s->smoother);
+    vs_aligner_destroy(s->aligner);
+    delete s;
+}
+
+int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem, void* out,
+                          int* out_w, int* out_h) {
+    VS_ARG(s && frame && out && out_w && out_h);
+    VS_ARG(format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
+    VS_ARG(stride >= 3 * w);
+    const int crop = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
+    VS_ARG(w > 2 * crop && h > 2 * crop);
+    vs_aligner* a = s->aligner;
+    VS_HIP(hipSetDevice(a->device));
+    hipStream_t st = a->stream;
+    const size_t esz = format == VS_FMT_BGR8 ? 1 : 2;
+    const size_t fbytes = (size_t)w * h * 3 * esz;
+    if (s->w != w || s->h != h || s->fmt != format) {
+        // a size change restarts the aligner (alignment.cpp:155); buffered frames of the old size are dropped
+        for (void* p : s->frames) (void)hipFree(p);
+        for (void* p : s->pool) (void)hipFree(p);
+        s->frames.clear(); s->pool.clear(); s->measurements.clear();
+        s->w = w; s->h = h; s->fmt = format; s->frame_bytes = fbytes;
+    }
+    ++s->frame_index;
+
+    // stabilizer.cpp:15: keep a private (device) copy of the frame, densely packed
+    void* copy = nullptr;
+    if (!s->pool.empty()) { copy = s->pool.back(); s->pool.pop_back(); }
+    else VS_HIP(hipMalloc(&copy, fbytes));
+    VS_HIP(hipMemcpy2DAsync(copy, (size_t)w * 3 * esz, frame, (size_t)stride * esz, (size_t)w * 3 * esz, h,
+                            mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    s->frames.push_back(copy);
+
+    // stabilizer.cpp:18-19 (aligning from the dense device copy: same bytes)
+    vs_transform meas{0, 0, 0, 0};
+    int r = vs_aligner_align_next(a, copy, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner, &meas);
+    if (r < 0) return r;
+    const bool success = r == 1;
+    s->last_meas = meas; s->last_success = success ? 1 : 0;
+
+    vs_transform earliest_smoothed{0, 0, 0, 0};
+    if (s->params.enable_smoother) (void)vs_smoother_update(s->smoother, &meas, &earliest_smoothed);   // :35
+    if (!success) s->accum = vs_transform{0, 0, 0, 0};                                                  // :39-41
+    s->measurements.push_back(meas);                                                                   // :44
+    int produced = 0;
+    if (s->measurements.size() > (size_t)s->params.lag) {                                              // :48
+        vs_transform earliest = s->measurements.front();
+        s->measurements.pop_front();
+        vs_transform jitter;
+        if (s->params.enable_smoother) {
+            vs_transform inv = vs_transform_inverse(&earliest_smoothed);
+            jitter = vs_transform_compose(&earliest, &inv);                                            // :60
+        } else {
+            jitter = earliest;
+        }
+        vs_transform na = vs_transform_compose(&s->accum, &jitter);                                    // :66
+        const double disp = vs_transform_max_corner_displacement(&na, w, h);                           // :69-70
+        double decay;
+        if (disp > s->params.max_disp) {
+            decay = s->params.max_decay;
+        } else if (disp > s->params.min_disp) {
+            double f = (disp - s->params.min_disp) / (s->params.max_disp - s->params.min_disp);
+            f = std::max(0.0, std::min(1.0, f));
+            decay = s->params.min_decay * (1.0 - f) + s->params.max_decay * f;
+        } else {
+            decay = s->params.min_decay;
+        }
+        na.TX *= decay; na.TY *= decay; na.A *= decay; na.B *= decay;                                  // :88-91
+        s->accum = na;
+        if (!s->frames.empty()) {
+            void* src = s->frames.front();
+            s->frames.pop_front();
+            // :97-99: warpBySimilarityTransform(frame, accum^-1); cv::warpAffine without WARP_INVERSE_MAP
+            // inverts the matrix it is given (imgproc.cpp:472), so the sampling map is (accum^-1)^-1.
+            vs_transform correction = vs_transform_inverse(&na);
+            vs_transform sampling = vs_transform_inverse(&correction);
+            if (s->warped_bytes < fbytes) {
+                if (s->warped) (void)hipFree(s->warped);
+                s->warped = nullptr; s->warped_bytes = 0;
+                VS_HIP(hipMalloc(&s->warped, fbytes));
+                s->warped_bytes = fbytes;
+            }
+            int wr = vs_bgr_image_warp(src, w, h, w * 3, 3, (int)esz * 8, &sampling, s->params.warp_mode,
+                                       s->params.warp_border, esz == 1 ? 255 : 65535, s->warped, w * 3, VS_MEM_DEVICE, st);
+            if (wr < 0) return wr;
+            const int ow = w - 2 * crop, oh = h - 2 * crop;                                            // :102-109
+            VS_HIP(hipMemcpy2DAsync(out, (size_t)ow * 3 * esz, (const uint8_t*)s->warped + ((size_t)crop * w + crop) * 3 * esz,
+                                    (size_t)w * 3 * esz, (size_t)ow * 3 * esz, oh,
+                                    mem == VS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+            VS_HIP(hipStreamSynchronize(st));
+            s->pool.push_back(src);
+            *out_w = ow; *out_h = oh;
+            produced = 1;
+        }
+    }
+    return produced;
+}
+
+void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success) {
+    if (last_meas) *last_meas = s->last_meas;
+    if (accum) *accum = s->accum;
+    if (last_success) *last_success = s->last_success;
+}
+
+}  // extern "C"

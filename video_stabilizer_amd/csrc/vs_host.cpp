@@ -1,0 +1,198 @@
+// vs_host.cpp -- the host-only part of the C ABI: scalar algebra the reference also keeps on the
+// CPU (SimilarityTransform, tile-size rule, L1 smoother).  No device calls in this file.
+#include "vs_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+namespace vsi {
+static thread_local char g_err[512] = "";
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace vsi
+
+extern "C" {
+
+const char* vs_last_error(void) { return vsi::g_err; }
+const char* vs_version(void) { return "video_stabilizer_amd 0.1 (gfx950)"; }
+
+// alignment.hpp:5-41
+void vs_aligner_params_default(vs_aligner_params* p) {
+    p->phase_correlate = 0;
+    p->phase_correlate_threshold = 0.5;
+    p->threshold = 0.02;
+    p->smallest_fraction = 0.8f;
+    p->max_iters = 64;
+    p->pyramid_min_width = 20;
+    p->pyramid_min_height = 20;
+    p->max_displacement = 10.0;
+}
+// stabilizer.hpp:13-30
+void vs_stabilizer_params_default(vs_stabilizer_params* p) {
+    vs_aligner_params_default(&p->aligner);
+    p->lag = 10;
+    p->smoother_memory = 5;
+    p->lambda = 4.0;
+    p->enable_smoother = 1;
+    p->crop_pixels = 32;
+    p->min_disp = 48.0;
+    p->max_disp = 64.0;
+    p->min_decay = 0.9;
+    p->max_decay = 0.7;
+    p->warp_mode = VS_WARP_LANCZOS2;
+    p->warp_border = VS_BORDER_CONSTANT;
+}
+
+// imgproc.cpp:333-359
+vs_transform vs_transform_inverse(const vs_transform* t) {
+    const double p = 1.0 + t->A, q = t->B;
+    const double denom = p * p + q * q;
+    vs_transform inv;
+    inv.A = (p / denom) - 1.0;
+    inv.B = -q / denom;
+    inv.TX = (-p * t->TX - q * t->TY) / denom;
+    inv.TY = (q * t->TX - p * t->TY) / denom;
+    return inv;
+}
+
+// imgproc.cpp:361-387: result(p) = t2(t1(p))
+vs_transform vs_transform_compose(const vs_transform* t1, const vs_transform* t2) {
+    const double p1 = 1.0 + t1->A, q1 = t1->B;
+    const double p2 = 1.0 + t2->A, q2 = t2->B;
+    vs_transform t3;
+    t3.A = (p2 * p1 - q2 * q1) - 1.0;
+    t3.B = (p2 * q1 + q2 * p1);
+    t3.TX = p2 * t1->TX - q2 * t1->TY + t2->TX;
+    t3.TY = q2 * t1->TX + p2 * t1->TY + t2->TY;
+    return t3;
+}
+
+// imgproc.cpp:389-394
+vs_point vs_transform_warp(const vs_transform* t, vs_point p) {
+    vs_point o;
+    o.x = (1 + t->A) * p.x - t->B * p.y + t->TX;
+    o.y = t->B * p.x + (1 + t->A) * p.y + t->TY;
+    return o;
+}
+
+// imgproc.cpp:401-411
+vs_point vs_transform_warp_center(const vs_transform* t, vs_point p, double cx, double cy) {
+    const double px = p.x - cx, py = p.y - cy;
+    vs_point o;
+    o.x = (1 + t->A) * px - t->B * py + cx + t->TX;
+    o.y = t->B * px + (1 + t->A) * py + cy + t->TY;
+    return o;
+}
+
+// imgproc.cpp:419-437
+double vs_transform_max_corner_displacement(const vs_transform* t, double width, double height) {
+    const double cx = width * 0.5, cy = height * 0.5;
+    const vs_point corners[4] = {{0.0, 0.0}, {width, 0.0}, {0.0, height}, {width, height}};
+    double max_d = 0.0;
+    for (const vs_point& c : corners) {
+        vs_point m = vs_transform_warp_center(t, c, cx, cy);
+        max_d = std::max(max_d, std::sqrt((m.x - c.x) * (m.x - c.x) + (m.y - c.y) * (m.y - c.y)));
+    }
+    return max_d;
+}
+
+// imgproc.cpp:151-162
+int vs_tile_size(int w, int h) {
+    int tile_size = 2;
+    for (int i = 4; i <= 20; i += 2) {
+        if ((w / i) * (h / i) < 1000) break;
+        tile_size = i;
+    }
+    return tile_size;
+}
+
+// imgproc.cpp:69-75 / 98-103
+void vs_ul_params_sparse(const vs_transform* t, int w, int h, float out4[4]) {
+    out4[0] = static_cast<float>(t->A);
+    out4[1] = static_cast<float>(t->B);
+    out4[2] = static_cast<float>(t->TX - t->A * (w * 0.5f) + t->B * (h * 0.5f));
+    out4[3] = static_cast<float>(t->TY - t->B * (w * 0.5f) - t->A * (h * 0.5f));
+}
+// imgproc.cpp:125-131
+void vs_ul_params_warp(const vs_transform* t, int w, int h, float out4[4]) {
+    const double cx = (w - 1) * 0.5, cy = (h - 1) * 0.5;
+    out4[0] = static_cast<float>(t->A);
+    out4[1] = static_cast<float>(t->B);
+    out4[2] = static_cast<float>(t->TX - t->A * cx + t->B * cy);
+    out4[3] = static_cast<float>(t->TY - t->B * cx - t->A * cy);
+}
+
+// smoother.cpp:18-65
+void vs_tvl1_smooth(const double* data, int n, double lambda, int iterations, double* x) {
+    if (n <= 0) return;
+    std::copy(data, data + n, x);
+    for (int it = 0; it < iterations; ++it) {
+        for (int i = 0; i < n; i++) x[i] = (1.0 - 0.5) * x[i] + 0.5 * data[i];
+        for (int i = 0; i + 1 < n; i++) {
+            const double diff = x[i + 1] - x[i];
+            const double mag = std::fabs(diff);
+            if (mag > lambda) {
+                const double shrink = (mag - lambda) / mag * 0.5;
+                x[i] += diff * shrink;
+                x[i + 1] -= diff * shrink;
+            } else {
+                const double mid = 0.5 * (x[i] + x[i + 1]);
+                x[i] = mid;
+                x[i + 1] = mid;
+            }
+        }
+    }
+}
+
+}  // extern "C"
+
+// smoother.cpp:67-127
+struct vs_smoother {
+    int lag_behind, lag_ahead;
+    double lambda;
+    int next_to_finalize = 0;
+    std::vector<vs_transform> measurements;
+};
+
+extern "C" {
+
+vs_smoother* vs_smoother_create(int lag_behind, int lag_ahead, double lambda) {
+    vs_smoother* s = new vs_smoother();
+    s->lag_behind = lag_behind;
+    s->lag_ahead = lag_ahead;
+    s->lambda = lambda;
+    return s;
+}
+void vs_smoother_destroy(vs_smoother* s) { delete s; }
+
+int vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* out_finalized) {
+    s->measurements.push_back(*meas);
+    const int newest = (int)s->measurements.size() - 1;
+    if (s->next_to_finalize + s->lag_ahead > newest) return 0;
+    const int start = std::max(0, s->next_to_finalize - s->lag_behind);
+    const int end = s->next_to_finalize + s->lag_ahead;
+    const int n = end - start + 1;
+    std::vector<double> in(4 * n), out(4 * n);
+    for (int i = 0; i < n; i++) {
+        const vs_transform& m = s->measurements[start + i];
+        in[i] = m.A; in[n + i] = m.B; in[2 * n + i] = m.TX; in[3 * n + i] = m.TY;
+    }
+    for (int k = 0; k < 4; k++) vs_tvl1_smooth(&in[k * n], n, s->lambda, 100, &out[k * n]);
+    const int middle = s->next_to_finalize - start;
+    out_finalized->A = out[middle];
+    out_finalized->B = out[n + middle];
+    out_finalized->TX = out[2 * n + middle];
+    out_finalized->TY = out[3 * n + middle];
+    s->next_to_finalize++;
+    return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// vs_internal.hpp -- shared by the translation units behind the C ABI.
+#pragma once
+
+#include "../../include/vs_amd.h"
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vsi {
+// records a thread-local message for vs_last_error() and returns `code`
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace vsi
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+
+#define VS_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return vsi::set_error(VS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+namespace vsi {
+
+// RAII device allocation used by the host-staged (VS_MEM_HOST) form of the kernel-level calls.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        return hipMalloc(&p, n ? n : 1);
+    }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+// An argument that lives wherever the caller said (`mem`): for device memory it is the caller's
+// pointer; for host memory it is a staged device copy (uploaded for inputs, downloaded for outputs).
+struct Staged {
+    DevBuf buf;
+    void* dev = nullptr;
+    void* host = nullptr;
+    size_t bytes = 0;
+    bool is_out = false, staged = false;
+    int in(const void* ptr, size_t n, int mem, hipStream_t s);
+    int out(void* ptr, size_t n, int mem);
+    int finish(hipStream_t s);   // D2H for staged outputs (async; caller syncs)
+    template <typename T> T* as() const { return (T*)dev; }
+};
+
+bool device_ready();   // true when a HIP device is usable (sets last error otherwise)
+
+}  // namespace vsi
+#endif

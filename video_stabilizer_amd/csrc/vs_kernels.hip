@@ -1,0 +1,503 @@
+// vs_kernels.hip -- gfx950 kernels for the per-pipeline (operator-level) entry points.
+// One kernel per reference Halide pipeline (generators.cpp); launchers at the bottom.
+// All of these are HBM/latency-bound byte and fp32 work: wave64, coalesced 4..16-byte accesses,
+// LDS staging for the stencils, no MFMA (DESIGN.md "Why no MFMA").
+#include "vs_kernels.hpp"
+#include "vs_device.hpp"
+
+using namespace vsd;
+
+// ------------------------------------------------------------------------------------------------
+// pyr_down: generators.cpp:56-92.  Separable [1 4 6 4 1]/16 on clamp-to-edge input, sampled at
+// (2x,2y), truncating cast.  Every intermediate of the fp32 original is an exact multiple of
+// 1/256 below 2^24, so it equals the integer form (sum_j sum_i w_j w_i in) >> 8.
+//
+// Block = 256 threads, output tile 64 x 16.  The 136 x 35 input footprint is staged in LDS
+// (aligned dword loads in the interior, clamped byte loads at the borders), a vertical 5-tap pass
+// leaves u16 column sums in LDS for the 16 even rows, then each thread does the horizontal pass
+// for 4 adjacent outputs and stores them as one dword.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int PD_TW = 64, PD_TH = 16;
+constexpr int PD_IW = 2 * PD_TW + 8;     // 136 staged input columns: 2*x0-4 .. 2*x0+2*TW+3 (dword aligned;
+                                         // columns 2..133 of them are used)
+constexpr int PD_IH = 2 * PD_TH + 3;     // 35 input rows:    2*y0-2 .. 2*y0+2*TH
+constexpr int PD_IWP = PD_IW;            // LDS row pitch (136 B)
+}
+
+__global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__ in, int w, int h, int in_stride,
+                                                     uint8_t* __restrict__ out, int ow, int oh, int out_stride,
+                                                     size_t in_frame_stride, size_t out_frame_stride) {
+    __shared__ uint8_t tile[PD_IH][PD_IWP];
+    __shared__ uint16_t vsum[PD_TH][PD_IWP];
+    in += blockIdx.z * in_frame_stride;
+    out += blockIdx.z * out_frame_stride;
+    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
+    const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;
+    // stage 35 rows x 136 bytes
+    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
+        int r = i / (PD_IW / 4), c4 = (i % (PD_IW / 4)) * 4;
+        int gy = clampi(iy0 + r, 0, h - 1);
+        const uint8_t* row = in + (size_t)gy * in_stride;
+        int gx = ix0 + c4;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < w && (((uintptr_t)(row + gx)) & 3) == 0) {
+            v = *(const uint32_t*)(row + gx);
+        } else {
+            v = (uint32_t)row[clampi(gx, 0, w - 1)] | ((uint32_t)row[clampi(gx + 1, 0, w - 1)] << 8) |
+                ((uint32_t)row[clampi(gx + 2, 0, w - 1)] << 16) | ((uint32_t)row[clampi(gx + 3, 0, w - 1)] << 24);
+        }
+        *(uint32_t*)&tile[r][c4] = v;
+    }
+    __syncthreads();
+    // vertical pass at the 16 even rows
+    for (int i = threadIdx.x; i < PD_TH * PD_IW; i += 256) {
+        int r = i / PD_IW, c = i % PD_IW;
+        int rr = 2 * r;   // tile row of input row 2*(y0+r)-2
+        unsigned s = tile[rr][c] + 4u * tile[rr + 1][c] + 6u * tile[rr + 2][c] + 4u * tile[rr + 3][c] + tile[rr + 4][c];
+        vsum[r][c] = (uint16_t)s;
+    }
+    __syncthreads();
+    // horizontal pass: thread -> 4 adjacent outputs of one row
+    const int r = threadIdx.x / (PD_TW / 4), q = threadIdx.x % (PD_TW / 4);
+    const int oy = y0 + r, ox = x0 + 4 * q;
+    if (oy < oh && ox < ow) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int c = 2 * (4 * q + k) + 2;   // staged column of input column 2*(ox+k)-2
+            unsigned s = vsum[r][c] + 4u * vsum[r][c + 1] + 6u * vsum[r][c + 2] + 4u * vsum[r][c + 3] + vsum[r][c + 4];
+            packed |= (s >> 8) << (8 * k);
+        }
+        uint8_t* dst = out + (size_t)oy * out_stride + ox;
+        if (ox + 3 < ow && (((uintptr_t)dst) & 3) == 0) {
+            *(uint32_t*)dst = packed;
+        } else {
+            for (int k = 0; k < 4 && ox + k < ow; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bgr_to_gray: stands in for cv::cvtColor(BGR2GRAY) at alignment.cpp:212 (OpenCV 4.x 15-bit fixed
+// point).  4 pixels per thread: 12 B in (three dwords when aligned), 4 B out.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vs_k_bgr_to_gray(const T* __restrict__ src, int w, int h, int src_stride,
+                                                        int shift_to_8, uint8_t* __restrict__ dst, int dst_stride,
+                                                        size_t src_frame_stride, size_t dst_frame_stride) {
+    src += blockIdx.z * src_frame_stride;
+    dst += blockIdx.z * dst_frame_stride;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= w) return;
+    const T* p = src + (size_t)y * src_stride + (size_t)x * 3;
+    uint8_t* o = dst + (size_t)y * dst_stride + x;
+    uint32_t g[4];
+    const int n = min(4, w - x);
+    if (sizeof(T) == 1 && n == 4 && (((uintptr_t)p) & 3) == 0) {
+        const uint32_t* p4 = (const uint32_t*)p;
+        uint32_t a = p4[0], b = p4[1], c = p4[2];
+        uint32_t px[12] = {a & 255, (a >> 8) & 255, (a >> 16) & 255, a >> 24, b & 255, (b >> 8) & 255,
+                           (b >> 16) & 255, b >> 24, c & 255, (c >> 8) & 255, (c >> 16) & 255, c >> 24};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            g[k] = (px[3 * k] * 3735u + px[3 * k + 1] * 19235u + px[3 * k + 2] * 9798u + 16384u) >> 15;
+    } else {
+        for (int k = 0; k < n; k++)
+            g[k] = ((uint32_t)p[3 * k] * 3735u + (uint32_t)p[3 * k + 1] * 19235u + (uint32_t)p[3 * k + 2] * 9798u + 16384u) >> 15;
+    }
+    for (int k = 0; k < n; k++) { g[k] >>= shift_to_8; g[k] = g[k] > 255u ? 255u : g[k]; }
+    if (n == 4 && (((uintptr_t)o) & 3) == 0) {
+        *(uint32_t*)o = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    } else {
+        for (int k = 0; k < n; k++) o[k] = (uint8_t)g[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad_xy: generators.cpp:202-224.  API-parity kernel only (the engine never writes gradients).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_grad_xy(const uint8_t* __restrict__ in, int w, int h, int stride,
+                                                    float* __restrict__ gx, float* __restrict__ gy) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t* row = in + (size_t)y * stride;
+    float l = (float)row[max(x - 1, 0)], r = (float)row[min(x + 1, w - 1)];
+    float u = (float)in[(size_t)max(y - 1, 0) * stride + x], d = (float)in[(size_t)min(y + 1, h - 1) * stride + x];
+    gx[(size_t)y * w + x] = 0.5f * (r - l);
+    gy[(size_t)y * w + x] = 0.5f * (d - u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad_argmax from float planes: generators.cpp:260-294.  One wave per tile.  The reference's
+// unscheduled Halide::argmax is a serial scan (r.x inner, r.y outer) that updates on strict '>',
+// i.e. the winner is the largest |g| and, among equals, the smallest scan index.  As a wave
+// max-reduction: key = (bits(|g|) << 32) | (0xffffffff - scan_index); |g| >= 0 so its IEEE bits
+// order like unsigned integers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_grad_argmax(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                        int w, int h, int ts, int tx, int ty,
+                                                        uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tx * ty) return;
+    const int tyi = tile / tx, txi = tile % tx;
+    const int bx = txi * ts, by = tyi * ts, n = ts * ts;
+    unsigned long long kx = 0, ky = 0;
+    for (int i = lane; i < n; i += 64) {
+        int ry = i / ts, rx = i % ts;
+        size_t o = (size_t)(by + ry) * w + (bx + rx);
+        unsigned long long inv = 0xffffffffu - (unsigned)i;
+        unsigned long long a = ((unsigned long long)__float_as_uint(fabsf(gx[o])) << 32) | inv;
+        unsigned long long b = ((unsigned long long)__float_as_uint(fabsf(gy[o])) << 32) | inv;
+        kx = a > kx ? a : kx;
+        ky = b > ky ? b : ky;
+    }
+    kx = wave_max_u64(kx);
+    ky = wave_max_u64(ky);
+    if (lane == 0) {
+        const size_t nt = (size_t)tx * ty;
+        int ix = (int)(0xffffffffu - (unsigned)(kx & 0xffffffffu)), iy = (int)(0xffffffffu - (unsigned)(ky & 0xffffffffu));
+        lmx[tile] = (uint16_t)(bx + ix % ts);
+        lmx[nt + tile] = (uint16_t)(by + ix / ts);
+        lmy[tile] = (uint16_t)(bx + iy % ts);
+        lmy[nt + tile] = (uint16_t)(by + iy / ts);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse_jac from float planes: generators.cpp:332-386.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_sparse_jac(const float* __restrict__ gx, const float* __restrict__ gy,
+                                                       int w, int h, const uint16_t* __restrict__ lmx,
+                                                       const uint16_t* __restrict__ lmy, int nt,
+                                                       float* __restrict__ jx, float* __restrict__ jy) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    const float cx = (float)w * 0.5f, cy = (float)h * 0.5f, scale = 1.f / (float)w;
+    int ix0 = min((int)lmx[i], w - 1), iy0 = min((int)lmx[nt + i], h - 1);
+    int ix1 = min((int)lmy[i], w - 1), iy1 = min((int)lmy[nt + i], h - 1);
+    float u0 = (float)ix0 - cx, v0 = (float)iy0 - cy, u1 = (float)ix1 - cx, v1 = (float)iy1 - cy;
+    float g0 = gx[(size_t)iy0 * w + ix0], g1 = gy[(size_t)iy1 * w + ix1];
+    jx[i] = 2.f * g0 * u0 * scale;
+    jx[nt + i] = 2.f * g0 * (-v0) * scale;
+    jx[2 * (size_t)nt + i] = 2.f * g0;
+    jx[3 * (size_t)nt + i] = 0.f;
+    jy[i] = 2.f * g1 * v1 * scale;
+    jy[nt + i] = 2.f * g1 * u1 * scale;
+    jy[2 * (size_t)nt + i] = 0.f;
+    jy[3 * (size_t)nt + i] = 2.f * g1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused keyframe pass: grad_xy + grad_argmax + sparse_jac straight from the u8 level
+// (alignment.cpp:237-276 runs them back to back; the 8 B/px gradient planes are never needed).
+// |0.5f*(a-b)| orders exactly like the integer |a-b| in [0,255], so the arg-max runs on u32
+// keys (|a-b| << 16) | (0xffff - scan_index) -- ts <= 64 keeps scan_index < 4096.
+// One wave per tile, 4 tiles per block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_keyframe(const uint8_t* __restrict__ img, int w, int h, int stride,
+                                                     int ts, int tx, int ty, uint16_t* __restrict__ lmx,
+                                                     uint16_t* __restrict__ lmy, float* __restrict__ jx,
+                                                     float* __restrict__ jy, size_t img_frame_stride,
+                                                     size_t lm_frame_stride, size_t jac_frame_stride) {
+    img += blockIdx.y * img_frame_stride;
+    lmx += blockIdx.y * lm_frame_stride; lmy += blockIdx.y * lm_frame_stride;
+    jx += blockIdx.y * jac_frame_stride; jy += blockIdx.y * jac_frame_stride;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= tx * ty) return;
+    const int tyi = tile / tx, txi = tile % tx;
+    const int bx = txi * ts, by = tyi * ts, n = ts * ts;
+    unsigned kx = 0, ky = 0;
+    for (int i = lane; i < n; i += 64) {
+        int ry = i / ts, rx = i % ts;
+        int x = bx + rx, y = by + ry;
+        const uint8_t* row = img + (size_t)y * stride;
+        int l = row[max(x - 1, 0)], r = row[min(x + 1, w - 1)];
+        int u = img[(size_t)max(y - 1, 0) * stride + x], d = img[(size_t)min(y + 1, h - 1) * stride + x];
+        unsigned inv = 0xffffu - (unsigned)i;
+        unsigned a = ((unsigned)abs(r - l) << 16) | inv, b = ((unsigned)abs(d - u) << 16) | inv;
+        kx = a > kx ? a : kx;
+        ky = b > ky ? b : ky;
+    }
+    kx = wave_max_u32(kx);
+    ky = wave_max_u32(ky);
+    if (lane == 0) {
+        const size_t nt = (size_t)tx * ty;
+        int sx = (int)(0xffffu - (kx & 0xffffu)), sy = (int)(0xffffu - (ky & 0xffffu));
+        int ix0 = bx + sx % ts, iy0 = by + sx / ts, ix1 = bx + sy % ts, iy1 = by + sy / ts;
+        lmx[tile] = (uint16_t)ix0; lmx[nt + tile] = (uint16_t)iy0;
+        lmy[tile] = (uint16_t)ix1; lmy[nt + tile] = (uint16_t)iy1;
+        // generators.cpp:346-385 (the min(.., w-1) clamps are no-ops: keypoints lie inside the image)
+        const float cx = (float)w * 0.5f, cy = (float)h * 0.5f, scale = 1.f / (float)w;
+        float g0 = 0.5f * ((float)img[(size_t)iy0 * stride + min(ix0 + 1, w - 1)] - (float)img[(size_t)iy0 * stride + max(ix0 - 1, 0)]);
+        float g1 = 0.5f * ((float)img[(size_t)min(iy1 + 1, h - 1) * stride + ix1] - (float)img[(size_t)max(iy1 - 1, 0) * stride + ix1]);
+        float u0 = (float)ix0 - cx, v0 = (float)iy0 - cy, u1 = (float)ix1 - cx, v1 = (float)iy1 - cy;
+        jx[tile] = 2.f * g0 * u0 * scale;
+        jx[nt + tile] = 2.f * g0 * (-v0) * scale;
+        jx[2 * nt + tile] = 2.f * g0;
+        jx[3 * nt + tile] = 0.f;
+        jy[tile] = 2.f * g1 * v1 * scale;
+        jy[nt + tile] = 2.f * g1 * u1 * scale;
+        jy[2 * nt + tile] = 0.f;
+        jy[3 * nt + tile] = 2.f * g1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse_warpdiff: generators.cpp:646-700.  One thread per tile keypoint.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_sparse_warpdiff(const uint8_t* __restrict__ tmpl,
+                                                            const uint8_t* __restrict__ key, int w, int h, int stride,
+                                                            const uint16_t* __restrict__ lm, int nt, float A, float B,
+                                                            float TX, float TY, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nt) return;
+    int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
+    float ox = (float)tile_x, oy = (float)tile_y;
+    float Wx = (1.0f + A) * ox - B * oy + TX;
+    float Wy = B * ox + (1.0f + A) * oy + TY;
+    float v = lanczos_sample_u8(key, w, h, stride, Wx, Wy);
+    float diff = fabsf(v - (float)tmpl[(size_t)tile_y * stride + tile_x]);
+    diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
+    out[i] = (uint16_t)diff;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse_ica: generators.cpp:429-596.  One block; each thread walks its strided share of both
+// point sets, accumulating double(J*residual) per set, then a block tree-sum.  The reference
+// reduces serially in index order; the tree differs from that by ~1e-16 relative (fp64 sums of
+// fp32 products), far inside the 1e-4 parameter gate.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ica_accumulate(const uint8_t* __restrict__ tmpl, const uint8_t* __restrict__ key,
+                                               int w, int h, int stride, const uint16_t* __restrict__ sel, int n,
+                                               const float* __restrict__ jac, float A1, float B, float TX, float TY,
+                                               double acc[4]) {
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        int px = sel[r], py = sel[n + r];
+        float ox = (float)px, oy = (float)py;
+        float Wx = A1 * ox - B * oy + TX;
+        float Wy = B * ox + A1 * oy + TY;
+        float warped = lanczos_sample_u8(key, w, h, stride, Wx, Wy);
+        float tv = (float)tmpl[(size_t)min(py, h - 1) * stride + min(px, w - 1)];
+        float residual = tv - warped;
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] += (double)(jac[(size_t)c * n + r] * residual);
+    }
+}
+
+__global__ __launch_bounds__(1024) void vs_k_sparse_ica(const uint8_t* __restrict__ tmpl, const uint8_t* __restrict__ key,
+                                                        int w, int h, int stride, const uint16_t* __restrict__ selx,
+                                                        int nx, const uint16_t* __restrict__ sely, int ny,
+                                                        const float* __restrict__ jacx, const float* __restrict__ jacy,
+                                                        float A, float B, float TX, float TY, double* __restrict__ out) {
+    __shared__ double red[16 * 8];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float A1 = 1.0f + A;
+    ica_accumulate(tmpl, key, w, h, stride, selx, nx, jacx, A1, B, TX, TY, acc);
+    ica_accumulate(tmpl, key, w, h, stride, sely, ny, jacy, A1, B, TX, TY, acc + 4);
+    block_sum<8>(acc, red);
+    if (threadIdx.x < 4) out[threadIdx.x] = (acc[threadIdx.x] + acc[4 + threadIdx.x]) * 0.5f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image_warp: generators.cpp:126-164.  Bilinear, u8 -> f32, clamp-to-edge.
+// Halide float lerp(a,b,t) = a*(1-t) + b*t.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+__global__ __launch_bounds__(256) void vs_k_image_warp(const uint8_t* __restrict__ in, int w, int h, int stride,
+                                                       float A, float B, float TX, float TY, float* __restrict__ out,
+                                                       int ow, int oh) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= ow) return;
+    float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
+    float Wy = B * (float)x + (1.0f + A) * (float)y + TY;
+    int fx = (int)floorf(Wx), fy = (int)floorf(Wy);
+    float wx = Wx - (float)fx, wy = Wy - (float)fy;
+    int x0 = clampi(fx, 0, w - 1), x1 = clampi(fx + 1, 0, w - 1);
+    const uint8_t* r0 = in + (size_t)clampi(fy, 0, h - 1) * stride;
+    const uint8_t* r1 = in + (size_t)clampi(fy + 1, 0, h - 1) * stride;
+    float top = lerpf((float)r0[x0], (float)r0[x1], wx);
+    float bottom = lerpf((float)r1[x0], (float)r1[x1], wx);
+    out[(size_t)y * ow + x] = lerpf(top, bottom, wy);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bgr_image_warp (general path): any channel count, u8/u16, Lanczos2 or bilinear, clamp or
+// constant border, integer or float output.  One thread per output pixel, taps through L1/L2.
+// The sampler is the reference's (generators.cpp:672-697 / 148-163) applied per channel with
+// image_warp's coordinates (generators.cpp:141-142).  The tuned u8 BGR kernels live in
+// vs_warp.hip; this one is the semantic baseline they are tested against.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int BORDER, bool F32OUT>
+__global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict__ src, int w, int h, int src_stride,
+                                                             int channels, const float4* __restrict__ params,
+                                                             int max_value, void* __restrict__ dstv, int dst_stride,
+                                                             size_t src_frame_stride, size_t dst_frame_stride) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float4 P = params[blockIdx.z];
+    src += blockIdx.z * src_frame_stride;
+    const float A = P.x, B = P.y, TX = P.z, TY = P.w;
+    float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
+    float Wy = B * (float)x + (1.0f + A) * (float)y + TY;
+    float flx = floorf(Wx), fly = floorf(Wy);
+    int ix = (int)flx, iy = (int)fly;
+    float frx = Wx - flx, fry = Wy - fly;
+    float wx[4], wy[4];
+    if (MODE == 0) { lanczos_weights4(frx, wx); lanczos_weights4(fry, wy); }
+    for (int c = 0; c < channels; c++) {
+        float v;
+        if (MODE == 0) {
+            float num = 0.0f, den = 0.0f;
+#pragma unroll
+            for (int ry = 0; ry < 4; ry++) {
+                int sy = iy + ry - 1;
+#pragma unroll
+                for (int rx = 0; rx < 4; rx++) {
+                    int sx = ix + rx - 1;
+                    float w2d = wx[rx] * wy[ry];
+                    float val;
+                    if (BORDER == 1) {
+                        val = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f
+                              : (float)src[(size_t)sy * src_stride + (size_t)sx * channels + c];
+                    } else {
+                        val = (float)src[(size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(sx, 0, w - 1) * channels + c];
+                    }
+                    num = num + w2d * val;
+                    den = den + w2d;
+                }
+            }
+            v = num / den;
+        } else {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int sx = ix + (k & 1), sy = iy + (k >> 1);
+                if (BORDER == 1) {
+                    t[k] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f
+                           : (float)src[(size_t)sy * src_stride + (size_t)sx * channels + c];
+                } else {
+                    t[k] = (float)src[(size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(sx, 0, w - 1) * channels + c];
+                }
+            }
+            v = lerpf(lerpf(t[0], t[1], frx), lerpf(t[2], t[3], frx), fry);
+        }
+        size_t o = (size_t)y * dst_stride + (size_t)x * channels + c;
+        if (F32OUT) {
+            ((float*)dstv + blockIdx.z * dst_frame_stride)[o] = v;
+        } else {
+            float r = floorf(v + 0.5f);
+            r = fminf(fmaxf(r, 0.0f), (float)max_value);
+            ((T*)dstv + blockIdx.z * dst_frame_stride)[o] = (T)r;
+        }
+    }
+}
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+namespace vsk {
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride,
+                    int n_frames, size_t in_fs, size_t out_fs, hipStream_t s) {
+    dim3 grid(cdiv(ow, PD_TW), cdiv(oh, PD_TH), n_frames);
+    hipLaunchKernelGGL(vs_k_pyr_down, grid, dim3(256), 0, s, in, w, h, in_stride, out, ow, oh, out_stride, in_fs, out_fs);
+    return hipGetLastError();
+}
+
+hipError_t bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,
+                       int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+    dim3 grid(cdiv(w, 1024), h, n_frames);
+    if (bits == 8)
+        hipLaunchKernelGGL(vs_k_bgr_to_gray<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)src, w, h, src_stride,
+                           shift_to_8, dst, dst_stride, src_fs, dst_fs);
+    else
+        hipLaunchKernelGGL(vs_k_bgr_to_gray<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
+                           shift_to_8, dst, dst_stride, src_fs, dst_fs);
+    return hipGetLastError();
+}
+
+hipError_t grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, hipStream_t s) {
+    hipLaunchKernelGGL(vs_k_grad_xy, dim3(cdiv(w, 256), h), dim3(256), 0, s, in, w, h, stride, gx, gy);
+    return hipGetLastError();
+}
+
+hipError_t grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy,
+                       hipStream_t s) {
+    int tx = w / ts, ty = h / ts;
+    if (tx * ty == 0) return hipSuccess;
+    hipLaunchKernelGGL(vs_k_grad_argmax, dim3(cdiv(tx * ty, 4)), dim3(256), 0, s, gx, gy, w, h, ts, tx, ty, lmx, lmy);
+    return hipGetLastError();
+}
+
+hipError_t sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy,
+                      int nt, float* jx, float* jy, hipStream_t s) {
+    if (nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(vs_k_sparse_jac, dim3(cdiv(nt, 256)), dim3(256), 0, s, gx, gy, w, h, lmx, lmy, nt, jx, jy);
+    return hipGetLastError();
+}
+
+hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
+                    float* jy, int n_frames, size_t img_fs, size_t lm_fs, size_t jac_fs, hipStream_t s) {
+    int tx = w / ts, ty = h / ts;
+    if (tx * ty == 0) return hipSuccess;
+    hipLaunchKernelGGL(vs_k_keyframe, dim3(cdiv(tx * ty, 4), n_frames), dim3(256), 0, s, img, w, h, stride, ts, tx, ty,
+                       lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs);
+    return hipGetLastError();
+}
+
+hipError_t sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm,
+                           int nt, float A, float B, float TX, float TY, uint16_t* out, hipStream_t s) {
+    if (nt == 0) return hipSuccess;
+    hipLaunchKernelGGL(vs_k_sparse_warpdiff, dim3(cdiv(nt, 256)), dim3(256), 0, s, tmpl, key, w, h, stride, lm, nt, A, B,
+                       TX, TY, out);
+    return hipGetLastError();
+}
+
+hipError_t sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
+                      const uint16_t* sely, int ny, const float* jacx, const float* jacy, float A, float B, float TX,
+                      float TY, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(vs_k_sparse_ica, dim3(1), dim3(1024), 0, s, tmpl, key, w, h, stride, selx, nx, sely, ny, jacx,
+                       jacy, A, B, TX, TY, out);
+    return hipGetLastError();
+}
+
+hipError_t image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out,
+                      int ow, int oh, hipStream_t s) {
+    hipLaunchKernelGGL(vs_k_image_warp, dim3(cdiv(ow, 256), oh), dim3(256), 0, s, in, w, h, stride, A, B, TX, TY, out, ow,
+                       oh);
+    return hipGetLastError();
+}
+
+template <typename T, bool F32OUT>
+static void launch_generic(const T* src, int w, int h, int src_stride, int channels, const float4* params, int mode,
+                           int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs,
+                           size_t dst_fs, hipStream_t s) {
+    dim3 grid(cdiv(w, 256), h, n_frames), block(256);
+#define VS_LAUNCH(M, Bd)                                                                                          \
+    hipLaunchKernelGGL((vs_k_bgr_warp_generic<T, M, Bd, F32OUT>), grid, block, 0, s, src, w, h, src_stride, channels, \
+                       params, max_value, dst, dst_stride, src_fs, dst_fs)
+    if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
+    else if (mode == 0) VS_LAUNCH(0, 1);
+    else if (border == 0) VS_LAUNCH(1, 0);
+    else VS_LAUNCH(1, 1);
+#undef VS_LAUNCH
+}
+
+hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int channels, int bits,
+                            const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
+                            bool f32out, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+    if (bits == 8) {
+        if (f32out) launch_generic<uint8_t, true>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+        else launch_generic<uint8_t, false>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+    } else {
+        if (f32out) launch_generic<uint16_t, true>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+        else launch_generic<uint16_t, false>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace vsk

@@ -1,0 +1,39 @@
+// vs_kernels.hpp -- host-callable launchers of the gfx950 kernels (all async on `s`).
+// Batched launchers take frame strides in ELEMENTS and a frame count in grid.z / grid.y.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vsk {
+
+hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride,
+                    int n_frames, size_t in_frame_stride, size_t out_frame_stride, hipStream_t s);
+hipError_t bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,
+                       int dst_stride, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, hipStream_t s);
+hipError_t grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, hipStream_t s);
+hipError_t grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy,
+                       hipStream_t s);
+hipError_t sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy, int nt,
+                      float* jx, float* jy, hipStream_t s);
+hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
+                    float* jy, int n_frames, size_t img_frame_stride, size_t lm_frame_stride, size_t jac_frame_stride,
+                    hipStream_t s);
+hipError_t sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm,
+                           int nt, float A, float B, float TX, float TY, uint16_t* out, hipStream_t s);
+hipError_t sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
+                      const uint16_t* sely, int ny, const float* jacx, const float* jacy, float A, float B, float TX,
+                      float TY, double* out, hipStream_t s);
+hipError_t image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out,
+                      int ow, int oh, hipStream_t s);
+// params_dev: n_frames float4 {A,B,TX,TY} (upper-left based kernel arguments) in device memory
+hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int channels, int bits,
+                            const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
+                            bool f32out, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, hipStream_t s);
+// tuned interleaved-BGR u8 path (vs_warp.hip); returns hipErrorNotSupported when the shape does not qualify
+hipError_t bgr_warp_u8c3(const uint8_t* src, int w, int h, int src_stride, const float4* params_dev, int mode,
+                         int border, uint8_t* dst, int dst_stride, int n_frames, size_t src_frame_stride,
+                         size_t dst_frame_stride, hipStream_t s);
+
+}  // namespace vsk
