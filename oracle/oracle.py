@@ -386,7 +386,8 @@ class Aligner:
         return bool(r), t
 
     def debug(self):
-        return lib().vso_aligner_debug(self.h).contents
+        # a snapshot: the struct behind the pointer is overwritten by the next align_next
+        return AlignDebug.from_buffer_copy(lib().vso_aligner_debug(self.h).contents)
 
     def level(self, i):
         w, h, tx, ty, ts = (C.c_int() for _ in range(5))
