@@ -179,6 +179,8 @@ typedef struct vs_align_info {
 vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);
 void vs_aligner_destroy(vs_aligner* a);
 int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
+/* forget the sequence: the next frame is treated as the first frame of a new clip (device memory is kept) */
+int  vs_aligner_reset(vs_aligner* a);
 /* VideoAligner::AlignNextFrame (alignment.hpp:55-58, alignment.cpp:334-704).
  * returns 1 aligned / 0 not aligned (first frame, no convergence, over displacement) / <0 error.
  * `params` may change per call like the reference's third argument (NULL = the creation params). */
@@ -199,6 +201,28 @@ int  vs_aligner_level_dims(const vs_aligner* a, int level, int* w, int* h, int* 
 int  vs_aligner_read_level_image(const vs_aligner* a, int i, int level, uint8_t* out);
 int  vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set, uint16_t* out);
 int  vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out);
+
+/* Opt-in per-stage timing (the reference's compiled-out PerformanceMetrics / TIME_FUNCTION,
+ * alignment.cpp:10-147).  Device stages are bracketed with hipEvents on the handle's stream, the
+ * selection stage is host wall-clock.  Values accumulate until reset. */
+enum {
+    VS_STAGE_INGEST = 0,     /* H2D (host frames) + BGR->gray / gray copy   "ConvertToBGR"       */
+    VS_STAGE_PYR_DOWN = 1,   /* all pyr_down launches                       "PyrDown_i"          */
+    VS_STAGE_KEYFRAME = 2,   /* fused grad/argmax/jacobian launches         "GradXY_i".."SparseJacobian_i" */
+    VS_STAGE_WARPDIFF = 3,   /*                                             "SparseWarpDiff_X/Y_i" */
+    VS_STAGE_SELECT = 4,     /* keep-best-80% incl. its copies              "NthElement_i"       */
+    VS_STAGE_GATHER = 5,     /*                                             "JacobianSetup_i"    */
+    VS_STAGE_GN = 6,         /* Hessian + solve + all iterations            "ICAIteration_i_iter" */
+    VS_STAGE_COUNT = 7
+};
+typedef struct vs_stage_timings {
+    double ms[VS_STAGE_COUNT];        /* accumulated milliseconds per stage */
+    int64_t launches[VS_STAGE_COUNT]; /* kernel launches per stage */
+    int64_t frames;                   /* frames processed while timing was on */
+    int64_t gn_iterations;            /* Gauss-Newton iterations summed over pairs and levels */
+} vs_stage_timings;
+int  vs_aligner_enable_timing(vs_aligner* a, int enable);   /* also resets the accumulators */
+int  vs_aligner_get_timings(vs_aligner* a, vs_stage_timings* out);
 
 typedef struct vs_stabilizer vs_stabilizer;
 vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params /* NULL = defaults */, int device);

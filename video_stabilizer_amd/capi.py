@@ -55,6 +55,13 @@ class AlignInfo(C.Structure):
                 ("levels", C.c_int32), ("iterations", C.c_int32 * 16), ("condition", C.c_double * 16)]
 
 
+STAGES = ["ingest", "pyr_down", "keyframe", "warpdiff", "select", "gather", "gn"]
+
+
+class StageTimings(C.Structure):
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7), ("frames", C.c_int64), ("gn_iterations", C.c_int64)]
+
+
 class VsError(RuntimeError):
     pass
 
@@ -98,8 +105,11 @@ SIGNATURES = {
     "vs_aligner_create": (_vp, [C.POINTER(AlignerParams), _i32]),
     "vs_aligner_destroy": (None, [_vp]),
     "vs_aligner_set_select_mode": (_i32, [_vp, _i32]),
+    "vs_aligner_reset": (_i32, [_vp]),
     "vs_aligner_align_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP]),
     "vs_aligner_align_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP, C.POINTER(C.c_int32)]),
+    "vs_aligner_enable_timing": (_i32, [_vp, _i32]),
+    "vs_aligner_get_timings": (_i32, [_vp, C.POINTER(StageTimings)]),
     "vs_aligner_get_info": (_i32, [_vp, _i32, C.POINTER(AlignInfo)]),
     "vs_aligner_level_dims": (_i32, [_vp, _i32, _IP, _IP, _IP, _IP, _IP]),
     "vs_aligner_read_level_image": (_i32, [_vp, _i32, _i32, _vp]),
@@ -444,6 +454,20 @@ class Aligner:
         _check(lib().vs_aligner_align_batch(self.h, _p(ptr), frame_stride, n, w, h, stride, fmt, MEM_DEVICE,
                                             C.byref(self.params), out, status))
         return list(status), list(out)
+
+    def reset(self):
+        _check(lib().vs_aligner_reset(self.h))
+
+    def enable_timing(self, on=True):
+        _check(lib().vs_aligner_enable_timing(self.h, 1 if on else 0))
+
+    def timings(self):
+        t = StageTimings()
+        _check(lib().vs_aligner_get_timings(self.h, C.byref(t)))
+        d = {name: {"ms": t.ms[i], "launches": t.launches[i]} for i, name in enumerate(STAGES)}
+        d["frames"] = t.frames
+        d["gn_iterations"] = t.gn_iterations
+        return d
 
     def info(self, i=0):
         inf = AlignInfo()

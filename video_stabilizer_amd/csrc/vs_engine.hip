@@ -18,6 +18,7 @@
 #include "vs_device.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -285,7 +286,37 @@ struct vs_aligner {
     std::vector<vs_align_info> info;   // last call
     int last_n = 0;
 
-    ~vs_aligner() { release(); if (stream) (void)hipStreamDestroy(stream); }
+    // opt-in stage timing (alignment.cpp:10-147's PerformanceMetrics)
+    bool timing = false;
+    vs_stage_timings tm{};
+    struct Span { int stage; hipEvent_t a, b; };
+    std::vector<Span> spans;               // open spans of the current chunk
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void t_begin(int stage) {
+        if (!timing) return;
+        Span sp{stage, get_event(), get_event()};
+        (void)hipEventRecord(sp.a, stream);
+        spans.push_back(sp);
+    }
+    void t_end(int launches) {
+        if (!timing) return;
+        (void)hipEventRecord(spans.back().b, stream);
+        tm.launches[spans.back().stage] += launches;
+    }
+    void t_collect() {   // call after a stream sync
+        for (Span& sp : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) tm.ms[sp.stage] += ms;
+            event_pool.push_back(sp.a); event_pool.push_back(sp.b);
+        }
+        spans.clear();
+    }
+
+    ~vs_aligner() { release(); for (hipEvent_t e : event_pool) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
     void release();
     int configure(int w, int h, int format, const vs_aligner_params& p);
     int ensure_capacity(int n);
@@ -428,6 +459,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
 
     // ---- ComputePyramid (alignment.cpp:149-235) for all n frames ------------------------------
     const void* dframes = frames;
+    t_begin(VS_STAGE_INGEST);
     if (mem == VS_MEM_HOST) {
         const size_t bytes = ((size_t)(n - 1) * frame_stride + (size_t)(H - 1) * stride + (size_t)W * ch) * esz;
         if (bytes > stage_bytes) {
@@ -448,9 +480,12 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         VS_HIP(vsk::bgr_to_gray(dframes, W, H, stride, fmt == VS_FMT_BGR8 ? 8 : 16, fmt == VS_FMT_BGR8 ? 0 : 2, slot1, W, n,
                                 frame_stride, pyr_frame, s));
     }
+    t_end(1);
+    t_begin(VS_STAGE_PYR_DOWN);
     for (int l = 1; l < levels; l++)
         VS_HIP(vsk::pyr_down(slot1 + L[l - 1].img_off, L[l - 1].w, L[l - 1].h, L[l - 1].w, slot1 + L[l].img_off, L[l].w,
                              L[l].h, L[l].w, n, pyr_frame, pyr_frame, s));
+    t_end(levels - 1);
 
     // ---- ComputeKeyFrame (alignment.cpp:237-276) for the odd frames of the sequence -----------
     // frame i of this chunk has sequence index g = seq + i and sits in slot i + 1
@@ -458,6 +493,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
     const int n_odd = first_odd < n ? (n - first_odd + 1) / 2 : 0;
     if (n_odd > 0) {
         const size_t so = (size_t)(first_odd + 1);
+        t_begin(VS_STAGE_KEYFRAME);
         for (int l = 0; l < levels; l++) {
             uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
             float* jx = jac + so * jac_frame + L[l].jac_off;
@@ -465,6 +501,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                                  lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
                                  2 * lm_frame, 2 * jac_frame, s));
         }
+        t_end(levels);
     }
 
     // ---- frame pairs --------------------------------------------------------------------------
@@ -499,27 +536,35 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         GnParams gp{p.threshold, p.max_displacement, p.max_iters};
         for (int l = levels - 1; l >= 0; l--) {
             const LevelDims& ld = L[l];
+            t_begin(VS_STAGE_WARPDIFF);
             hipLaunchKernelGGL(vs_k_warpdiff_batch, dim3((ld.nt + 255) / 256, n_pairs, 2), dim3(256), 0, s, states, descs, pyr,
                                pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, ld.nt, wd, wd_pair);
             VS_HIP(hipGetLastError());
+            t_end(1);
             if (select_mode == VS_SELECT_STL_HOST) {
+                const auto t0 = std::chrono::steady_clock::now();
                 VS_HIP(hipMemcpyAsync(h_wd, wd, (size_t)n_pairs * wd_pair * 2, hipMemcpyDeviceToHost, s));
                 VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
                 VS_HIP(hipStreamSynchronize(s));
                 VS_TRY(select_host(n_pairs, ld));
                 VS_HIP(hipMemcpyAsync(idx, h_idx, (size_t)n_pairs * wd_pair * 4, hipMemcpyHostToDevice, s));
+                if (timing) tm.ms[VS_STAGE_SELECT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             } else {
                 return set_error(VS_ERR_UNSUPPORTED, "VS_SELECT_DEVICE is not built yet");
             }
             if (ld.nsel > 0) {
+                t_begin(VS_STAGE_GATHER);
                 hipLaunchKernelGGL(vs_k_gather_selected, dim3((ld.nsel + 255) / 256, n_pairs, 2), dim3(256), 0, s, states,
                                    descs, lm, lm_frame, ld.lm_off, jac, jac_frame, ld.jac_off, ld.nt, ld.nsel, idx, wd_pair,
                                    sel, sel_pair, seljac, seljac_pair);
                 VS_HIP(hipGetLastError());
+                t_end(1);
             }
+            t_begin(VS_STAGE_GN);
             hipLaunchKernelGGL(vs_k_gn_level, dim3(n_pairs), dim3(kGnThreads), 0, s, states, descs, pyr, pyr_frame, ld.img_off,
                                ld.w, ld.h, ld.nsel, sel, sel_pair, seljac, seljac_pair, l, gp);
             VS_HIP(hipGetLastError());
+            t_end(1);
         }
         VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
@@ -528,7 +573,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             const PairState& st = h_states[q];
             vs_align_info& inf = infos[i];
             inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
-            for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; }
+            for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l]; }
             if (st.status == 1) {
                 vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
                 if (((seq + i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
@@ -539,6 +584,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
     } else {
         VS_HIP(hipStreamSynchronize(s));
     }
+    if (timing) { t_collect(); tm.frames += n; }
     seq += n;
     last_n = n;
     return VS_OK;
@@ -574,6 +620,12 @@ void vs_aligner_destroy(vs_aligner* a) {
 int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
     VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE));
     a->select_mode = mode;
+    return VS_OK;
+}
+
+int vs_aligner_reset(vs_aligner* a) {
+    VS_ARG(a);
+    a->seq = 0;
     return VS_OK;
 }
 
@@ -613,6 +665,19 @@ int vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int st
     int r = vs_aligner_align_batch(a, frame, 0, 1, w, h, stride, format, mem, params, out, &st);
     if (r < 0) return r;
     return st;
+}
+
+int vs_aligner_enable_timing(vs_aligner* a, int enable) {
+    VS_ARG(a);
+    a->timing = enable != 0;
+    memset(&a->tm, 0, sizeof(a->tm));
+    return VS_OK;
+}
+
+int vs_aligner_get_timings(vs_aligner* a, vs_stage_timings* out) {
+    VS_ARG(a && out);
+    *out = a->tm;
+    return VS_OK;
 }
 
 int vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info) {

@@ -101,3 +101,35 @@ def make_clip(width, height, n_frames, seed, channels=1, bits=8, path=None, marg
             else:
                 frames[i, :, :, c] = v
     return frames, path
+
+
+def make_clip_torch(width, height, n_frames, seed, device, channels=3, bits=8, path=None, margin=128, **path_kw):
+    """Device-side twin of make_clip for full-size clips: same textures (numpy, uploaded once), the
+    per-frame bilinear resampling runs as torch ops on `device`.  Returns (uint8/int16-viewed tensor
+    (n,h,w,c), path).  torch is plumbing here: it only produces the input bytes."""
+    import torch
+    max_value = 255 if bits == 8 else (1 << bits) - 1
+    if path is None:
+        path = camera_path(n_frames, seed, **path_kw)
+    texs = [torch.from_numpy(base_texture(width + 2 * margin, height + 2 * margin, seed + c, max_value)).to(device)
+            for c in range(channels)]
+    th, tw = texs[0].shape
+    dt = torch.uint8 if bits == 8 else torch.int16      # int16 carries the u16 bit pattern (values < 32768)
+    out = torch.empty((n_frames, height, width, channels), dtype=dt, device=device)
+    ys = torch.arange(height, dtype=torch.float64, device=device)[:, None]
+    xs = torch.arange(width, dtype=torch.float64, device=device)[None, :]
+    cx, cy = width * 0.5, height * 0.5
+    px, py = xs - cx, ys - cy
+    for i, (A, B, TX, TY) in enumerate(path):
+        sx = (1 + A) * px - B * py + cx + TX + margin
+        sy = B * px + (1 + A) * py + cy + TY + margin
+        x0 = torch.clamp(torch.floor(sx).long(), 0, tw - 2)
+        y0 = torch.clamp(torch.floor(sy).long(), 0, th - 2)
+        fx = torch.clamp(sx - x0, 0, 1)
+        fy = torch.clamp(sy - y0, 0, 1)
+        i00 = y0 * tw + x0
+        for c in range(channels):
+            t = texs[c].reshape(-1)
+            v = (t[i00] * (1 - fx) + t[i00 + 1] * fx) * (1 - fy) + (t[i00 + tw] * (1 - fx) + t[i00 + tw + 1] * fx) * fy
+            out[i, :, :, c] = torch.clamp(torch.floor(v + 0.5), 0, max_value).to(dt)
+    return out, path
