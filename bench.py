@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override the clip length")
-    ap.add_argument("--select", default="host", choices=["host", "device"])
+    ap.add_argument("--select", default="device", choices=["host", "device"])
     ap.add_argument("--no-warp", action="store_true", help="alignment only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -156,7 +156,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl["name"], "frames_per_clip": n, "clips_per_gpu": 1, "width": W, "height": H,
-                       "selection": "std::nth_element on the host (reference-literal)" if args.select == "host" else "device introselect",
+                       "selection": "std::nth_element on the host" if args.select == "host" else "on-device replica of libstdc++ nth_element (same survivors, same order)",
                        "warp": None if args.no_warp else "bgr_image_warp lanczos2 u8 clamp", "resident": "HBM"},
             "aligned_per_step": int(sum(status)),
             "stages": stages,

@@ -137,6 +137,14 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
                   const uint16_t* selx, int nx, const uint16_t* sely, int ny,
                   const float* jacx, const float* jacy,
                   float A, float B, float TX, float TY, double* out4, int mem, void* stream);
+/* The keep-best-fraction selection of alignment.cpp:435-492 as a device op, for n_arrays independent
+ * warpdiff tables (each tx*ty u16, row-major): flatten, std::nth_element on abs_delta, keep the first
+ * size_t(tx*ty*fraction).  out_idx: n_arrays x (tx*ty) int32, the first `count` of each row are the
+ * surviving tile indices (tile_y*tx+tile_x) in the exact order libstdc++'s nth_element leaves them
+ * (an on-device replica of its introselect).  status[a] = 1 if libstdc++ would have taken its
+ * heap-select fallback for array a (not replicated; callers then use the host).  Returns count. */
+int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction,
+                       int32_t* out_idx, int32_t* status, int mem, void* stream);
 /* int image_warp(in, A, B, TX, TY, out)                   imgproc.cpp:131, generators.cpp:126-164 */
 int vs_image_warp(const uint8_t* in, int w, int h, int stride,
                   float A, float B, float TX, float TY, float* out, int ow, int oh, int mem, void* stream);

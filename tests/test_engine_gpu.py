@@ -78,6 +78,39 @@ def test_bgr_clip_sequence(gpu_vs, oracle, w, h, kw):
     _check_seq(res)
 
 
+@pytest.mark.parametrize("w,h,ch,kw", [(640, 480, 1, {}), (1920, 1080, 3, dict(pyramid_min_width=256)), (322, 246, 3, {}),
+                                       (3840, 2160, 1, dict(pyramid_min_width=256))])
+def test_device_selection_is_identical_to_host_selection(gpu_vs, oracle, w, h, ch, kw):
+    # VS_SELECT_DEVICE (fused single-launch path, on-device introselect) must reproduce VS_SELECT_STL_HOST
+    # exactly: same survivors in the same order => the same fp64 sums => bit-identical transforms
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 5, seed=33, channels=ch)
+    host = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STL_HOST, **kw)
+    dev = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_DEVICE, **kw)
+    sh, th = host.align_batch(frames)
+    sd, td = dev.align_batch(frames)
+    assert sh == sd and sum(sh) >= 3
+    for i in range(len(frames)):
+        assert th[i].tup() == td[i].tup(), i
+        ih, idv = host.info(i), dev.info(i)
+        assert list(ih.iterations) == list(idv.iterations) and list(ih.condition) == list(idv.condition)
+    cpu = oracle.Aligner(**kw)
+    for i, f in enumerate(frames[:3]):
+        ok_c, t_c = cpu.align_next(f)
+        assert ok_c == bool(sd[i])
+        if ok_c:
+            assert _cmp_transform(td[i], t_c) < TOL
+
+
+def test_device_selection_failures_and_sequence(gpu_vs, oracle):
+    from video_stabilizer_amd import synth
+    path = [(0, 0, 0, 0), (0, 0, 60.0, -45.0), (0, 0, 0, 0), (0.0, 0.3, 0, 0), (0, 0, 1, 1)]
+    frames, _ = synth.make_clip(320, 240, 5, seed=51, path=path, margin=160)
+    for kw in ({}, dict(max_iters=2)):
+        gpu, cpu, res = _run_both(gpu_vs, oracle, frames, select_mode=gpu_vs.SELECT_DEVICE, **kw)
+        _check_seq(res)
+
+
 def test_batch_equals_sequential(gpu_vs, oracle):
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(640, 360, 9, seed=41, channels=3)

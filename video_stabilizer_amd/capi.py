@@ -97,6 +97,7 @@ SIGNATURES = {
     "vs_keyframe_fused": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "vs_sparse_warpdiff": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "vs_sparse_ica": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "vs_select_smallest": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
     "vs_image_warp": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _i32, _i32, _vp]),
     "vs_bgr_image_warp": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vs_bgr_image_warp_batch": (_i32, [_vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _sz, _i32, _i32, _vp]),
@@ -337,6 +338,18 @@ def sparse_ica(tmpl, key, selx, sely, jacx, jacy, t):
     return sparse_ica_raw(tmpl, key, selx, sely, jacx, jacy, float(p[0]), float(p[1]), float(p[2]), float(p[3]))
 
 
+def select_smallest(warpdiff, fraction=0.8):
+    """warpdiff: (ty,tx) or (n,ty,tx) u16.  returns (list of idx arrays, status array)"""
+    wd = _c(warpdiff, np.uint16)
+    if wd.ndim == 2:
+        wd = wd[None]
+    n, ty, tx = wd.shape
+    idx = np.empty((n, ty * tx), np.int32)
+    status = np.empty(n, np.int32)
+    cnt = _check(lib().vs_select_smallest(_p(wd), n, tx, ty, fraction, _p(idx), _p(status), MEM_HOST, None))
+    return [idx[i, :cnt].copy() for i in range(n)], status
+
+
 def image_warp_raw(img, A, B, TX, TY, out_shape=None):
     img = _c(img, np.uint8)
     h, w = img.shape
@@ -414,7 +427,7 @@ def _fmt_of(frame_dtype, ndim_tail):
 class Aligner:
     """VideoAligner (alignment.hpp:51-99) on the GPU engine."""
 
-    def __init__(self, device=0, select_mode=SELECT_STL_HOST, **params):
+    def __init__(self, device=0, select_mode=SELECT_DEVICE, **params):
         self.params = aligner_params(**params)
         self.h = lib().vs_aligner_create(C.byref(self.params), device)
         if not self.h:

@@ -5,6 +5,9 @@
 #include "vs_internal.hpp"
 #include "vs_kernels.hpp"
 
+#include <cstring>
+#include <deque>
+#include <mutex>
 #include <vector>
 
 namespace vsi {
@@ -49,6 +52,68 @@ using vsi::set_error;
 
 #define VS_TRY(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
 #define VS_ARG(cond) do { if (!(cond)) return set_error(VS_ERR_ARG, "bad argument: %s (%s)", #cond, __func__); } while (0)
+
+
+// Pinned host ring + device mirror for small parameter blocks.  upload() copies `n` float4 into the next
+// free span of the pinned ring, enqueues H2D into the same span of the device mirror on `s`, and returns
+// the device pointer.  A span is reused only after the event recorded behind its last consumer-side copy
+// has completed, so the call never blocks in steady state and the source of an in-flight copy is never
+// overwritten.  (The kernel that consumes the span runs on the same stream, after the copy.)
+namespace {
+struct ParamRing {
+    static constexpr size_t kSlots = 1 << 15;    // 32768 float4 = 512 KiB
+    std::mutex mu;
+    float4* host = nullptr;
+    float4* dev[16] = {};
+    int dev_of = -1;
+    size_t head = 0;
+    struct Busy { size_t begin, end; hipEvent_t ev; int device; };
+    std::deque<Busy> busy;
+    int upload(const float* src, size_t n, hipStream_t s, float4** out) {
+        if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
+        std::lock_guard<std::mutex> lock(mu);
+        int device = 0;
+        VS_HIP(hipGetDevice(&device));
+        if (device < 0 || device >= 16) return vsi::set_error(VS_ERR_UNSUPPORTED, "device index %d", device);
+        if (!host) VS_HIP(hipHostMalloc((void**)&host, kSlots * sizeof(float4)));
+        if (!dev[device]) VS_HIP(hipMalloc((void**)&dev[device], kSlots * sizeof(float4)));
+        if (head + n > kSlots) head = 0;
+        const size_t b = head, e = head + n;
+        // wait for (and retire) every in-flight span that overlaps [b, e)
+        for (auto it = busy.begin(); it != busy.end();) {
+            if (it->begin < e && b < it->end) {
+                VS_HIP(hipEventSynchronize(it->ev));
+                (void)hipEventDestroy(it->ev);
+                it = busy.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        memcpy(host + b, src, n * sizeof(float4));
+        VS_HIP(hipMemcpyAsync(dev[device] + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s));
+        *out = dev[device] + b;
+        head = e;
+        return VS_OK;
+    }
+    // called after the consuming kernel has been enqueued on `s`
+    int fence(float4* p, size_t n, hipStream_t s) {
+        std::lock_guard<std::mutex> lock(mu);
+        int device = 0;
+        VS_HIP(hipGetDevice(&device));
+        Busy bz{(size_t)(p - dev[device]), (size_t)(p - dev[device]) + n, nullptr, device};
+        VS_HIP(hipEventCreateWithFlags(&bz.ev, hipEventDisableTiming));
+        VS_HIP(hipEventRecord(bz.ev, s));
+        busy.push_back(bz);
+        while (busy.size() > 64) {   // keep the list short: retire the oldest
+            VS_HIP(hipEventSynchronize(busy.front().ev));
+            (void)hipEventDestroy(busy.front().ev);
+            busy.pop_front();
+        }
+        return VS_OK;
+    }
+};
+ParamRing g_param_ring;
+}  // namespace
 
 static inline size_t img_span(int w, int h, int stride, int channels) {
     return (size_t)(h - 1) * stride + (size_t)w * channels;
@@ -214,11 +279,10 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     const size_t esz = bits / 8, osz = f32out ? 4 : esz;
     std::vector<float> P((size_t)n_frames * 4);
     for (int i = 0; i < n_frames; i++) vs_ul_params_warp(&t[i], w, h, &P[(size_t)i * 4]);
-    // stream-ordered allocation: freed on the stream after the kernel, so a VS_MEM_DEVICE call never syncs
+    // Per-frame kernel parameters travel host -> device through a pinned ring (ParamRing below), so a
+    // VS_MEM_DEVICE call stays asynchronous and never reads a host buffer that has gone out of scope.
     float4* pdev = nullptr;
-    VS_HIP(hipMallocAsync((void**)&pdev, P.size() * 4, s));
-    struct Free { float4* p; hipStream_t s; ~Free() { (void)hipFreeAsync(p, s); } } free_params{pdev, s};
-    VS_HIP(hipMemcpyAsync(pdev, P.data(), P.size() * 4, hipMemcpyHostToDevice, s));
+    VS_TRY(g_param_ring.upload(P.data(), (size_t)n_frames, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
     const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(w, h, dst_stride, channels)) * osz;
@@ -232,6 +296,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, s);
     VS_HIP(e);
+    VS_TRY(g_param_ring.fence(pdev, (size_t)n_frames, s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
 }

@@ -35,6 +35,9 @@ namespace {
 
 constexpr int kMaxLevels = 16;
 constexpr int kGnThreads = 1024;
+// on-device selection keeps (abs_delta,index) u32 + a u16 rank table per tile in LDS: 6 B x tiles <= 160 KB less
+// the static part; index fits 16 bits; a thread's chunk fits a 32-bit mask
+constexpr int kSelectCap = 26000;
 
 struct LevelDims {
     int w, h, ts, tx, ty, nt, nsel;
@@ -120,31 +123,24 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
     for (int k = 0; k < 4; k++) jo[(size_t)k * nsel + j] = jac[(size_t)k * nt + t];
 }
 
-// ---- persistent Gauss-Newton level solver: alignment.cpp:548-688 --------------------------------
-// One workgroup per frame pair.  H = sum j j^T (fp64) -> cond / Tikhonov / pseudo-inverse once,
-// then up to max_iters iterations of { sparse_ica (generators.cpp:429-596) -> dt = Hinv b ->
-// delta.compose(T) -> corner test }, all without leaving the device.  Every thread carries the
-// (identical) fp64 transform state in registers; the only exchange per iteration is the block sum.
-__global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restrict__ states,
-                                                            const PairDesc* __restrict__ descs,
-                                                            const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                            size_t img_off, int w, int h, int nsel,
-                                                            const uint16_t* __restrict__ sel, size_t sel_pair,
-                                                            const float* __restrict__ seljac, size_t seljac_pair,
-                                                            int level, GnParams gp) {
-    __shared__ double red[2][(kGnThreads / 64) * 10];
-    __shared__ double s_hinv[17];
-    const int p = blockIdx.x;
-    PairState& st = states[p];
-    if (st.status != 1) return;   // uniform for the block
-    const PairDesc d = descs[p];
-    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
-    const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
-    const uint16_t* selx = sel + (size_t)p * sel_pair;
-    const uint16_t* sely = selx + 2 * (size_t)nsel;
-    const float* jacx = seljac + (size_t)p * seljac_pair;
-    const float* jacy = jacx + 4 * (size_t)nsel;
+// ---- Gauss-Newton level solver: alignment.cpp:548-688 -------------------------------------------
+// Runs inside a workgroup that owns one frame pair.  H = sum j j^T (fp64) -> cond / Tikhonov /
+// pseudo-inverse once, then up to max_iters iterations of { sparse_ica (generators.cpp:429-596) ->
+// dt = Hinv b -> delta.compose(T) -> corner test }, all without leaving the device.  Every thread
+// carries the (identical) fp64 transform in registers; the only exchange per iteration is the block
+// sum.  T is updated in place (including the x2 of TX,TY when moving to a finer level).
+// Returns 0 ok / 2 max iterations / 3 over displacement; *iters_out, *cond_out as the reference logs.
+struct GnShared {
+    double red[2][(kGnThreads / 64) * 10];
+    double hinv[17];
+    double c0[8];   // corners at level start (block-uniform; parked here instead of 16 VGPRs)
+};
 
+__device__ __forceinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ tmpl, const uint8_t* __restrict__ key,
+                                        int w, int h, int nsel, const uint16_t* __restrict__ selx,
+                                        const uint16_t* __restrict__ sely, const float* __restrict__ jacx,
+                                        const float* __restrict__ jacy, int level, const GnParams& gp, double T[4],
+                                        int* iters_out, double* cond_out) {
     // Hessian (alignment.cpp:278-332): upper triangle of sum j j^T over both sets, in fp64
     {
         double hacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -160,7 +156,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
                     for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
             }
         }
-        block_sum<10>(hacc, red[0]);
+        block_sum<10>(hacc, sh.red[0]);
         if (threadIdx.x < 64) {   // one wave does the 4x4 eigen work; the others wait at the barrier
             double H[16], Hinv[16];
             int k = 0;
@@ -171,16 +167,19 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
             double cond = condition_and_invert(H, Hinv);
             if (threadIdx.x == 0) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) s_hinv[i] = Hinv[i];
-                s_hinv[16] = cond;
+                for (int i = 0; i < 16; i++) sh.hinv[i] = Hinv[i];
+                sh.hinv[16] = cond;
             }
         }
         __syncthreads();
     }
-    // Hinv and the level-start corners are block-uniform: they stay in LDS, not in 48 VGPRs
-    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
+    // Hinv is block-uniform: it stays in LDS, not in 32 VGPRs
     double c1[8];
     warp_corners(T, w, h, c1);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) sh.c0[i] = c1[i];   // read back after the loop (>= 1 barrier in between)
+    }
 
     const double scale = 1.0 / w;   // alignment.cpp:629
     int iters = 0, fail = 0;
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
                 for (int c = 0; c < 4; c++) a[c] += (double)(jac[(size_t)c * nsel + r] * residual);
             }
         }
-        block_sum<8>(acc, red[(iter & 1) ^ 1]);
+        block_sum<8>(acc, sh.red[(iter & 1) ^ 1]);
         double b[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) b[c] = (acc[c] + acc[4 + c]) * 0.5f;   // generators.cpp:595
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
         for (int r = 0; r < 4; r++) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) s += s_hinv[r * 4 + k] * b[k];
+            for (int k = 0; k < 4; k++) s += sh.hinv[r * 4 + k] * b[k];
             dt[r] = s;
         }
         double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
@@ -233,16 +232,274 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
     }
     if (!fail) {
         double c0[8];
-        double T0[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};   // state is only rewritten below
-        warp_corners(T0, w, h, c0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) c0[i] = sh.c0[i];
         double disp01 = corner_move(c0, c1);
         if (disp01 > gp.max_displacement) fail = 3;
     }
     if (!fail && level > 0) { T[2] *= 2.0; T[3] *= 2.0; }   // alignment.cpp:683-687
+    *iters_out = iters;
+    *cond_out = sh.hinv[16];
+    // sh.hinv / sh.red are rewritten by the next level only after its own barriers
+    return fail;
+}
+
+// Per-level form (selection on the host between launches: VS_SELECT_STL_HOST)
+__global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restrict__ states,
+                                                            const PairDesc* __restrict__ descs,
+                                                            const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                            size_t img_off, int w, int h, int nsel,
+                                                            const uint16_t* __restrict__ sel, size_t sel_pair,
+                                                            const float* __restrict__ seljac, size_t seljac_pair,
+                                                            int level, GnParams gp) {
+    __shared__ GnShared sh;
+    const int p = blockIdx.x;
+    PairState& st = states[p];
+    if (st.status != 1) return;   // uniform for the block
+    const PairDesc d = descs[p];
+    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
+    const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
+    const uint16_t* selx = sel + (size_t)p * sel_pair;
+    const float* jacx = seljac + (size_t)p * seljac_pair;
+    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
+    int iters;
+    double cond;
+    const int fail = gn_level(sh, tmpl, key, w, h, nsel, selx, selx + 2 * (size_t)nsel, jacx, jacx + 4 * (size_t)nsel,
+                              level, gp, T, &iters, &cond);
+    __syncthreads();   // every thread has read st.T before thread 0 rewrites it
     if (threadIdx.x == 0) {
         st.iterations[level] = iters;
-        st.condition[level] = s_hinv[16];
+        st.condition[level] = cond;
         if (fail) { st.status = 0; st.fail_reason = fail; st.fail_level = level; }
+        st.T[0] = T[0]; st.T[1] = T[1]; st.T[2] = T[2]; st.T[3] = T[3];
+    }
+}
+
+// ---- on-device replica of libstdc++'s std::nth_element (bits/stl_algo.h, GCC 11) -----------------
+// alignment.cpp:466-486 calls std::nth_element(begin, begin+n, end, abs_delta <) and keeps the first
+// n elements.  Which tied elements survive, and in which order, is decided by libstdc++'s
+// __introselect: median-of-3 (first+1, mid, last-1) moved to `first`, an unguarded Hoare partition of
+// [first+1,last) around it, recurse into the side holding nth, insertion sort once <= 3 remain.
+// The Hoare sweep is sequential in the STL but depends only on the ORIGINAL values: its k-th swap
+// exchanges the k-th left stopper (a[i] >= pivot, scanning up) with the k-th right stopper
+// (a[j] <= pivot, scanning down) for as long as the former lies left of the latter, and it returns
+// the first left stopper that did not swap (or the last right stopper that did).  That is a pair of
+// prefix counts, so one partition is a few block-wide scans.  tests/test_select_gpu.py checks the
+// permutation against the host's std::nth_element on tie-heavy inputs.
+// Elements are packed (abs_delta << 16) | tile_index; only abs_delta takes part in comparisons.
+struct SelShared {
+    int wl[kGnThreads / 64], wr[kGnThreads / 64];   // per-wave stopper counts
+    int red_k[kGnThreads / 64], red_c[kGnThreads / 64];
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// returns 0 on success, 1 when libstdc++ would have fallen back to heap-select (depth limit): the
+// caller then re-runs the pair through the host path.
+__device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t* __restrict__ posR, SelShared& ss,
+                                              int n, int nth) {
+    if (n == 0 || nth == n) return 0;                 // std::nth_element's early return
+    int first = 0, last = n;
+    int depth = 2 * (31 - __clz(n));                  // std::__lg(n) * 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    while (last - first > 3) {
+        if (depth == 0) return 1;
+        --depth;
+        // __unguarded_partition_pivot: __move_median_to_first(first, first+1, mid, last-1)
+        if (tid == 0) {
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            const uint32_t A = a[ia] >> 16, B = a[ib] >> 16, C = a[ic] >> 16;
+            int m;
+            if (A < B) m = (B < C) ? ib : ((A < C) ? ic : ia);
+            else if (A < C) m = ia;
+            else if (B < C) m = ic;
+            else m = ib;
+            const uint32_t t = a[first]; a[first] = a[m]; a[m] = t;
+        }
+        __syncthreads();
+        const uint32_t pv = a[first] >> 16;
+        const int f0 = first + 1, m = last - f0;
+        const int chunk = (m + kGnThreads - 1) / kGnThreads;   // <= 32: the caller caps n at 32*kGnThreads
+        const int lo = min(f0 + tid * chunk, last), hi = min(lo + chunk, last);
+        // classify my chunk once, from the unmodified values: bit e of maskL / maskR = element lo+e stops the
+        // left / right scan.  Later passes use only the masks, so swaps by other threads cannot disturb them.
+        uint32_t maskL = 0, maskR = 0;
+        for (int i = lo; i < hi; i++) {
+            const uint32_t k = a[i] >> 16;
+            maskL |= (uint32_t)(k >= pv) << (i - lo);
+            maskR |= (uint32_t)(k <= pv) << (i - lo);
+        }
+        const int cl = __popc(maskL), cr = __popc(maskR);
+        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
+        if (lane == 63) { ss.wl[wave] = il; ss.wr[wave] = ir; }
+        __syncthreads();
+        int pre_l = il - cl, pre_r_incl = ir, nR = 0;
+        for (int wv = 0; wv < kGnThreads / 64; wv++) {
+            const int a_l = ss.wl[wv], a_r = ss.wr[wv];
+            if (wv < wave) { pre_l += a_l; pre_r_incl += a_r; }
+            nR += a_r;
+        }
+        // right-stopper ranks count from the right: rank of my topmost stopper = # stoppers after my chunk
+        {
+            int rk = nR - pre_r_incl;
+            uint32_t mr = maskR;
+            while (mr) {
+                const int e = 31 - __clz(mr);
+                mr &= ~(1u << e);
+                posR[rk++] = (uint16_t)(lo + e);
+            }
+        }
+        __syncthreads();
+        // left stoppers in increasing order: rank k swaps with posR[k] while it lies to the left of it.
+        // Swapped pairs are disjoint (every swapping left stopper is left of every swapping right stopper).
+        int swaps = 0, cand = 0x7fffffff;
+        {
+            int k = pre_l;
+            uint32_t ml = maskL;
+            while (ml) {
+                const int e = __ffs(ml) - 1;
+                ml &= ml - 1;
+                const int i = lo + e;
+                const int j = k < nR ? (int)posR[k] : -1;
+                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
+                else if (cand == 0x7fffffff) cand = i;
+                k++;
+            }
+        }
+        // K = total swaps; cand = position of the first left stopper that did not swap
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            swaps += __shfl_down(swaps, off, 64);
+            cand = min(cand, __shfl_down(cand, off, 64));
+        }
+        if (lane == 0) { ss.red_k[wave] = swaps; ss.red_c[wave] = cand; }
+        __syncthreads();
+        int K = 0, c = 0x7fffffff;
+        for (int wv = 0; wv < kGnThreads / 64; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
+        const int RK = K > 0 ? (int)posR[K - 1] : last;
+        const int cut = (c != 0x7fffffff && c < RK) ? c : RK;
+        if (cut <= nth) first = cut; else last = cut;
+        __syncthreads();   // posR / ss are rewritten by the next round
+    }
+    // __insertion_sort(first, last) on <= 3 elements
+    if (tid == 0) {
+        for (int i = first + 1; i < last; i++) {
+            const uint32_t v = a[i];
+            if ((v >> 16) < (a[first] >> 16)) {
+                for (int j = i; j > first; j--) a[j] = a[j - 1];
+                a[first] = v;
+            } else {
+                int j = i;
+                while ((v >> 16) < (a[j - 1] >> 16)) { a[j] = a[j - 1]; j--; }
+                a[j] = v;
+            }
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
+// Kernel-level selection op (one block per array): out_idx[0..nsel) = tile indices in the order
+// std::nth_element leaves them.  status[b] = 1 when the depth limit was hit.
+__global__ __launch_bounds__(kGnThreads) void vs_k_select(const uint16_t* __restrict__ wd, int nt, int nsel,
+                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+    __shared__ SelShared ss;
+    uint32_t* a = (uint32_t*)dyn;
+    uint16_t* posR = (uint16_t*)(a + nt);
+    wd += (size_t)blockIdx.x * nt;
+    out_idx += (size_t)blockIdx.x * nt;
+    for (int i = threadIdx.x; i < nt; i += kGnThreads) a[i] = ((uint32_t)wd[i] << 16) | (uint32_t)i;
+    __syncthreads();
+    const int r = introselect_block(a, posR, ss, nt, nsel);
+    for (int i = threadIdx.x; i < nsel; i += kGnThreads) out_idx[i] = (int32_t)(a[i] & 0xffffu);
+    if (threadIdx.x == 0) status[blockIdx.x] = r;
+}
+
+// ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
+struct FusedLevels {
+    int levels;
+    int w[kMaxLevels], h[kMaxLevels], nt[kMaxLevels], nsel[kMaxLevels];
+    unsigned long long img_off[kMaxLevels], lm_off[kMaxLevels], jac_off[kMaxLevels];
+};
+
+__global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __restrict__ states,
+                                                               const PairDesc* __restrict__ descs,
+                                                               const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                               const uint16_t* __restrict__ lm_tab, size_t lm_frame,
+                                                               const float* __restrict__ jac_tab, size_t jac_frame,
+                                                               uint16_t* __restrict__ sel, size_t sel_pair,
+                                                               float* __restrict__ seljac, size_t seljac_pair,
+                                                               int nt_cap, FusedLevels fl, GnParams gp) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
+    __shared__ SelShared ss;
+    __shared__ GnShared sh;
+    uint32_t* a = (uint32_t*)dyn;
+    uint16_t* posR = (uint16_t*)(a + nt_cap);
+    const int p = blockIdx.x;
+    PairState& st = states[p];
+    const PairDesc d = descs[p];
+    double T[4] = {0.0, 0.0, 0.0, 0.0};     // alignment.cpp:344 identity
+    int fail = 0, fail_level = 0;
+    for (int l = fl.levels - 1; l >= 0 && !fail; l--) {
+        const int w = fl.w[l], h = fl.h[l], nt = fl.nt[l], nsel = fl.nsel[l];
+        const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + fl.img_off[l];
+        const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + fl.img_off[l];
+        uint16_t* selx = sel + (size_t)p * sel_pair;
+        float* jacx = seljac + (size_t)p * seljac_pair;
+        float P[4];
+        ul_params_sparse(T, w, h, P);
+        const float A1 = 1.0f + P[0];
+        for (int set = 0; set < 2 && !fail; set++) {
+            const uint16_t* lm = lm_tab + (size_t)d.key_slot * lm_frame + fl.lm_off[l] + (size_t)set * 2 * nt;
+            const float* jac = jac_tab + (size_t)d.key_slot * jac_frame + fl.jac_off[l] + (size_t)set * 4 * nt;
+            // sparse_warpdiff (generators.cpp:646-700) straight into the selection array, row-major tile order
+            for (int i = threadIdx.x; i < nt; i += kGnThreads) {
+                int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
+                float ox = (float)tile_x, oy = (float)tile_y;
+                float Wx = A1 * ox - P[1] * oy + P[2];
+                float Wy = P[1] * ox + A1 * oy + P[3];
+                float v = lanczos_sample_u8(key, w, h, w, Wx, Wy);
+                float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
+                diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
+                a[i] = ((uint32_t)(uint16_t)diff << 16) | (uint32_t)i;
+            }
+            __syncthreads();
+            if (introselect_block(a, posR, ss, nt, nsel)) { fail = 100; fail_level = l; }
+            // gather (alignment.cpp:523-546) in the order nth_element left the survivors
+            uint16_t* so = selx + (size_t)set * 2 * nsel;
+            float* jo = jacx + (size_t)set * 4 * nsel;
+            for (int j = threadIdx.x; j < nsel; j += kGnThreads) {
+                const int t = (int)(a[j] & 0xffffu);
+                so[j] = lm[t];
+                so[nsel + j] = lm[nt + t];
+#pragma unroll
+                for (int k = 0; k < 4; k++) jo[(size_t)k * nsel + j] = jac[(size_t)k * nt + t];
+            }
+            __syncthreads();   // a[] is refilled by the next set; sel/seljac stores are visible block-wide
+        }
+        if (fail) break;
+        int iters;
+        double cond;
+        const int f = gn_level(sh, tmpl, key, w, h, nsel, selx, selx + 2 * (size_t)nsel, jacx, jacx + 4 * (size_t)nsel, l, gp,
+                               T, &iters, &cond);
+        if (threadIdx.x == 0) { st.iterations[l] = iters; st.condition[l] = cond; }
+        if (f) { fail = f; fail_level = l; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st.status = fail ? 0 : 1;
+        st.fail_reason = fail;
+        st.fail_level = fail_level;
         st.T[0] = T[0]; st.T[1] = T[1]; st.T[2] = T[2]; st.T[3] = T[3];
     }
 }
@@ -256,7 +513,7 @@ struct vs_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
     vs_aligner_params params;
-    int select_mode = VS_SELECT_STL_HOST;
+    int select_mode = VS_SELECT_DEVICE;   // same survivors in the same order as the host path (tests/test_select_gpu.py)
 
     // sequence state (alignment.hpp:61-70)
     int W = -1, H = -1, fmt = -1;
@@ -534,14 +791,40 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
 
         const size_t wd_pair = (size_t)2 * nt_max, sel_pair = (size_t)4 * nt_max, seljac_pair = (size_t)8 * nt_max;
         GnParams gp{p.threshold, p.max_displacement, p.max_iters};
-        for (int l = levels - 1; l >= 0; l--) {
+        bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
+        if (!use_host) {
+            // VS_SELECT_DEVICE: every level of every pair in one launch (selection = on-device introselect)
+            FusedLevels fl;
+            fl.levels = levels;
+            for (int l = 0; l < levels; l++) {
+                fl.w[l] = L[l].w; fl.h[l] = L[l].h; fl.nt[l] = L[l].nt; fl.nsel[l] = L[l].nsel;
+                fl.img_off[l] = L[l].img_off; fl.lm_off[l] = L[l].lm_off; fl.jac_off[l] = L[l].jac_off;
+            }
+            const size_t dyn = (((size_t)nt_max * 6 + 15) & ~(size_t)15);
+            VS_HIP(hipFuncSetAttribute((const void*)vs_k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            t_begin(VS_STAGE_GN);
+            hipLaunchKernelGGL(vs_k_align_pairs, dim3(n_pairs), dim3(kGnThreads), dyn, s, states, descs, pyr, pyr_frame, lm,
+                               lm_frame, jac, jac_frame, sel, sel_pair, seljac, seljac_pair, nt_max, fl, gp);
+            VS_HIP(hipGetLastError());
+            t_end(1);
+            VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+            VS_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < n_pairs; q++)
+                if (h_states[q].fail_reason == 100) use_host = true;   // libstdc++ would have heap-selected: redo on the host
+            if (use_host) {
+                for (int q = 0; q < n_pairs; q++) { memset(&h_states[q], 0, sizeof(PairState)); h_states[q].status = 1; }
+                VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
+                VS_HIP(hipStreamSynchronize(s));
+            }
+        }
+        for (int l = levels - 1; use_host && l >= 0; l--) {
             const LevelDims& ld = L[l];
             t_begin(VS_STAGE_WARPDIFF);
             hipLaunchKernelGGL(vs_k_warpdiff_batch, dim3((ld.nt + 255) / 256, n_pairs, 2), dim3(256), 0, s, states, descs, pyr,
                                pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, ld.nt, wd, wd_pair);
             VS_HIP(hipGetLastError());
             t_end(1);
-            if (select_mode == VS_SELECT_STL_HOST) {
+            {
                 const auto t0 = std::chrono::steady_clock::now();
                 VS_HIP(hipMemcpyAsync(h_wd, wd, (size_t)n_pairs * wd_pair * 2, hipMemcpyDeviceToHost, s));
                 VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -549,8 +832,6 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 VS_TRY(select_host(n_pairs, ld));
                 VS_HIP(hipMemcpyAsync(idx, h_idx, (size_t)n_pairs * wd_pair * 4, hipMemcpyHostToDevice, s));
                 if (timing) tm.ms[VS_STAGE_SELECT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            } else {
-                return set_error(VS_ERR_UNSUPPORTED, "VS_SELECT_DEVICE is not built yet");
             }
             if (ld.nsel > 0) {
                 t_begin(VS_STAGE_GATHER);
@@ -566,8 +847,10 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipGetLastError());
             t_end(1);
         }
-        VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
+        if (use_host) {
+            VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+            VS_HIP(hipStreamSynchronize(s));
+        }
         for (int q = 0; q < n_pairs; q++) {
             const int i = first_pair + q;
             const PairState& st = h_states[q];
@@ -591,6 +874,31 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
 }
 
 extern "C" {
+
+// Kernel-level form of the keep-best-fraction step (alignment.cpp:435-492) for n_arrays independent
+// warpdiff tables: out_idx[a*tx*ty + 0..count) = tile_y*tx+tile_x of the survivors in std::nth_element's order.
+int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
+                       int32_t* status, int mem, void* stream) {
+    VS_ARG(warpdiff && out_idx && status && n_arrays >= 1 && tx >= 1 && ty >= 1 && fraction > 0.0f && fraction <= 1.0f);
+    const int nt = tx * ty;
+    if (nt > kSelectCap) return set_error(VS_ERR_UNSUPPORTED, "%d tiles exceed the on-device selection capacity %d", nt, kSelectCap);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    const int nsel = (int)static_cast<size_t>((size_t)nt * fraction);
+    vsi::Staged a, o, st;
+    VS_TRY(a.in(warpdiff, (size_t)n_arrays * nt * 2, mem, s));
+    VS_TRY(o.out(out_idx, (size_t)n_arrays * nt * 4, mem));
+    VS_TRY(st.out(status, (size_t)n_arrays * 4, mem));
+    const size_t dyn = (((size_t)nt * 6 + 15) & ~(size_t)15);
+    VS_HIP(hipFuncSetAttribute((const void*)vs_k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(vs_k_select, dim3(n_arrays), dim3(kGnThreads), dyn, s, a.as<uint16_t>(), nt, nsel, o.as<int32_t>(),
+                       st.as<int32_t>());
+    VS_HIP(hipGetLastError());
+    VS_TRY(o.finish(s));
+    VS_TRY(st.finish(s));
+    if (mem == VS_MEM_HOST) VS_HIP(hipStreamSynchronize(s));
+    return nsel;
+}
 
 vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
     if (!vsi::device_ready()) return nullptr;
