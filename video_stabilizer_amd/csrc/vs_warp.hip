@@ -10,20 +10,25 @@
 //   1. The similarity is affine, so the tile's source footprint is the bounding box of its four
 //      corners (fp32 rounding is monotonic, so the corners bound every pixel exactly).  For the
 //      near-identity transforms of stabilisation that is ~67x19 pixels.
-//   2. The footprint (+ the Lanczos halo) is copied HBM -> LDS once as raw interleaved bytes with
-//      aligned dword loads; clamp-to-edge / constant-0 borders are resolved during this copy, so the
-//      inner loop has no address clamps and no global loads at all.
-//   3. Each thread produces 4 adjacent pixels of one row.  A tap row (4 px x BGR = 12 bytes at an
-//      arbitrary byte offset) is 4 LDS dwords re-aligned with v_alignbyte_b32 and unpacked with
-//      v_cvt_f32_ubyteN; all LDS offsets are immediates off one address register.
-//   4. 12 output bytes per thread leave as one 12-byte store; a wave writes 4 x 192 contiguous bytes.
+//   2. The footprint (+ the Lanczos halo) is read from HBM once with aligned 12-byte loads (4 pixels),
+//      converted to float ONCE, and parked in LDS as one float4 {B,G,R,1} per source pixel.  Clamp /
+//      constant-0 borders are resolved here, so the inner loop has no clamps and no global loads.
+//   3. Lane = output column, each wave owns 4 output rows.  One tap = one ds_read_b128 at an immediate
+//      offset from a single address register; neighbouring lanes read neighbouring 16-byte slots, so
+//      the reads are conflict-free.  The arithmetic is packed fp32 (v_pk_mul_f32 / v_pk_add_f32 on
+//      {B,G} and {R,den} pairs -- the trailing 1.0 makes den += w fall out of the same instruction,
+//      and w*1.0 is exact) and the eight polynomial weights run as four {x,y} packed Horner chains.
+//      Packed instructions issue at the scalar-VALU rate on gfx950, so this halves the VALU time;
+//      each component still sees exactly the reference's sequence of roundings.
+//   4. Results are transposed through a 3 KB LDS tile so that the stores leave as aligned dwords,
+//      192 contiguous bytes per output row.
 // Tiles whose footprint does not fit the LDS window (large rotation / zoom) take the generic
 // global-memory path inside the same kernel, so every transform is supported.
 //
-// Cost model (DESIGN.md "bgr_image_warp roofline"): ~380 VALU instructions per output pixel in the
-// exact-order Lanczos2 form (8 polynomial weights = 120, 16 taps x 3 channels mul+add = 128, byte
-// unpack = 60, 3 IEEE divides = 30, ...), which is above the HBM time of the 6 bytes the pixel moves:
-// the kernel is VALU-bound, not HBM-bound, on gfx950.
+// Cost model (DESIGN.md "bgr_image_warp roofline"): measured with rocprofv3 PMC the exact-order
+// Lanczos2 form needs a few hundred VALU instructions per output pixel against 6 bytes of HBM
+// traffic, and a wave64 VALU instruction occupies its SIMD for 4 cycles: the kernel is VALU-bound,
+// not HBM-bound, on gfx950 (bilinear is ~4x lighter).
 #include "vs_kernels.hpp"
 #include "vs_device.hpp"
 
@@ -32,9 +37,12 @@ using namespace vsd;
 namespace {
 
 constexpr int WT_W = 64, WT_H = 16;      // output tile
-constexpr int WS_BYTES = 240;            // staged bytes per source row (80 px)
-constexpr int WS_PITCH_DW = 61;          // LDS row pitch in dwords (244 B: odd pitch spreads rows over banks)
-constexpr int WS_H = 32;                 // staged source rows
+constexpr int WS_W = 80;                 // staged source pixels per row (multiple of 4)
+constexpr int WS_H = 24;                 // staged source rows
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
@@ -46,7 +54,34 @@ __device__ __forceinline__ uint32_t store_u8(float v) {
     return (uint32_t)r;
 }
 
-// one pixel, all three channels, straight from global memory (footprint too large for the LDS window)
+// generators.cpp:31-47 on an {x,y} pair: identical roundings per component, packed instructions.
+// EDGE = the argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]); for taps 2
+// and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
+template <bool EDGE>
+__device__ __forceinline__ f2 lanczos2_pk(f2 x) {
+    f2 x2 = x * x;
+    f2 v = 0.000858519f;
+    v = -0.0158853f + v * x2;
+    v = 0.128693f + v * x2;
+    v = -0.583468f + v * x2;
+    v = 1.52229f + v * x2;
+    v = -2.05238f + v * x2;
+    v = 0.999861f + v * x2;
+    if (EDGE) {
+        v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
+        v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
+    }
+    return v;
+}
+
+// 4 adjacent lanes hold one BGR pixel each (p = B | G<<8 | R<<16); lanes 0..2 of the quad assemble the three
+// dwords of the 12-byte group from their own pixel and their right neighbour's: bytes m..m+3 of {own, next}.
+__device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, int m) {
+    const uint32_t q = (uint32_t)__shfl_down((int)p, 1, 64);
+    const uint32_t lo = p | (q << 24), hi = q >> 8;
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)m);
+}
+
 template <int MODE, int BORDER>
 __device__ __forceinline__ void warp_pixel_global(const uint8_t* __restrict__ src, int w, int h, int stride, float Wx,
                                                   float Wy, uint32_t out[3]) {
@@ -83,13 +118,11 @@ __device__ __forceinline__ void warp_pixel_global(const uint8_t* __restrict__ sr
     }
 }
 
-__device__ __forceinline__ int floor_div3(int v) { return v >= 0 ? v / 3 : -((2 - v) / 3); }
-
 template <int MODE, int BORDER>
 __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
                                                           const float4* __restrict__ params, uint8_t* __restrict__ dst,
                                                           int dst_stride, size_t src_fs, size_t dst_fs) {
-    __shared__ uint32_t tile[WS_H * WS_PITCH_DW + 4];
+    __shared__ f4 tile[WS_H * WS_W];                       // {B,G,R,1} per staged source pixel
     const float4 P = params[blockIdx.z];
     src += blockIdx.z * src_fs;
     dst += blockIdx.z * dst_fs;
@@ -97,130 +130,132 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
     const int x0 = blockIdx.x * WT_W, y0 = blockIdx.y * WT_H;
     const int x1 = min(x0 + WT_W, w) - 1, y1 = min(y0 + WT_H, h) - 1;
 
-    // source footprint of the tile: the four corners, evaluated with the per-pixel expression
-    float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
-    float cxs[4] = {A1 * fx0 - B * fy0 + TX, A1 * fx1 - B * fy0 + TX, A1 * fx0 - B * fy1 + TX, A1 * fx1 - B * fy1 + TX};
-    float cys[4] = {B * fx0 + A1 * fy0 + TY, B * fx1 + A1 * fy0 + TY, B * fx0 + A1 * fy1 + TY, B * fx1 + A1 * fy1 + TY};
-    float mnx = fminf(fminf(cxs[0], cxs[1]), fminf(cxs[2], cxs[3])), mxx = fmaxf(fmaxf(cxs[0], cxs[1]), fmaxf(cxs[2], cxs[3]));
-    float mny = fminf(fminf(cys[0], cys[1]), fminf(cys[2], cys[3])), mxy = fmaxf(fmaxf(cys[0], cys[1]), fmaxf(cys[2], cys[3]));
+    // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is
+    // monotone), so its extremes over the tile sit at corners chosen by the signs of A1 and B: 4 evaluations.
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float xa = A1 >= 0.f ? fx0 : fx1, xb = A1 >= 0.f ? fx1 : fx0;     // x minimising / maximising A1*x
+    const float ya = B >= 0.f ? fy0 : fy1, yb = B >= 0.f ? fy1 : fy0;       // y minimising / maximising B*y
+    const float mnx = A1 * xa - B * yb + TX, mxx = A1 * xb - B * ya + TX;
+    const float xc = B >= 0.f ? fx0 : fx1, xd = B >= 0.f ? fx1 : fx0;       // x minimising / maximising B*x
+    const float yc = A1 >= 0.f ? fy0 : fy1, yd = A1 >= 0.f ? fy1 : fy0;
+    const float mny = B * xc + A1 * yc + TY, mxy = B * xd + A1 * yd + TY;
     bool fits = fabsf(mnx) < 1.0e6f && fabsf(mxx) < 1.0e6f && fabsf(mny) < 1.0e6f && fabsf(mxy) < 1.0e6f;
-    int sx_lo = 0, sy_lo = 0, bx0 = 0;
+    int sx_lo = 0, sy_lo = 0;
     if (fits) {
-        sx_lo = (int)floorf(mnx) - 1;
+        sx_lo = ((int)floorf(mnx) - 1) & ~3;               // first staged column: a multiple of 4 pixels (12 bytes)
         const int sx_hi = (int)floorf(mxx) + 2;
         sy_lo = (int)floorf(mny) - 1;
         const int sy_hi = (int)floorf(mxy) + 2;
-        bx0 = (sx_lo * 3) & ~3;                                   // first staged byte of every row (dword aligned)
-        fits = (sx_hi * 3 + 2 - bx0 + 1) <= WS_BYTES && (sy_hi - sy_lo + 1) <= WS_H;
+        fits = (sx_hi - sx_lo + 1) <= WS_W && (sy_hi - sy_lo + 1) <= WS_H;
         if (fits) {
+            // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4
             const int rows = sy_hi - sy_lo + 1;
-            const int row_bytes = w * 3;
-            for (int i = threadIdx.x; i < rows * (WS_BYTES / 4); i += 256) {
-                const int r = i / (WS_BYTES / 4), c = i - r * (WS_BYTES / 4);
-                const int sy = sy_lo + r, gb = bx0 + 4 * c;
-                uint32_t v = 0;
+            const int groups = (sx_hi - sx_lo + 4) >> 2;
+            for (int i = threadIdx.x; i < rows * groups; i += 256) {
+                const int r = i / groups, g = i - r * groups;
+                const int sy = sy_lo + r, sx = sx_lo + 4 * g;
+                f4* t = tile + r * WS_W + 4 * g;
                 const bool row_in = sy >= 0 && sy < h;
-                if (BORDER == 0 || row_in) {
-                    const uint8_t* row = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
-                    if (gb >= 0 && gb + 3 < row_bytes && ((((uintptr_t)(row + gb)) & 3) == 0)) {
-                        v = *(const uint32_t*)(row + gb);
-                    } else {
+                if (BORDER == 1 && !row_in) {
+                    const f4 z = {0.f, 0.f, 0.f, 1.f};
+                    t[0] = z; t[1] = z; t[2] = z; t[3] = z;
+                    continue;
+                }
+                const uint8_t* row = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
+                if (sx >= 0 && sx + 3 < w && ((((uintptr_t)(row + sx * 3)) & 3) == 0)) {
+                    const u32x3 q = *(const u32x3*)(row + sx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                    t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
+                    t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
+                    t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
+                    t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
+                } else {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int px = floor_div3(gb + k), ch = gb + k - 3 * px;
-                            uint32_t b;
-                            if (BORDER == 1) b = (px < 0 || px >= w) ? 0u : row[px * 3 + ch];
-                            else b = row[clampi(px, 0, w - 1) * 3 + ch];
-                            v |= b << (8 * k);
+                    for (int k = 0; k < 4; k++) {
+                        const int px = sx + k;
+                        if (BORDER == 1 && (px < 0 || px >= w)) {
+                            t[k] = f4{0.f, 0.f, 0.f, 1.f};
+                        } else {
+                            const uint8_t* q = row + clampi(px, 0, w - 1) * 3;
+                            t[k] = f4{(float)q[0], (float)q[1], (float)q[2], 1.f};
                         }
                     }
                 }
-                tile[r * WS_PITCH_DW + c] = v;
             }
         }
     }
     __syncthreads();
 
-    const int row = threadIdx.x >> 4, xq = threadIdx.x & 15;
-    const int y = y0 + row;
-    if (y >= h) return;
-    const int xb = x0 + 4 * xq;
-    if (xb >= w) return;
-    const float fy = (float)y;
-    const float By = B * fy, A1y = A1 * fy;
-    uint32_t o[12];
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = x0 + lx;
+    const float fx = (float)x;
+    const float A1x = A1 * fx, Bx = B * fx;
+    // a quad of lanes owns 4 pixels = 12 output bytes; it stores them as 3 aligned dwords when the whole
+    // quad is inside the row and the row is dword aligned, else byte by byte
+    const int m = lx & 3;
+    const bool quad_in = (x | 3) < w;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float fx = (float)(xb + k);
-        const float Wx = A1 * fx - By + TX;          // generators.cpp:141
-        const float Wy = B * fx + A1y + TY;          // generators.cpp:142
-        if (!fits) {
-            warp_pixel_global<MODE, BORDER>(src, w, h, src_stride, Wx, Wy, &o[3 * k]);
-            continue;
-        }
-        const float flx = floorf(Wx), fly = floorf(Wy);
-        const int ix = (int)flx, iy = (int)fly;
-        const float frx = Wx - flx, fry = Wy - fly;
-        if (MODE == 0) {
-            float wx[4], wy[4];
-            lanczos_weights4(frx, wx);
-            lanczos_weights4(fry, wy);
-            const int lb = (ix - 1) * 3 - bx0;                    // byte offset of tap (rx=0) in the staged row
-            const uint32_t* t = tile + (iy - 1 - sy_lo) * WS_PITCH_DW + (lb >> 2);
-            const uint32_t sh = (uint32_t)(lb & 3);
-            float nb = 0.f, ng = 0.f, nr = 0.f, den = 0.f;
+        const int y = y0 + wv * 4 + k;
+        if (y >= h) break;                               // wave-uniform
+        uint32_t o[3] = {0, 0, 0};
+        if (x < w) {
+            const float fy = (float)y;
+            const float Wx = A1x - B * fy + TX;          // generators.cpp:141
+            const float Wy = Bx + A1 * fy + TY;          // generators.cpp:142
+            if (!fits) {
+                warp_pixel_global<MODE, BORDER>(src, w, h, src_stride, Wx, Wy, o);
+            } else {
+                const float flx = floorf(Wx), fly = floorf(Wy);
+                const int ix = (int)flx, iy = (int)fly;
+                const f2 fr = {Wx - flx, Wy - fly};
+                if (MODE == 0) {
+                    // the four live taps of the 5-tap window (tap 0 has weight exactly 0), x and y together
+                    const f2 w0 = lanczos2_pk<true>(f2{-1.0f, -1.0f} - fr), w1 = lanczos2_pk<false>(f2{0.0f, 0.0f} - fr),
+                             w2 = lanczos2_pk<false>(f2{1.0f, 1.0f} - fr), w3 = lanczos2_pk<true>(f2{2.0f, 2.0f} - fr);
+                    const float wx[4] = {w0.x, w1.x, w2.x, w3.x}, wy[4] = {w0.y, w1.y, w2.y, w3.y};
+                    const f4* t = tile + (iy - 1 - sy_lo) * WS_W + (ix - 1 - sx_lo);
+                    f2 nbg = {0.f, 0.f}, nrd = {0.f, 0.f};
 #pragma unroll
-            for (int ry = 0; ry < 4; ry++) {
-                const uint32_t d0 = t[ry * WS_PITCH_DW], d1 = t[ry * WS_PITCH_DW + 1], d2 = t[ry * WS_PITCH_DW + 2],
-                               d3 = t[ry * WS_PITCH_DW + 3];
-                const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, sh), q1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                               q2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-                // q0 q1 q2 = B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                const float vb[4] = {ub(q0, 0), ub(q0, 3), ub(q1, 2), ub(q2, 1)};
-                const float vg[4] = {ub(q0, 1), ub(q1, 0), ub(q1, 3), ub(q2, 2)};
-                const float vr[4] = {ub(q0, 2), ub(q1, 1), ub(q2, 0), ub(q2, 3)};
+                    for (int ry = 0; ry < 4; ry++)
 #pragma unroll
-                for (int rx = 0; rx < 4; rx++) {
-                    const float w2d = wx[rx] * wy[ry];
-                    nb = nb + w2d * vb[rx];
-                    ng = ng + w2d * vg[rx];
-                    nr = nr + w2d * vr[rx];
-                    den = den + w2d;
+                        for (int rx = 0; rx < 4; rx++) {
+                            const f4 v = t[ry * WS_W + rx];
+                            const float w2d = wx[rx] * wy[ry];
+                            const f2 ww = {w2d, w2d};
+                            nbg = nbg + ww * f2{v.x, v.y};       // num_B, num_G
+                            nrd = nrd + ww * f2{v.z, v.w};       // num_R, den (v.w == 1: den + w2d*1 == den + w2d)
+                        }
+                    o[0] = store_u8(nbg.x / nrd.y);
+                    o[1] = store_u8(nbg.y / nrd.y);
+                    o[2] = store_u8(nrd.x / nrd.y);
+                } else {
+                    const f4* t = tile + (iy - sy_lo) * WS_W + (ix - sx_lo);
+                    const f4 a0 = t[0], a1 = t[1], b0 = t[WS_W], b1 = t[WS_W + 1];
+                    const f2 tx = {fr.x, fr.x}, ty = {fr.y, fr.y};
+                    const f2 otx = 1.0f - tx, oty = 1.0f - ty;
+                    // lerp(a,b,t) = a*(1-t) + b*t (generators.cpp:161-163), {B,G} and {R,-} pairs
+                    const f2 top_bg = f2{a0.x, a0.y} * otx + f2{a1.x, a1.y} * tx;
+                    const f2 bot_bg = f2{b0.x, b0.y} * otx + f2{b1.x, b1.y} * tx;
+                    const f2 top_r = f2{a0.z, a0.z} * otx + f2{a1.z, a1.z} * tx;
+                    const f2 bot_r = f2{b0.z, b0.z} * otx + f2{b1.z, b1.z} * tx;
+                    const f2 bg = top_bg * oty + bot_bg * ty;
+                    const f2 rr = top_r * oty + bot_r * ty;
+                    o[0] = store_u8(bg.x);
+                    o[1] = store_u8(bg.y);
+                    o[2] = store_u8(rr.x);
                 }
             }
-            o[3 * k] = store_u8(nb / den);
-            o[3 * k + 1] = store_u8(ng / den);
-            o[3 * k + 2] = store_u8(nr / den);
-        } else {
-            const int lb = ix * 3 - bx0;
-            const uint32_t* t = tile + (iy - sy_lo) * WS_PITCH_DW + (lb >> 2);
-            const uint32_t sh = (uint32_t)(lb & 3);
-            uint32_t q[2][2];
-#pragma unroll
-            for (int ry = 0; ry < 2; ry++) {
-                const uint32_t d0 = t[ry * WS_PITCH_DW], d1 = t[ry * WS_PITCH_DW + 1], d2 = t[ry * WS_PITCH_DW + 2];
-                q[ry][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);   // B0 G0 R0 B1
-                q[ry][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);   // G1 R1 .. ..
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float a0 = ub(q[0][0], c), a1 = c == 0 ? ub(q[0][0], 3) : ub(q[0][1], c - 1);
-                const float b0 = ub(q[1][0], c), b1 = c == 0 ? ub(q[1][0], 3) : ub(q[1][1], c - 1);
-                o[3 * k + c] = store_u8(lerpf(lerpf(a0, a1, frx), lerpf(b0, b1, frx), fry));
-            }
         }
-    }
-    uint8_t* op = dst + (size_t)y * dst_stride + (size_t)xb * 3;
-    if (xb + 3 < w && ((((uintptr_t)op) & 3) == 0)) {
-        uint32_t p0 = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-        uint32_t p1 = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
-        uint32_t p2 = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        u32x3 pk = {p0, p1, p2};
-        *(u32x3*)op = pk;
-    } else {
-        const int n = min(4, w - xb);
-        for (int k = 0; k < 3 * n; k++) op[k] = (uint8_t)o[k];
+        uint8_t* orow = dst + (size_t)y * dst_stride;
+        const uint32_t p = o[0] | (o[1] << 8) | (o[2] << 16);
+        const uint32_t d = quad_pack_bgr(p, m);          // every lane of the wave takes part in the shuffle
+        if (quad_in && ((((uintptr_t)orow) & 3) == 0)) {
+            if (m < 3) *(uint32_t*)(orow + (size_t)(x & ~3) * 3 + 4 * m) = d;
+        } else if (x < w) {
+            orow[(size_t)x * 3] = (uint8_t)o[0];
+            orow[(size_t)x * 3 + 1] = (uint8_t)o[1];
+            orow[(size_t)x * 3 + 2] = (uint8_t)o[2];
+        }
     }
 }
 
