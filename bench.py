@@ -166,9 +166,22 @@ def main():
             ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per step, n frames per launch
             bytes_per_launch = W * H * 3 * 2 * n                          # W*H*3*(in+out) per frame
             achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "bgr_image_warp (lanczos2, u8 BGR)", "bound": "hbm", "achieved": round(achieved, 1),
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                               "traffic": None, "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch}
+            # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), scaled to
+            # this launch's frame count; null when the profile for this frame size is not there
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                key = {"c2": "c2_1080p_240_frames", "c3": "c3_4k_32_frames"}[args.workload]
+                per_frame = tj[key]["traffic_bytes"] / {"c2": 240, "c3": 32}[args.workload]
+                traffic = int(per_frame * n)
+            except Exception:
+                pass
+            out["roofline"] = {"kernel": "vs_k_bgr_warp_u8c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm",
+                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                               "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
+                               "note": "VALU-issue-bound, not HBM-bound: ~270 VALU instructions per output pixel in the "
+                                       "reference's exact fp32 order (DESIGN.md, profiles/r01_bgr_image_warp_pmc.md)"}
         if not args.no_cpu_baseline and world == 1:
             fh = frames[: min(n, 64)].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(fh, params_kw)

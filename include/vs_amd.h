@@ -170,6 +170,11 @@ int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int cha
 int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8,
                    uint8_t* dst, int dst_stride, int mem, void* stream);
 
+/* Profiling aid, not part of the reference's surface: device-to-device copy of floor(bytes/12)*12 bytes
+ * with 12-byte accesses per lane, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for the warp
+ * kernel's access width (tools/calibrate_counters.py). */
+int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Engine level: VideoAligner (alignment.hpp:51-99) and VideoStabilizer (stabilizer.hpp:32-56)
  * ------------------------------------------------------------------------------------------ */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vs_smoother_destroy": (None, [_vp]),
     "vs_smoother_update": (_i32, [_vp, _TP, _TP]),
     "vs_tvl1_smooth": (None, [_vp, _i32, _f64, _i32, _vp]),
+    "vs_calib_copy12": (_i32, [_vp, _vp, _sz, _vp]),
     "vs_pyr_down": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vs_grad_xy": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "vs_grad_argmax": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),

@@ -131,6 +131,13 @@ int vs_device_count(void) {
     return n;
 }
 
+int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stream) {
+    VS_ARG(src_dev && dst_dev && bytes >= 12);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    VS_HIP(vsk::calib_copy12(src_dev, dst_dev, bytes, (hipStream_t)stream));
+    return VS_OK;
+}
+
 int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride, int mem,
                 void* stream) {
     VS_ARG(in && out && w > 0 && h > 0 && ow > 0 && oh > 0 && in_stride >= w && out_stride >= ow);

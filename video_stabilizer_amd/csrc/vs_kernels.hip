@@ -394,12 +394,29 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Counter calibration: a plain copy with the warp kernel's access width (12 bytes per lane,
+// global_load/store_dwordx3).  MI355X_MICROARCH.md says FETCH_SIZE is only calibrated for 16-byte
+// streams on gfx950 and asks for a known-byte-count run in the kernel's own access pattern.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vs_k_calib_copy12(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                         size_t n_groups) {
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_groups; i += (size_t)gridDim.x * 256)
+        *(u32x3*)(dst + 3 * i) = *(const u32x3*)(src + 3 * i);
+}
+
 // ================================================================================================
 // launchers
 // ================================================================================================
 namespace vsk {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+hipError_t calib_copy12(const void* src, void* dst, size_t bytes, hipStream_t s) {
+    hipLaunchKernelGGL(vs_k_calib_copy12, dim3(4096), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)dst, bytes / 12);
+    return hipGetLastError();
+}
 
 hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride,
                     int n_frames, size_t in_fs, size_t out_fs, hipStream_t s) {

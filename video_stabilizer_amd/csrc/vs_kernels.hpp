@@ -8,6 +8,8 @@
 
 namespace vsk {
 
+hipError_t calib_copy12(const void* src, void* dst, size_t bytes, hipStream_t s);
+
 hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride,
                     int n_frames, size_t in_frame_stride, size_t out_frame_stride, hipStream_t s);
 hipError_t bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,

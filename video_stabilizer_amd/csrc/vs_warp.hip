@@ -121,13 +121,21 @@ __device__ __forceinline__ void warp_pixel_global(const uint8_t* __restrict__ sr
 template <int MODE, int BORDER>
 __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
                                                           const float4* __restrict__ params, uint8_t* __restrict__ dst,
-                                                          int dst_stride, size_t src_fs, size_t dst_fs) {
+                                                          int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x,
+                                                          int tiles_per_frame, int total_tiles, int chunk) {
     __shared__ f4 tile[WS_H * WS_W];                       // {B,G,R,1} per staged source pixel
-    const float4 P = params[blockIdx.z];
-    src += blockIdx.z * src_fs;
-    dst += blockIdx.z * dst_fs;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+    // workgroup b works on logical tile (b % 8) * chunk + b / 8: every XCD walks one contiguous run of
+    // tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
+    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (logical >= total_tiles) return;
+    const int frame = logical / tiles_per_frame, tl = logical - frame * tiles_per_frame;
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    const float4 P = params[frame];
+    src += (size_t)frame * src_fs;
+    dst += (size_t)frame * dst_fs;
     const float A1 = 1.0f + P.x, B = P.y, TX = P.z, TY = P.w;
-    const int x0 = blockIdx.x * WT_W, y0 = blockIdx.y * WT_H;
+    const int x0 = txi * WT_W, y0 = tyi * WT_H;
     const int x1 = min(x0 + WT_W, w) - 1, y1 = min(y0 + WT_H, h) - 1;
 
     // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is
@@ -265,10 +273,14 @@ namespace vsk {
 
 hipError_t bgr_warp_u8c3(const uint8_t* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border,
                          uint8_t* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
-    if (n_frames > 65535 || (h + WT_H - 1) / WT_H > 65535) return hipErrorNotSupported;
-    dim3 grid((w + WT_W - 1) / WT_W, (h + WT_H - 1) / WT_H, n_frames), block(256);
+    const int tiles_x = (w + WT_W - 1) / WT_W, tiles_y = (h + WT_H - 1) / WT_H;
+    const long long total = (long long)tiles_x * tiles_y * n_frames;
+    if (total > 0x3fffffffLL) return hipErrorNotSupported;
+    const int chunk = (int)((total + 7) / 8);
+    dim3 grid((unsigned)(chunk * 8)), block(256);
 #define VS_LAUNCH(M, Bd) \
-    hipLaunchKernelGGL((vs_k_bgr_warp_u8c3<M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs)
+    hipLaunchKernelGGL((vs_k_bgr_warp_u8c3<M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs, \
+                       tiles_x, tiles_x * tiles_y, (int)total, chunk)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
