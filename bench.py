@@ -87,17 +87,16 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
     from video_stabilizer_amd import capi, synth
+    from video_stabilizer_amd import dist as vsdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    world, rank, local_rank = vsdist.env_world()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
+        dist = vsdist.init("nccl", rank, world, device_id=dev)
 
     wl = WORKLOADS[args.workload]
     W, H = wl["w"], wl["h"]
@@ -140,13 +139,10 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # whole-job numbers: max seconds over ranks, frames summed over ranks (the only collectives of the run)
+    dt, total_frames, total_aligned = vsdist.aggregate(dt, n * args.steps, int(sum(status)) * args.steps, device=dev)
 
     if rank == 0:
-        total_frames = n * args.steps * world
         tm = aligner.timings()
         stages = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // max(1, args.steps)}
                   for k, v in tm.items() if isinstance(v, dict)}
@@ -155,10 +151,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": wl["name"], "frames_per_clip": n, "clips_per_gpu": 1, "width": W, "height": H,
+            "config": {"workload": wl["name"], "frames_per_clip": n, "clips_per_gpu": 1, "clip_seeds": "rank r gets seed %d + 1000 r" % wl["seed"], "width": W, "height": H,
                        "selection": "std::nth_element on the host" if args.select == "host" else "on-device replica of libstdc++ nth_element (same survivors, same order)",
                        "warp": None if args.no_warp else "bgr_image_warp lanczos2 u8 clamp", "resident": "HBM"},
-            "aligned_per_step": int(sum(status)),
+            "aligned_per_step": total_aligned // args.steps,
             "stages": stages,
             "gn_iterations_per_frame": round(tm["gn_iterations"] / max(1, tm["frames"]), 2),
         }

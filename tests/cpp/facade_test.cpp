@@ -1,0 +1,111 @@
+// facade_test.cpp -- the reference's align_test.cpp (TestSimilarityTransformsAll + a synthetic AlignImagePair /
+// TestImageWarpCorrectness) rewritten with assertions against the drop-in facade headers.
+//   usage: facade_test cpu   -> transform algebra only (no device)
+//          facade_test gpu   -> + ImageWarp known answer, + align a synthetic pair, + stabilizer lag
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../video_stabilizer_amd/facade/stabilizer.hpp"
+
+static int fails = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("[FAIL] %s:%d %s\n", __FILE__, __LINE__, #cond); fails++; } } while (0)
+static const float EPSILON = 1e-5f;                                    // align_test.cpp:249
+static bool nearlyEqual(float a, float b) { return std::fabs(a - b) < EPSILON; }
+
+static void TestSimilarityTransformInverse() {                         // align_test.cpp:261-303
+    std::vector<SimilarityTransform> ts(4);
+    ts[1].A = 0.1f; ts[1].TX = 10.f; ts[1].TY = 20.f;
+    ts[2].B = 0.1f; ts[2].TX = 5.f; ts[2].TY = -5.f;
+    ts[3].A = 0.05f; ts[3].B = 0.05f; ts[3].TX = 100.f; ts[3].TY = 50.f;
+    std::vector<Point> pts = {{0.f, 0.f}, {100.f, 100.f}, {50.f, 200.f}, {-10.f, 30.f}, {1.3f, -2.7f}};
+    for (auto& T : ts) {
+        SimilarityTransform Tinv = T.inverse();
+        for (auto& p : pts) {
+            Point u = Tinv.warp(T.warp(p));
+            CHECK(nearlyEqual((float)p.x, (float)u.x) && nearlyEqual((float)p.y, (float)u.y));
+        }
+    }
+}
+static void TestSimilarityTransformCompose() {                         // align_test.cpp:311-346
+    SimilarityTransform T1, T2;
+    T1.A = 0.1f; T1.TX = 10.f; T1.TY = 20.f;
+    T2.B = 0.1f; T2.TX = 5.f; T2.TY = 5.f;
+    SimilarityTransform T3 = T1.compose(T2);
+    for (Point p : std::vector<Point>{{0.f, 0.f}, {10.f, 20.f}, {50.f, 50.f}, {-10.f, 30.f}}) {
+        Point a = T3.warp(p), b = T2.warp(T1.warp(p));
+        CHECK(nearlyEqual((float)a.x, (float)b.x) && nearlyEqual((float)a.y, (float)b.y));
+    }
+}
+static void TestRandomized() {                                         // align_test.cpp:444-601
+    std::mt19937 rng(12345);
+    std::uniform_real_distribution<double> dA(-0.3, 0.3), dB(-0.2, 0.2), dT(-50, 50), dP(-100, 100);
+    for (int i = 0; i < 50; i++) {
+        SimilarityTransform T, U;
+        T.A = dA(rng); T.B = dB(rng); T.TX = dT(rng); T.TY = dT(rng);
+        U.A = dA(rng); U.B = dB(rng); U.TX = dT(rng); U.TY = dT(rng);
+        for (int k = 0; k < 10; k++) {
+            Point p{dP(rng), dP(rng)};
+            Point u = T.inverse().warp(T.warp(p));
+            CHECK(std::fabs(u.x - p.x) < EPSILON && std::fabs(u.y - p.y) < EPSILON);
+            Point a = T.compose(U).warp(p), b = U.warp(T.warp(p));
+            CHECK(std::fabs(a.x - b.x) < EPSILON && std::fabs(a.y - b.y) < EPSILON);
+        }
+        SimilarityTransform I = T.compose(T.inverse());
+        CHECK(std::fabs(I.A) < EPSILON && std::fabs(I.B) < EPSILON && std::fabs(I.TX) < EPSILON && std::fabs(I.TY) < EPSILON);
+    }
+}
+static void TestImageWarpCorrectness() {                               // align_test.cpp:358-400, exact instead of +-0.5 px
+    vs::Buffer<uint8_t> in(64, 64);
+    for (int y = 20; y < 30; y++) for (int x = 20; x < 30; x++) in(x, y) = 255;
+    SimilarityTransform T; T.TX = 5; T.TY = 7;
+    vs::Buffer<float> out(64, 64);
+    CHECK(ImageWarp(in, T.inverse(), out));
+    for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++)
+        CHECK(out(x, y) == ((x >= 25 && x < 35 && y >= 27 && y < 37) ? 255.f : 0.f));
+}
+static std::vector<uint8_t> texture(int w, int h, double dx, double dy) {   // smooth synthetic BGR frame, shifted by (dx,dy)
+    std::vector<uint8_t> f((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+        double u = x + dx, v = y + dy;
+        double g = 128 + 50 * std::sin(u * 0.11) * std::cos(v * 0.07) + 40 * std::sin((u + v) * 0.045) + 30 * std::cos(u * 0.031 - v * 0.052);
+        int q = (int)std::floor(g + 0.5); q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        f[((size_t)y * w + x) * 3] = (uint8_t)q; f[((size_t)y * w + x) * 3 + 1] = (uint8_t)q; f[((size_t)y * w + x) * 3 + 2] = (uint8_t)q;
+    }
+    return f;
+}
+static void AlignImagePair() {                                         // align_test.cpp:625-691 on synthetic frames
+    const int w = 640, h = 480;
+    auto a = texture(w, h, 0, 0), b = texture(w, h, 2.5, -1.75);
+    VideoAligner aligner;
+    SimilarityTransform t1, t2;
+    CHECK(!aligner.AlignNextFrame(a.data(), w, h, t1));                // first call: false
+    CHECK(aligner.AlignNextFrame(b.data(), w, h, t2));
+    std::printf("Alignment successful. Transform = %s\n", t2.toString().c_str());
+    CHECK(std::fabs(std::fabs(t2.TX) - 2.5) < 0.3 && std::fabs(std::fabs(t2.TY) - 1.75) < 0.3);
+    VideoStabilizerParams sp; sp.lag = 3; sp.smoother_memory = 1; sp.crop_pixels = 8;
+    VideoStabilizer st(sp);
+    int ow = 0, oh = 0, produced = 0;
+    for (int i = 0; i < 6; i++) {
+        auto f = texture(w, h, 0.4 * i, -0.3 * i);
+        auto out = st.processFrame(f.data(), w, h, ow, oh);
+        if (i < 3) CHECK(out.empty()); else { CHECK(!out.empty() && ow == w - 16 && oh == h - 16); produced++; }
+    }
+    CHECK(produced == 3);
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    TestSimilarityTransformInverse();
+    TestSimilarityTransformCompose();
+    TestRandomized();
+    if (mode == "gpu") {
+        TestImageWarpCorrectness();
+        AlignImagePair();
+    }
+    std::printf(fails ? "FAILED (%d)\n" : "ALL PASS\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,38 @@
+"""Multi-GPU plumbing: clips are independent units, so ranks share NOTHING on the data path.
+Clip i goes to rank i mod world (static round robin); the only collectives are the barrier that brackets the
+timed region and one tiny all-reduce (max of seconds, sums of frame counters) for the whole-job report --
+RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests."""
+import os
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_clips(n_clips, rank, world):
+    """clip indices owned by `rank`: i mod world == rank"""
+    return list(range(rank, n_clips, world))
+
+
+def init(backend, rank, world, device_id=None):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    kw = {}
+    if device_id is not None:
+        kw["device_id"] = device_id
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def aggregate(seconds, frames, aligned, device=None):
+    """whole-job numbers: (max seconds over ranks, total frames, total aligned).  Works on any backend."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds), int(frames), int(aligned)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    c = torch.tensor([int(frames), int(aligned)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(c[0].item()), int(c[1].item())

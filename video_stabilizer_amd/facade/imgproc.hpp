@@ -1,0 +1,144 @@
+// imgproc.hpp -- source-level drop-in for the reference's imgproc.hpp (imgproc.hpp:8-95), implemented purely
+// on the C ABI of libvs_amd.so (include/vs_amd.h).  Same function names, argument order and `bool` protocol
+// (true iff the underlying call succeeded; outputs passed by non-const reference and (re)allocated by the
+// callee when their shape does not match -- imgproc.cpp:34-40,56-60,87-92,166-172).
+//
+// The reference's Halide::Runtime::Buffer<T> / cv::Mat are replaced by the small owning vs::Buffer<T> below
+// (dense, dim0 stride 1, "planar" like Halide: element (x,y,c) at c*w*h + y*w + x).  With OpenCV present a
+// caller wraps cv::Mat data with vs::Buffer<T>::view().
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vs_amd.h"
+
+namespace vs {
+
+template <typename T>
+class Buffer {
+public:
+    Buffer() = default;
+    Buffer(int w, int h = 1, int c = 1) : w_(w), h_(h), c_(c), own_((size_t)w * h * c), p_(own_.data()), dims_(c > 1 ? 3 : (h > 1 ? 2 : 1)) {}
+    static Buffer view(T* data, int w, int h, int c = 1) { Buffer b; b.w_ = w; b.h_ = h; b.c_ = c; b.p_ = data; b.dims_ = c > 1 ? 3 : 2; return b; }
+    int dimensions() const { return dims_; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+    int channels() const { return c_; }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    T& operator()(int x, int y = 0, int c = 0) { return p_[((size_t)c * h_ + y) * w_ + x]; }
+    const T& operator()(int x, int y = 0, int c = 0) const { return p_[((size_t)c * h_ + y) * w_ + x]; }
+    size_t size() const { return (size_t)w_ * h_ * c_; }
+private:
+    int w_ = 0, h_ = 0, c_ = 1;
+    std::vector<T> own_;
+    T* p_ = nullptr;
+    int dims_ = 0;
+};
+
+}  // namespace vs
+
+// imgproc.hpp:34-38
+struct Point {
+    double x = 0.0, y = 0.0;
+    double distance(const Point& p) const { double dx = x - p.x, dy = y - p.y; return std::sqrt(dx * dx + dy * dy); }
+};
+
+// imgproc.hpp:40-65
+struct SimilarityTransform {
+    double A = 0.0, B = 0.0, TX = 0.0, TY = 0.0;
+
+    std::string toString() const {   // imgproc.cpp:327-331
+        std::stringstream ss;
+        ss << "A=" << A << ", B=" << B << ", TX=" << TX << ", TY=" << TY;
+        return ss.str();
+    }
+    SimilarityTransform inverse() const { return from(vs_transform_inverse(&c())); }
+    Point warp(Point p) const { vs_point q = vs_transform_warp(&c(), vs_point{p.x, p.y}); return Point{q.x, q.y}; }
+    Point warp(Point p, double cx, double cy) const { vs_point q = vs_transform_warp_center(&c(), vs_point{p.x, p.y}, cx, cy); return Point{q.x, q.y}; }
+    double maxCornerDisplacement(double width, double height) const { return vs_transform_max_corner_displacement(&c(), width, height); }
+    // "this" = T1, param = T2: T3 = T2(T1(p))
+    SimilarityTransform compose(const SimilarityTransform& w2) const { return from(vs_transform_compose(&c(), &w2.c())); }
+
+    const vs_transform& c() const { return *reinterpret_cast<const vs_transform*>(this); }
+    static SimilarityTransform from(const vs_transform& t) { SimilarityTransform s; s.A = t.A; s.B = t.B; s.TX = t.TX; s.TY = t.TY; return s; }
+};
+static_assert(sizeof(SimilarityTransform) == sizeof(vs_transform), "layout must match vs_transform");
+
+// imgproc.cpp:108-114
+inline bool PyrDown(vs::Buffer<uint8_t>& input, vs::Buffer<uint8_t>& output) {
+    return vs_pyr_down(input.data(), input.width(), input.height(), input.width(), output.data(), output.width(), output.height(),
+                       output.width(), VS_MEM_HOST, nullptr) == 0;
+}
+// imgproc.cpp:135-142
+inline bool GradXY(vs::Buffer<uint8_t>& input, vs::Buffer<float>& output_x, vs::Buffer<float>& output_y) {
+    return vs_grad_xy(input.data(), input.width(), input.height(), input.width(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
+}
+// imgproc.cpp:144-202 (tile-size rule + (re)allocation + dispatch)
+inline bool GradArgMax(vs::Buffer<float>& grad_x, vs::Buffer<float>& grad_y, int& tile_size, vs::Buffer<uint16_t>& local_max_x,
+                       vs::Buffer<uint16_t>& local_max_y) {
+    tile_size = vs_tile_size(grad_x.width(), grad_y.height());
+    const int wt = grad_x.width() / tile_size, ht = grad_y.height() / tile_size;
+    if (local_max_x.dimensions() != 3 || local_max_x.width() != wt || local_max_x.height() != ht) {
+        local_max_x = vs::Buffer<uint16_t>(wt, ht, 2);
+        local_max_y = vs::Buffer<uint16_t>(wt, ht, 2);
+    }
+    return vs_grad_argmax(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), tile_size, local_max_x.data(), local_max_y.data(),
+                          VS_MEM_HOST, nullptr) == 0;
+}
+// imgproc.cpp:26-44
+inline bool SparseJacobian(vs::Buffer<float>& grad_x, vs::Buffer<float>& grad_y, vs::Buffer<uint16_t>& local_max_x,
+                           vs::Buffer<uint16_t>& local_max_y, vs::Buffer<float>& output_x, vs::Buffer<float>& output_y) {
+    if (output_x.dimensions() != 3 || output_x.width() != local_max_x.width() || output_x.height() != local_max_x.height()) {
+        output_x = vs::Buffer<float>(local_max_x.width(), local_max_x.height(), 4);
+        output_y = vs::Buffer<float>(local_max_x.width(), local_max_x.height(), 4);
+    }
+    return vs_sparse_jac(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), local_max_x.data(), local_max_y.data(),
+                         local_max_x.width(), local_max_x.height(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
+}
+// imgproc.cpp:46-78: selected_pixels (n,2) u16, selected_jacobians (n,4) f32
+inline bool SparseICA(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8_t>& input_keyframe, vs::Buffer<uint16_t>& selected_pixels_x,
+                      vs::Buffer<uint16_t>& selected_pixels_y, vs::Buffer<float>& selected_jacobians_x,
+                      vs::Buffer<float>& selected_jacobians_y, const SimilarityTransform& transform, vs::Buffer<double>& output) {
+    if (output.dimensions() != 1 || output.width() != 4) output = vs::Buffer<double>(4);
+    float p[4];
+    vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
+    return vs_sparse_ica(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(), input_keyframe.width(),
+                         selected_pixels_x.data(), selected_pixels_x.width(), selected_pixels_y.data(), selected_pixels_y.width(),
+                         selected_jacobians_x.data(), selected_jacobians_y.data(), p[0], p[1], p[2], p[3], output.data(), VS_MEM_HOST,
+                         nullptr) == 0;
+}
+// imgproc.cpp:80-106
+inline bool SparseWarpDiff(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8_t>& input_keyframe, vs::Buffer<uint16_t>& local_max,
+                           const SimilarityTransform& transform, vs::Buffer<uint16_t>& output) {
+    if (output.dimensions() != 2 || output.width() != local_max.width() || output.height() != local_max.height())
+        output = vs::Buffer<uint16_t>(local_max.width(), local_max.height());
+    float p[4];
+    vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
+    return vs_sparse_warpdiff(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(),
+                              input_keyframe.width(), local_max.data(), local_max.width(), local_max.height(), p[0], p[1], p[2], p[3],
+                              output.data(), VS_MEM_HOST, nullptr) == 0;
+}
+// imgproc.cpp:116-133
+inline bool ImageWarp(vs::Buffer<uint8_t>& input, const SimilarityTransform& transform, vs::Buffer<float>& output) {
+    float p[4];
+    vs_ul_params_warp(&transform.c(), input.width(), input.height(), p);
+    return vs_image_warp(input.data(), input.width(), input.height(), input.width(), p[0], p[1], p[2], p[3], output.data(), output.width(),
+                         output.height(), VS_MEM_HOST, nullptr) == 0;
+}
+
+// imgproc.cpp:446-484 warpBySimilarityTransform on an interleaved BGR image (h x w x 3, u8).  OpenCV's warpAffine
+// without WARP_INVERSE_MAP inverts the matrix it is given (imgproc.cpp:472), i.e. it samples the source at
+// transform^-1; bgr_image_warp takes the sampling map, so it receives transform.inverse().  The reference's
+// interpolation is OpenCV's fixed-point bilinear with a black border; `mode` picks this build's sampler.
+inline bool warpBySimilarityTransform(const uint8_t* src_bgr, int w, int h, const SimilarityTransform& transform, uint8_t* dst_bgr,
+                                      int mode = VS_WARP_BILINEAR, int border = VS_BORDER_CONSTANT) {
+    const SimilarityTransform sampling = transform.inverse();
+    return vs_bgr_image_warp(src_bgr, w, h, w * 3, 3, 8, &sampling.c(), mode, border, 255, dst_bgr, w * 3, VS_MEM_HOST, nullptr) == 0;
+}
