@@ -68,6 +68,73 @@ __device__ __forceinline__ float lanczos_sample_u8(const uint8_t* __restrict__ i
     return num / den;
 }
 
+// ---- the same sampler, arranged for the Gauss-Newton loop -------------------------------------
+// Identical fp32 operations per value (so identical results), but: the eight weights run as four
+// packed {x,y} Horner chains, and the 4x4 window is fetched as four unaligned dword loads (the
+// hardware handles unaligned global loads) from a window origin clamped into the image.  Lanes
+// whose window touches the border re-select bytes with v_perm_b32 so that they see exactly the
+// clamp-to-edge pixels; that fix-up runs only in waves that contain such a lane.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <bool EDGE>
+__device__ __forceinline__ f2v lanczos2_pk(f2v x) {
+    f2v x2 = x * x;
+    f2v v = 0.000858519f;
+    v = -0.0158853f + v * x2;
+    v = 0.128693f + v * x2;
+    v = -0.583468f + v * x2;
+    v = 1.52229f + v * x2;
+    v = -2.05238f + v * x2;
+    v = 0.999861f + v * x2;
+    if (EDGE) {   // only taps 1 and 4 (-1-frac, 2-frac) can reach |x| >= 2
+        v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
+        v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
+    uint32_t r;
+    __builtin_memcpy(&r, p, 4);
+    return r;
+}
+
+// requires w >= 4
+__device__ __forceinline__ float lanczos_sample_u8_fast(const uint8_t* __restrict__ img, int w, int h, int stride,
+                                                        float Wx, float Wy) {
+    const float flx = floorf(Wx), fly = floorf(Wy);
+    const int ix = (int)flx, iy = (int)fly;
+    const f2v fr = {Wx - flx, Wy - fly};
+    const f2v w0 = lanczos2_pk<true>(f2v{-1.0f, -1.0f} - fr), w1 = lanczos2_pk<false>(f2v{0.0f, 0.0f} - fr),
+              w2 = lanczos2_pk<false>(f2v{1.0f, 1.0f} - fr), w3 = lanczos2_pk<true>(f2v{2.0f, 2.0f} - fr);
+    const float wx[4] = {w0.x, w1.x, w2.x, w3.x}, wy[4] = {w0.y, w1.y, w2.y, w3.y};
+    const int xb = clampi(ix - 1, 0, w - 4);                  // window origin, always inside the row
+    uint32_t r[4];
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++)
+        r[ry] = load_u32_unaligned(img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride + xb);
+    const bool edge = ix < 1 || ix + 2 >= w;
+    if (__any(edge)) {                                        // wave-uniform branch
+        uint32_t sel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel |= (uint32_t)(clampi(ix - 1 + k, 0, w - 1) - xb) << (8 * k);
+#pragma unroll
+        for (int ry = 0; ry < 4; ry++) r[ry] = __builtin_amdgcn_perm(r[ry], r[ry], sel);
+    }
+    float num = 0.0f, den = 0.0f;
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+            const float w2d = wx[rx] * wy[ry];
+            const float val = (float)((r[ry] >> (8 * rx)) & 0xffu);
+            num = num + w2d * val;
+            den = den + w2d;
+        }
+    }
+    return num / den;
+}
+
 // imgproc.cpp:69-75 / 98-103: centre-based double transform -> float kernel arguments.
 // `w*0.5f` is a float in the reference, promoted to double inside the expression.
 __device__ __forceinline__ void ul_params_sparse(const double T[4], int w, int h, float p[4]) {

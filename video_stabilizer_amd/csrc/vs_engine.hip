@@ -98,15 +98,42 @@ __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __re
 }
 
 // ---- gather of the selected keypoints + Jacobians: alignment.cpp:523-546 ------------------------
-// sel layout per pair: selx u16[2*nsel] | sely u16[2*nsel] ; jac layout: jacx f32[4*nsel] | jacy f32[4*nsel]
+// The solver reads one compact record per selected point, built once per level (both sets back to
+// back: x-set at [0,nsel), y-set at [nsel,2*nsel)):
+//   xy  u32    x | y << 16                       (SelectedPixels, alignment.cpp:530-531)
+//   tv  f32    float(template(min(x,w-1), min(y,h-1)))   -- constant over the iterations (generators.cpp:554-556)
+//   j   float4 the four Jacobian components     (SelectedJacobian, alignment.cpp:532-534)
+struct PointRecs {
+    uint32_t* xy;
+    float* tv;
+    float4* j;
+};
+__device__ __forceinline__ PointRecs pair_recs(uint8_t* recs, size_t recs_pair, int p, int nt_cap) {
+    uint8_t* base = recs + (size_t)p * recs_pair;
+    PointRecs r;
+    r.j = (float4*)base;                                      // 2*nt_cap float4
+    r.xy = (uint32_t*)(base + (size_t)2 * nt_cap * 16);       // 2*nt_cap u32
+    r.tv = (float*)(base + (size_t)2 * nt_cap * 20);          // 2*nt_cap f32
+    return r;
+}
+__device__ __forceinline__ void write_rec(const PointRecs& rc, int slot, const uint16_t* __restrict__ lm,
+                                          const float* __restrict__ jac, int nt, int t, const uint8_t* __restrict__ tmpl,
+                                          int w, int h) {
+    const int px = lm[t], py = lm[nt + t];
+    rc.xy[slot] = (uint32_t)px | ((uint32_t)py << 16);
+    rc.tv[slot] = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
+    rc.j[slot] = make_float4(jac[t], jac[(size_t)nt + t], jac[2 * (size_t)nt + t], jac[3 * (size_t)nt + t]);
+}
+
 __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __restrict__ states,
                                                             const PairDesc* __restrict__ descs,
+                                                            const uint8_t* __restrict__ pyr, size_t pyr_frame,
+                                                            size_t img_off, int w, int h,
                                                             const uint16_t* __restrict__ lm_tab, size_t lm_frame,
                                                             size_t lm_off, const float* __restrict__ jac_tab,
                                                             size_t jac_frame, size_t jac_off, int nt, int nsel,
                                                             const int32_t* __restrict__ idx, size_t idx_pair,
-                                                            uint16_t* __restrict__ sel, size_t sel_pair,
-                                                            float* __restrict__ seljac, size_t seljac_pair) {
+                                                            uint8_t* __restrict__ recs, size_t recs_pair, int nt_cap) {
     const int p = blockIdx.y, set = blockIdx.z;
     if (states[p].status != 1) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -114,13 +141,9 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
     const PairDesc d = descs[p];
     const uint16_t* lm = lm_tab + (size_t)d.key_slot * lm_frame + lm_off + (size_t)set * 2 * nt;
     const float* jac = jac_tab + (size_t)d.key_slot * jac_frame + jac_off + (size_t)set * 4 * nt;
+    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
     const int t = idx[(size_t)p * idx_pair + (size_t)set * nt + j];
-    uint16_t* so = sel + (size_t)p * sel_pair + (size_t)set * 2 * nsel;
-    float* jo = seljac + (size_t)p * seljac_pair + (size_t)set * 4 * nsel;
-    so[j] = lm[t];
-    so[nsel + j] = lm[nt + t];
-#pragma unroll
-    for (int k = 0; k < 4; k++) jo[(size_t)k * nsel + j] = jac[(size_t)k * nt + t];
+    write_rec(pair_recs(recs, recs_pair, p, nt_cap), set * nsel + j, lm, jac, nt, t, tmpl, w, h);
 }
 
 // ---- Gauss-Newton level solver: alignment.cpp:548-688 -------------------------------------------
@@ -136,25 +159,23 @@ struct GnShared {
     double c0[8];   // corners at level start (block-uniform; parked here instead of 16 VGPRs)
 };
 
-__device__ __forceinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ tmpl, const uint8_t* __restrict__ key,
-                                        int w, int h, int nsel, const uint16_t* __restrict__ selx,
-                                        const uint16_t* __restrict__ sely, const float* __restrict__ jacx,
-                                        const float* __restrict__ jacy, int level, const GnParams& gp, double T[4],
-                                        int* iters_out, double* cond_out) {
+__device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ key, int w, int h, int nsel,
+                                        const PointRecs& rc, int level, const GnParams& gp, double T[4], int* iters_out,
+                                        double* cond_out) {
+    const uint32_t* __restrict__ rxy = rc.xy;
+    const float* __restrict__ rtv = rc.tv;
+    const float4* __restrict__ rj = rc.j;
     // Hessian (alignment.cpp:278-332): upper triangle of sum j j^T over both sets, in fp64
     {
         double hacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int set = 0; set < 2; set++) {
-            const float* jac = set == 0 ? jacx : jacy;
-            for (int r = threadIdx.x; r < nsel; r += kGnThreads) {
-                double j[4] = {(double)jac[r], (double)jac[nsel + r], (double)jac[2 * (size_t)nsel + r],
-                               (double)jac[3 * (size_t)nsel + r]};
-                int k = 0;
+        for (int r = threadIdx.x; r < 2 * nsel; r += kGnThreads) {
+            const float4 jf = rj[r];
+            const double j[4] = {(double)jf.x, (double)jf.y, (double)jf.z, (double)jf.w};
+            int k = 0;
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+            for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
-            }
+                for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
         }
         block_sum<10>(hacc, sh.red[0]);
         if (threadIdx.x < 64) {   // one wave does the 4x4 eigen work; the others wait at the barrier
@@ -190,19 +211,19 @@ __device__ __forceinline__ int gn_level(GnShared& sh, const uint8_t* __restrict_
         const float A1 = 1.0f + P[0];
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int set = 0; set < 2; set++) {
-            const uint16_t* sl = set == 0 ? selx : sely;
-            const float* jac = set == 0 ? jacx : jacy;
             double* a = acc + 4 * set;
-            for (int r = threadIdx.x; r < nsel; r += kGnThreads) {
-                int px = sl[r], py = sl[nsel + r];
-                float ox = (float)px, oy = (float)py;
-                float Wx = A1 * ox - P[1] * oy + P[2];
-                float Wy = P[1] * ox + A1 * oy + P[3];
-                float warped = lanczos_sample_u8(key, w, h, w, Wx, Wy);
-                float tv = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
-                float residual = tv - warped;
-#pragma unroll
-                for (int c = 0; c < 4; c++) a[c] += (double)(jac[(size_t)c * nsel + r] * residual);
+            for (int r = set * nsel + threadIdx.x; r < (set + 1) * nsel; r += kGnThreads) {
+                const uint32_t xy = rxy[r];
+                const float4 jf = rj[r];
+                const float ox = (float)(xy & 0xffffu), oy = (float)(xy >> 16);
+                const float Wx = A1 * ox - P[1] * oy + P[2];
+                const float Wy = P[1] * ox + A1 * oy + P[3];
+                const float warped = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
+                const float residual = rtv[r] - warped;
+                a[0] += (double)(jf.x * residual);
+                a[1] += (double)(jf.y * residual);
+                a[2] += (double)(jf.z * residual);
+                a[3] += (double)(jf.w * residual);
             }
         }
         block_sum<8>(acc, sh.red[(iter & 1) ^ 1]);
@@ -249,23 +270,19 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
                                                             const PairDesc* __restrict__ descs,
                                                             const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                             size_t img_off, int w, int h, int nsel,
-                                                            const uint16_t* __restrict__ sel, size_t sel_pair,
-                                                            const float* __restrict__ seljac, size_t seljac_pair,
+                                                            uint8_t* __restrict__ recs, size_t recs_pair, int nt_cap,
                                                             int level, GnParams gp) {
     __shared__ GnShared sh;
     const int p = blockIdx.x;
     PairState& st = states[p];
     if (st.status != 1) return;   // uniform for the block
     const PairDesc d = descs[p];
-    const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
     const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
-    const uint16_t* selx = sel + (size_t)p * sel_pair;
-    const float* jacx = seljac + (size_t)p * seljac_pair;
+    const PointRecs rc = pair_recs(recs, recs_pair, p, nt_cap);
     double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
     int iters;
     double cond;
-    const int fail = gn_level(sh, tmpl, key, w, h, nsel, selx, selx + 2 * (size_t)nsel, jacx, jacx + 4 * (size_t)nsel,
-                              level, gp, T, &iters, &cond);
+    const int fail = gn_level(sh, key, w, h, nsel, rc, level, gp, T, &iters, &cond);
     __syncthreads();   // every thread has read st.T before thread 0 rewrites it
     if (threadIdx.x == 0) {
         st.iterations[level] = iters;
@@ -437,8 +454,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
                                                                const uint8_t* __restrict__ pyr, size_t pyr_frame,
                                                                const uint16_t* __restrict__ lm_tab, size_t lm_frame,
                                                                const float* __restrict__ jac_tab, size_t jac_frame,
-                                                               uint16_t* __restrict__ sel, size_t sel_pair,
-                                                               float* __restrict__ seljac, size_t seljac_pair,
+                                                               uint8_t* __restrict__ recs, size_t recs_pair,
                                                                int nt_cap, FusedLevels fl, GnParams gp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
     __shared__ SelShared ss;
@@ -454,8 +470,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
         const int w = fl.w[l], h = fl.h[l], nt = fl.nt[l], nsel = fl.nsel[l];
         const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + fl.img_off[l];
         const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + fl.img_off[l];
-        uint16_t* selx = sel + (size_t)p * sel_pair;
-        float* jacx = seljac + (size_t)p * seljac_pair;
+        const PointRecs rc = pair_recs(recs, recs_pair, p, nt_cap);
         float P[4];
         ul_params_sparse(T, w, h, P);
         const float A1 = 1.0f + P[0];
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
                 float ox = (float)tile_x, oy = (float)tile_y;
                 float Wx = A1 * ox - P[1] * oy + P[2];
                 float Wy = P[1] * ox + A1 * oy + P[3];
-                float v = lanczos_sample_u8(key, w, h, w, Wx, Wy);
+                float v = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
                 float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
                 diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
                 a[i] = ((uint32_t)(uint16_t)diff << 16) | (uint32_t)i;
@@ -476,22 +491,14 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
             __syncthreads();
             if (introselect_block(a, posR, ss, nt, nsel)) { fail = 100; fail_level = l; }
             // gather (alignment.cpp:523-546) in the order nth_element left the survivors
-            uint16_t* so = selx + (size_t)set * 2 * nsel;
-            float* jo = jacx + (size_t)set * 4 * nsel;
-            for (int j = threadIdx.x; j < nsel; j += kGnThreads) {
-                const int t = (int)(a[j] & 0xffffu);
-                so[j] = lm[t];
-                so[nsel + j] = lm[nt + t];
-#pragma unroll
-                for (int k = 0; k < 4; k++) jo[(size_t)k * nsel + j] = jac[(size_t)k * nt + t];
-            }
-            __syncthreads();   // a[] is refilled by the next set; sel/seljac stores are visible block-wide
+            for (int j = threadIdx.x; j < nsel; j += kGnThreads)
+                write_rec(rc, set * nsel + j, lm, jac, nt, (int)(a[j] & 0xffffu), tmpl, w, h);
+            __syncthreads();   // a[] is refilled by the next set; the record stores are visible block-wide
         }
         if (fail) break;
         int iters;
         double cond;
-        const int f = gn_level(sh, tmpl, key, w, h, nsel, selx, selx + 2 * (size_t)nsel, jacx, jacx + 4 * (size_t)nsel, l, gp,
-                               T, &iters, &cond);
+        const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond);
         if (threadIdx.x == 0) { st.iterations[l] = iters; st.condition[l] = cond; }
         if (f) { fail = f; fail_level = l; }
         __syncthreads();
@@ -532,8 +539,7 @@ struct vs_aligner {
     PairDesc* descs = nullptr;
     uint16_t* wd = nullptr;
     int32_t* idx = nullptr;
-    uint16_t* sel = nullptr;
-    float* seljac = nullptr;
+    uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
     void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area
     // pinned host mirrors
     uint16_t* h_wd = nullptr;
@@ -583,12 +589,12 @@ struct vs_aligner {
 };
 
 void vs_aligner::release() {
-    void* d[] = {pyr, lm, jac, states, descs, wd, idx, sel, seljac, stage};
+    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, stage};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hp[] = {h_wd, h_idx, h_states};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; idx = nullptr;
-    sel = nullptr; seljac = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
+    recs = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
     cap = 0;
 }
 
@@ -641,7 +647,7 @@ int vs_aligner::ensure_capacity(int n) {
         VS_HIP(hipStreamSynchronize(stream));
         last_n = 0;   // carry-over now lives in slot 0 of the new slabs
     }
-    void* old[] = {pyr, lm, jac, states, descs, wd, idx, sel, seljac};
+    void* old[] = {pyr, lm, jac, states, descs, wd, idx, recs};
     for (void* p : old) if (p) (void)hipFree(p);
     void* oldh[] = {h_wd, h_idx, h_states};
     for (void* p : oldh) if (p) (void)hipHostFree(p);
@@ -650,8 +656,7 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipMalloc((void**)&descs, sizeof(PairDesc) * newcap));
     VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
-    VS_HIP(hipMalloc((void**)&sel, (size_t)newcap * 4 * nt_max * sizeof(uint16_t)));
-    VS_HIP(hipMalloc((void**)&seljac, (size_t)newcap * 8 * nt_max * sizeof(float)));
+    VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 24));
     VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
     VS_HIP(hipHostMalloc((void**)&h_states, sizeof(PairState) * newcap));
@@ -789,7 +794,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
         VS_HIP(hipStreamSynchronize(s));   // hd goes out of scope; also orders the pinned h_states reuse below
 
-        const size_t wd_pair = (size_t)2 * nt_max, sel_pair = (size_t)4 * nt_max, seljac_pair = (size_t)8 * nt_max;
+        const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 24;
         GnParams gp{p.threshold, p.max_displacement, p.max_iters};
         bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
         if (!use_host) {
@@ -804,7 +809,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipFuncSetAttribute((const void*)vs_k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             t_begin(VS_STAGE_GN);
             hipLaunchKernelGGL(vs_k_align_pairs, dim3(n_pairs), dim3(kGnThreads), dyn, s, states, descs, pyr, pyr_frame, lm,
-                               lm_frame, jac, jac_frame, sel, sel_pair, seljac, seljac_pair, nt_max, fl, gp);
+                               lm_frame, jac, jac_frame, recs, recs_pair, nt_max, fl, gp);
             VS_HIP(hipGetLastError());
             t_end(1);
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -836,14 +841,14 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             if (ld.nsel > 0) {
                 t_begin(VS_STAGE_GATHER);
                 hipLaunchKernelGGL(vs_k_gather_selected, dim3((ld.nsel + 255) / 256, n_pairs, 2), dim3(256), 0, s, states,
-                                   descs, lm, lm_frame, ld.lm_off, jac, jac_frame, ld.jac_off, ld.nt, ld.nsel, idx, wd_pair,
-                                   sel, sel_pair, seljac, seljac_pair);
+                                   descs, pyr, pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, jac, jac_frame,
+                                   ld.jac_off, ld.nt, ld.nsel, idx, wd_pair, recs, recs_pair, nt_max);
                 VS_HIP(hipGetLastError());
                 t_end(1);
             }
             t_begin(VS_STAGE_GN);
             hipLaunchKernelGGL(vs_k_gn_level, dim3(n_pairs), dim3(kGnThreads), 0, s, states, descs, pyr, pyr_frame, ld.img_off,
-                               ld.w, ld.h, ld.nsel, sel, sel_pair, seljac, seljac_pair, l, gp);
+                               ld.w, ld.h, ld.nsel, recs, recs_pair, nt_max, l, gp);
             VS_HIP(hipGetLastError());
             t_end(1);
         }
