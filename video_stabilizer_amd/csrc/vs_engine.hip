@@ -739,12 +739,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipMemcpy2DAsync(slot1 + (size_t)i * pyr_frame, W, (const uint8_t*)dframes + (size_t)i * frame_stride,
                                     stride, W, H, hipMemcpyDeviceToDevice, s));
     } else {
-        VS_HIP(vsk::bgr_to_gray(dframes, W, H, stride, fmt == VS_FMT_BGR8 ? 8 : 16, fmt == VS_FMT_BGR8 ? 0 : 2, slot1, W, n,
-                                frame_stride, pyr_frame, s));
+        // BGR -> gray level 0 and level 1 in one pass (levels >= 3 always, so level 1 exists)
+        VS_HIP(vsk::ingest_pyr(dframes, W, H, stride, fmt == VS_FMT_BGR8 ? 8 : 16, fmt == VS_FMT_BGR8 ? 0 : 2, slot1,
+                               slot1 + L[1].img_off, n, frame_stride, pyr_frame, s));
     }
     t_end(1);
     t_begin(VS_STAGE_PYR_DOWN);
-    for (int l = 1; l < levels; l++)
+    for (int l = (fmt == VS_FMT_GRAY8 ? 1 : 2); l < levels; l++)
         VS_HIP(vsk::pyr_down(slot1 + L[l - 1].img_off, L[l - 1].w, L[l - 1].h, L[l - 1].w, slot1 + L[l].img_off, L[l].w,
                              L[l].h, L[l].w, n, pyr_frame, pyr_frame, s));
     t_end(levels - 1);

@@ -25,32 +25,10 @@ constexpr int PD_IH = 2 * PD_TH + 3;     // 35 input rows:    2*y0-2 .. 2*y0+2*T
 constexpr int PD_IWP = PD_IW;            // LDS row pitch (136 B)
 }
 
-__global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__ in, int w, int h, int in_stride,
-                                                     uint8_t* __restrict__ out, int ow, int oh, int out_stride,
-                                                     size_t in_frame_stride, size_t out_frame_stride) {
-    __shared__ uint8_t tile[PD_IH][PD_IWP];
-    __shared__ uint16_t vsum[PD_TH][PD_IWP];
-    in += blockIdx.z * in_frame_stride;
-    out += blockIdx.z * out_frame_stride;
-    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
-    const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;
-    // stage 35 rows x 136 bytes
-    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
-        int r = i / (PD_IW / 4), c4 = (i % (PD_IW / 4)) * 4;
-        int gy = clampi(iy0 + r, 0, h - 1);
-        const uint8_t* row = in + (size_t)gy * in_stride;
-        int gx = ix0 + c4;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < w && (((uintptr_t)(row + gx)) & 3) == 0) {
-            v = *(const uint32_t*)(row + gx);
-        } else {
-            v = (uint32_t)row[clampi(gx, 0, w - 1)] | ((uint32_t)row[clampi(gx + 1, 0, w - 1)] << 8) |
-                ((uint32_t)row[clampi(gx + 2, 0, w - 1)] << 16) | ((uint32_t)row[clampi(gx + 3, 0, w - 1)] << 24);
-        }
-        *(uint32_t*)&tile[r][c4] = v;
-    }
-    __syncthreads();
-    // vertical pass at the 16 even rows
+// The two LDS passes of pyr_down on a staged 35 x 136 tile (rows 2*y0-2.., columns 2*x0-4..): vertical 5 taps
+// at the 16 even rows into u16 column sums, then horizontal 5 taps, >> 8, 4 outputs per thread as one dword.
+__device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint16_t (*vsum)[PD_IWP], int x0, int y0,
+                                           uint8_t* __restrict__ out, int ow, int oh, int out_stride) {
     for (int i = threadIdx.x; i < PD_TH * PD_IW; i += 256) {
         int r = i / PD_IW, c = i % PD_IW;
         int rr = 2 * r;   // tile row of input row 2*(y0+r)-2
@@ -76,6 +54,34 @@ __global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__
             for (int k = 0; k < 4 && ox + k < ow; k++) dst[k] = (uint8_t)(packed >> (8 * k));
         }
     }
+}
+
+__global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__ in, int w, int h, int in_stride,
+                                                     uint8_t* __restrict__ out, int ow, int oh, int out_stride,
+                                                     size_t in_frame_stride, size_t out_frame_stride) {
+    __shared__ uint8_t tile[PD_IH][PD_IWP];
+    __shared__ uint16_t vsum[PD_TH][PD_IWP];
+    in += blockIdx.z * in_frame_stride;
+    out += blockIdx.z * out_frame_stride;
+    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
+    const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;
+    // stage 35 rows x 136 bytes
+    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
+        int r = i / (PD_IW / 4), c4 = (i % (PD_IW / 4)) * 4;
+        int gy = clampi(iy0 + r, 0, h - 1);
+        const uint8_t* row = in + (size_t)gy * in_stride;
+        int gx = ix0 + c4;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < w && (((uintptr_t)(row + gx)) & 3) == 0) {
+            v = *(const uint32_t*)(row + gx);
+        } else {
+            v = (uint32_t)row[clampi(gx, 0, w - 1)] | ((uint32_t)row[clampi(gx + 1, 0, w - 1)] << 8) |
+                ((uint32_t)row[clampi(gx + 2, 0, w - 1)] << 16) | ((uint32_t)row[clampi(gx + 3, 0, w - 1)] << 24);
+        }
+        *(uint32_t*)&tile[r][c4] = v;
+    }
+    __syncthreads();
+    pyr_passes(tile, vsum, x0, y0, out, ow, oh, out_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -112,6 +118,80 @@ __global__ __launch_bounds__(256) void vs_k_bgr_to_gray(const T* __restrict__ sr
     } else {
         for (int k = 0; k < n; k++) o[k] = (uint8_t)g[k];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ingest: BGR -> gray level 0 AND level 1 of the pyramid in one pass (alignment.cpp:212 + the first
+// PyrDown of :220-223).  A workgroup converts the 136 x 35 gray footprint of one 64 x 16 level-1 tile into
+// LDS straight from the BGR frame, writes its own 128 x 32 block of level 0, and runs pyr_down's two LDS
+// passes on the staged tile.  Level 0 is never re-read from HBM (saves W*H bytes per frame); the halo
+// (19 % more BGR reads, mostly L2 hits) is recomputed instead.  Clamp-to-edge of the gray image = gray of
+// the clamped BGR pixel, so the result is the same bytes as bgr_to_gray followed by pyr_down.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint32_t gray_of(const T* p, int shift_to_8) {
+    uint32_t g = ((uint32_t)p[0] * 3735u + (uint32_t)p[1] * 19235u + (uint32_t)p[2] * 9798u + 16384u) >> 15;
+    g >>= shift_to_8;
+    return g > 255u ? 255u : g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src, int w, int h, int src_stride,
+                                                       int shift_to_8, uint8_t* __restrict__ g0, uint8_t* __restrict__ g1,
+                                                       int ow, int oh, size_t src_frame_stride, size_t pyr_frame_stride,
+                                                       int tiles_x, int tiles_per_frame, int total_tiles, int chunk) {
+    __shared__ uint8_t tile[PD_IH][PD_IWP];
+    __shared__ uint16_t vsum[PD_TH][PD_IWP];
+    // XCD-aware order (see vs_warp.hip): each XCD walks a contiguous raster run of tiles
+    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (logical >= total_tiles) return;
+    const int frame = logical / tiles_per_frame, tl = logical - frame * tiles_per_frame;
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    src += (size_t)frame * src_frame_stride;
+    g0 += (size_t)frame * pyr_frame_stride;
+    g1 += (size_t)frame * pyr_frame_stride;
+    const int x0 = txi * PD_TW, y0 = tyi * PD_TH;          // level-1 tile origin
+    const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;          // level-0 origin of the staged tile
+    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
+        const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
+        const int gy = clampi(iy0 + r, 0, h - 1), gx = ix0 + c4;
+        const T* row = src + (size_t)gy * src_stride;
+        uint32_t v;
+        if (sizeof(T) == 1 && gx >= 0 && gx + 3 < w && ((((uintptr_t)(row + gx * 3)) & 3) == 0)) {
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            const u32x3 q = *(const u32x3*)((const uint8_t*)row + gx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            const uint32_t px[12] = {q.x & 255, (q.x >> 8) & 255, (q.x >> 16) & 255, q.x >> 24, q.y & 255, (q.y >> 8) & 255,
+                                     (q.y >> 16) & 255, q.y >> 24, q.z & 255, (q.z >> 8) & 255, (q.z >> 16) & 255, q.z >> 24};
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t g = (px[3 * k] * 3735u + px[3 * k + 1] * 19235u + px[3 * k + 2] * 9798u + 16384u) >> 15;
+                g >>= shift_to_8;
+                v |= (g > 255u ? 255u : g) << (8 * k);
+            }
+        } else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= gray_of(row + (size_t)clampi(gx + k, 0, w - 1) * 3, shift_to_8) << (8 * k);
+        }
+        *(uint32_t*)&tile[r][c4] = v;
+    }
+    __syncthreads();
+    // level 0: this workgroup's own 128 x 32 block = tile rows 2..33, columns 4..131
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        const int gy = 2 * y0 + r, gx = 2 * x0 + c4;
+        if (gy < h && gx < w) {
+            const uint32_t v = *(const uint32_t*)&tile[r + 2][c4 + 4];
+            uint8_t* dst = g0 + (size_t)gy * w + gx;
+            if (gx + 3 < w && ((((uintptr_t)dst) & 3) == 0)) {
+                *(uint32_t*)dst = v;
+            } else {
+                for (int k = 0; k < 4 && gx + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+    pyr_passes(tile, vsum, x0, y0, g1, ow, oh, ow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,6 +556,22 @@ hipError_t bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, 
     else
         hipLaunchKernelGGL(vs_k_bgr_to_gray<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
                            shift_to_8, dst, dst_stride, src_fs, dst_fs);
+    return hipGetLastError();
+}
+
+hipError_t ingest_pyr(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* g0, uint8_t* g1,
+                      int n_frames, size_t src_fs, size_t pyr_fs, hipStream_t s) {
+    const int ow = w / 2, oh = h / 2;
+    const int tiles_x = cdiv(w, 2 * PD_TW), tiles_y = cdiv(h, 2 * PD_TH);
+    const long long total = (long long)tiles_x * tiles_y * n_frames;
+    if (total > 0x3fffffffLL) return hipErrorNotSupported;
+    const int chunk = (int)((total + 7) / 8);
+    if (bits == 8)
+        hipLaunchKernelGGL(vs_k_ingest_pyr<uint8_t>, dim3(chunk * 8), dim3(256), 0, s, (const uint8_t*)src, w, h, src_stride,
+                           shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
+    else
+        hipLaunchKernelGGL(vs_k_ingest_pyr<uint16_t>, dim3(chunk * 8), dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
+                           shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
     return hipGetLastError();
 }
 

@@ -14,6 +14,9 @@ hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out
                     int n_frames, size_t in_frame_stride, size_t out_frame_stride, hipStream_t s);
 hipError_t bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,
                        int dst_stride, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, hipStream_t s);
+// BGR -> gray level 0 (dense, stride w) and level 1 (dense, stride w/2) of every frame's pyramid in one pass
+hipError_t ingest_pyr(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* g0, uint8_t* g1,
+                      int n_frames, size_t src_frame_stride, size_t pyr_frame_stride, hipStream_t s);
 hipError_t grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, hipStream_t s);
 hipError_t grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy,
                        hipStream_t s);
