@@ -125,27 +125,42 @@ def main():
                 ev.append((a, b))
         return status
 
+    def timed_loop(fn, k):
+        """k calls of fn between barrier + synchronize on both sides; returns seconds on this rank"""
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            st = fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0, st
+
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
     aligner.enable_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        status = step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, status = timed_loop(lambda: step(True), args.steps)
     # whole-job numbers: max seconds over ranks, frames summed over ranks (the only collectives of the run)
     dt, total_frames, total_aligned = vsdist.aggregate(dt, n * args.steps, int(sum(status)) * args.steps, device=dev)
+    tm = aligner.timings()
+
+    # second, separately reported figure: the alignment stage alone (BASELINE configs[1] read literally)
+    def align_only():
+        aligner.reset()
+        return aligner.align_batch_device(frames.data_ptr(), n, W, H, capi.FMT_BGR8)[0]
+    aligner.enable_timing(True)
+    dt_a, _ = timed_loop(align_only, args.steps)
+    dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * args.steps, 0, device=dev)
+    tm_a = aligner.timings()
 
     if rank == 0:
-        tm = aligner.timings()
-        stages = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // max(1, args.steps)}
-                  for k, v in tm.items() if isinstance(v, dict)}
+        def stage_table(t):
+            return {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // max(1, args.steps)}
+                    for k, v in t.items() if isinstance(v, dict) and v["launches"]}
+        stages = stage_table(tm)
         out = {
             "metric": "aligned frames/sec", "value": round(total_frames / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,6 +172,9 @@ def main():
             "aligned_per_step": total_aligned // args.steps,
             "stages": stages,
             "gn_iterations_per_frame": round(tm["gn_iterations"] / max(1, tm["frames"]), 2),
+            "align_only": {"value": round(frames_a / dt_a, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_a / args.steps, 4),
+                           "stages": stage_table(tm_a),
+                           "note": "same clip, alignment stages only (no warp launch competing for the CUs)"},
         }
         if ev:
             ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per step, n frames per launch

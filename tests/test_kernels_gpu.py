@@ -203,6 +203,36 @@ def test_bgr_image_warp_f32_and_u16(gpu_vs, oracle, mode):
     assert np.array_equal(g, o)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("border", [0, 1])
+@pytest.mark.parametrize("w,h", [(322, 241), (129, 50), (64, 16)])
+def test_bgr_image_warp_u16_bit_exact(gpu_vs, oracle, mode, border, w, h):
+    # 10-bit BGR in a u16 container (build extension): tuned path, odd sizes hit the tail stores
+    rng = np.random.default_rng(w * 7 + h)
+    src = rng.integers(0, 1024, (h, w, 3)).astype(np.uint16)
+    for tr in TRANSFORMS:
+        g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode, border, max_value=1023)
+        o = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), mode, border, max_value=1023)
+        assert np.array_equal(g, o), tr
+    full = rng.integers(0, 65536, (h, w, 3)).astype(np.uint16)
+    g = gpu_vs.bgr_image_warp(full, gpu_vs.Transform.of(0.004, -0.003, 1.3, 2.6), mode, border)
+    o = oracle.bgr_image_warp(full, oracle.Transform.of(0.004, -0.003, 1.3, 2.6), mode, border)
+    assert np.array_equal(g, o)
+
+
+@pytest.mark.parametrize("w,h", [(322, 241), (67, 35), (5, 9)])
+def test_bgr_image_warp_u8_odd_sizes_and_large_rotation(gpu_vs, oracle, w, h):
+    # tail stores, tiles narrower than 64, and footprints that do not fit the LDS window (global path)
+    rng = np.random.default_rng(w + h)
+    src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    for tr in [(0.0, 0.0, 0.5, 0.5), (0.3, 0.25, 3.0, -2.0), (-0.5, 0.0, 10.0, 5.0), (0.0, 1.0, 0.0, 0.0), (1.5, 0.0, 0.0, 0.0)]:
+        for mode in (0, 1):
+            for border in (0, 1):
+                g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode, border)
+                o = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), mode, border)
+                assert np.array_equal(g, o), (tr, mode, border)
+
+
 def test_bgr_image_warp_gray_and_4ch(gpu_vs, oracle):
     rng = np.random.default_rng(5)
     tr = (0.003, 0.002, -3.3, 4.4)

@@ -296,9 +296,9 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     VS_TRY(a.in(src, in_bytes, mem, s));
     VS_TRY(o.out(dst, out_bytes, mem));
     hipError_t e = hipErrorNotSupported;
-    if (bits == 8 && channels == 3 && !f32out && max_value == 255)
-        e = vsk::bgr_warp_u8c3(a.as<uint8_t>(), w, h, src_stride, pdev, mode, border, o.as<uint8_t>(),
-                               dst_stride, n_frames, src_fs, dst_fs, s);
+    if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
+        e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
+                             dst_fs, s);
     if (e == hipErrorNotSupported)
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, s);

@@ -623,7 +623,8 @@ int vs_aligner::configure(int w, int h, int format, const vs_aligner_params& p) 
         l.lm_off = lmo; lmo += (size_t)l.nt * 4;     // x-set (2*nt) + y-set (2*nt)
         l.jac_off = jo; jo += (size_t)l.nt * 8;      // x-set (4*nt) + y-set (4*nt)
         nt_max = std::max(nt_max, l.nt);
-        if (l.nt < 1) return set_error(VS_ERR_UNSUPPORTED, "level %d (%dx%d) has no tiles", i, ww, hh);
+        if (l.nt < 1 || ww < 4 || hh < 4)
+            return set_error(VS_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: levels below 4x4 are not supported", i, ww, hh);
     }
     pyr_frame = img; lm_frame = (lmo + 63) & ~(size_t)63; jac_frame = (jo + 63) & ~(size_t)63;
     return VS_OK;

@@ -36,9 +36,9 @@ hipError_t image_warp(const uint8_t* in, int w, int h, int stride, float A, floa
 hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int channels, int bits,
                             const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
                             bool f32out, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, hipStream_t s);
-// tuned interleaved-BGR u8 path (vs_warp.hip); returns hipErrorNotSupported when the shape does not qualify
-hipError_t bgr_warp_u8c3(const uint8_t* src, int w, int h, int src_stride, const float4* params_dev, int mode,
-                         int border, uint8_t* dst, int dst_stride, int n_frames, size_t src_frame_stride,
-                         size_t dst_frame_stride, hipStream_t s);
+// tuned interleaved 3-channel path, u8 or u16 (vs_warp.hip); hipErrorNotSupported when the grid would overflow
+hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
+                       int max_value, void* dst, int dst_stride, int n_frames, size_t src_frame_stride,
+                       size_t dst_frame_stride, hipStream_t s);
 
 }  // namespace vsk

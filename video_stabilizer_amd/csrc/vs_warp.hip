@@ -1,4 +1,4 @@
-// vs_warp.hip -- tuned bgr_image_warp for interleaved 3-channel u8 frames (the 1080p / 4K roofline kernel).
+// vs_warp.hip -- tuned bgr_image_warp for interleaved 3-channel u8 / u16 frames (the 1080p / 4K roofline kernel).
 //
 // Sampler semantics = vs_k_bgr_warp_generic (vs_kernels.hip), i.e. the reference's Lanczos2 sampler
 // (generators.cpp:672-697: 5x5 window, polynomial weights, rx inner / ry outer, num and den summed
@@ -48,15 +48,23 @@ __device__ __forceinline__ float lerpf(float a, float b, float t) { return a * (
 
 __device__ __forceinline__ float ub(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xffu); }
 
-__device__ __forceinline__ uint32_t store_u8(float v) {
+__device__ __forceinline__ uint32_t store_u(float v, float maxv) {
     float r = floorf(v + 0.5f);                 // build rule: round half up, saturate
-    r = fminf(fmaxf(r, 0.0f), 255.0f);
+    r = fminf(fmaxf(r, 0.0f), maxv);
     return (uint32_t)r;
 }
 
 // generators.cpp:31-47 on an {x,y} pair: identical roundings per component, packed instructions.
 // EDGE = the argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]); for taps 2
 // and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
+// u16 pixels: a pair of lanes owns 2 pixels = 12 bytes = 3 dwords {B0|G0, R0|B1, G1|R1}
+__device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, uint32_t& d0, uint32_t& d1) {
+    const uint32_t bg = o[0] | (o[1] << 16);
+    const uint32_t nbg = (uint32_t)__shfl_down((int)bg, 1, 64);
+    d0 = odd ? (o[1] | (o[2] << 16)) : bg;            // odd lane: G1|R1 ; even lane: B0|G0
+    d1 = o[2] | (nbg << 16);                           // even lane only: R0|B1
+}
+
 template <bool EDGE>
 __device__ __forceinline__ f2 lanczos2_pk(f2 x) {
     f2 x2 = x * x;
@@ -82,9 +90,9 @@ __device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, int m) {
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)m);
 }
 
-template <int MODE, int BORDER>
-__device__ __forceinline__ void warp_pixel_global(const uint8_t* __restrict__ src, int w, int h, int stride, float Wx,
-                                                  float Wy, uint32_t out[3]) {
+template <typename T, int MODE, int BORDER>
+__device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int w, int h, int stride, float Wx,
+                                                  float Wy, float maxv, uint32_t out[3]) {
     float flx = floorf(Wx), fly = floorf(Wy);
     int ix = (int)flx, iy = (int)fly;
     float frx = Wx - flx, fry = Wy - fly;
@@ -107,22 +115,22 @@ __device__ __forceinline__ void warp_pixel_global(const uint8_t* __restrict__ sr
                 den = den + w2d;
             }
 #pragma unroll
-        for (int c = 0; c < 3; c++) out[c] = store_u8(num[c] / den);
+        for (int c = 0; c < 3; c++) out[c] = store_u(num[c] / den, maxv);
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float top = lerpf(fetch(ix, iy, c), fetch(ix + 1, iy, c), frx);
             float bottom = lerpf(fetch(ix, iy + 1, c), fetch(ix + 1, iy + 1, c), frx);
-            out[c] = store_u8(lerpf(top, bottom, fry));
+            out[c] = store_u(lerpf(top, bottom, fry), maxv);
         }
     }
 }
 
-template <int MODE, int BORDER>
-__global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
-                                                          const float4* __restrict__ params, uint8_t* __restrict__ dst,
-                                                          int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x,
-                                                          int tiles_per_frame, int total_tiles, int chunk) {
+template <typename T, int MODE, int BORDER>
+__global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ src, int w, int h, int src_stride,
+                                                        const float4* __restrict__ params, T* __restrict__ dst,
+                                                        int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x,
+                                                        int tiles_per_frame, int total_tiles, int chunk, float maxv) {
     __shared__ f4 tile[WS_H * WS_W];                       // {B,G,R,1} per staged source pixel
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
     // workgroup b works on logical tile (b % 8) * chunk + b / 8: every XCD walks one contiguous run of
@@ -169,13 +177,22 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
                     t[0] = z; t[1] = z; t[2] = z; t[3] = z;
                     continue;
                 }
-                const uint8_t* row = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
+                const T* row = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
                 if (sx >= 0 && sx + 3 < w && ((((uintptr_t)(row + sx * 3)) & 3) == 0)) {
-                    const u32x3 q = *(const u32x3*)(row + sx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                    t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
-                    t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
-                    t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
-                    t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
+                    if (sizeof(T) == 1) {
+                        const u32x3 q = *(const u32x3*)(row + sx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                        t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
+                        t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
+                        t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
+                        t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
+                    } else {
+                        const u32x3 q0 = *(const u32x3*)(row + sx * 3), q1 = *(const u32x3*)(row + sx * 3 + 6);
+                        // q0 = B0G0 R0B1 G1R1 ; q1 = B2G2 R2B3 G3R3 (16 bits each)
+                        t[0] = f4{(float)(q0.x & 0xffffu), (float)(q0.x >> 16), (float)(q0.y & 0xffffu), 1.f};
+                        t[1] = f4{(float)(q0.y >> 16), (float)(q0.z & 0xffffu), (float)(q0.z >> 16), 1.f};
+                        t[2] = f4{(float)(q1.x & 0xffffu), (float)(q1.x >> 16), (float)(q1.y & 0xffffu), 1.f};
+                        t[3] = f4{(float)(q1.y >> 16), (float)(q1.z & 0xffffu), (float)(q1.z >> 16), 1.f};
+                    }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
                         if (BORDER == 1 && (px < 0 || px >= w)) {
                             t[k] = f4{0.f, 0.f, 0.f, 1.f};
                         } else {
-                            const uint8_t* q = row + clampi(px, 0, w - 1) * 3;
+                            const T* q = row + clampi(px, 0, w - 1) * 3;
                             t[k] = f4{(float)q[0], (float)q[1], (float)q[2], 1.f};
                         }
                     }
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
             const float Wx = A1x - B * fy + TX;          // generators.cpp:141
             const float Wy = Bx + A1 * fy + TY;          // generators.cpp:142
             if (!fits) {
-                warp_pixel_global<MODE, BORDER>(src, w, h, src_stride, Wx, Wy, o);
+                warp_pixel_global<T, MODE, BORDER>(src, w, h, src_stride, Wx, Wy, maxv, o);
             } else {
                 const float flx = floorf(Wx), fly = floorf(Wy);
                 const int ix = (int)flx, iy = (int)fly;
@@ -233,9 +250,9 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
                             nbg = nbg + ww * f2{v.x, v.y};       // num_B, num_G
                             nrd = nrd + ww * f2{v.z, v.w};       // num_R, den (v.w == 1: den + w2d*1 == den + w2d)
                         }
-                    o[0] = store_u8(nbg.x / nrd.y);
-                    o[1] = store_u8(nbg.y / nrd.y);
-                    o[2] = store_u8(nrd.x / nrd.y);
+                    o[0] = store_u(nbg.x / nrd.y, maxv);
+                    o[1] = store_u(nbg.y / nrd.y, maxv);
+                    o[2] = store_u(nrd.x / nrd.y, maxv);
                 } else {
                     const f4* t = tile + (iy - sy_lo) * WS_W + (ix - sx_lo);
                     const f4 a0 = t[0], a1 = t[1], b0 = t[WS_W], b1 = t[WS_W + 1];
@@ -248,21 +265,36 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
                     const f2 bot_r = f2{b0.z, b0.z} * otx + f2{b1.z, b1.z} * tx;
                     const f2 bg = top_bg * oty + bot_bg * ty;
                     const f2 rr = top_r * oty + bot_r * ty;
-                    o[0] = store_u8(bg.x);
-                    o[1] = store_u8(bg.y);
-                    o[2] = store_u8(rr.x);
+                    o[0] = store_u(bg.x, maxv);
+                    o[1] = store_u(bg.y, maxv);
+                    o[2] = store_u(rr.x, maxv);
                 }
             }
         }
-        uint8_t* orow = dst + (size_t)y * dst_stride;
-        const uint32_t p = o[0] | (o[1] << 8) | (o[2] << 16);
-        const uint32_t d = quad_pack_bgr(p, m);          // every lane of the wave takes part in the shuffle
-        if (quad_in && ((((uintptr_t)orow) & 3) == 0)) {
-            if (m < 3) *(uint32_t*)(orow + (size_t)(x & ~3) * 3 + 4 * m) = d;
-        } else if (x < w) {
-            orow[(size_t)x * 3] = (uint8_t)o[0];
-            orow[(size_t)x * 3 + 1] = (uint8_t)o[1];
-            orow[(size_t)x * 3 + 2] = (uint8_t)o[2];
+        T* orow = dst + (size_t)y * dst_stride;
+        if (sizeof(T) == 1) {
+            const uint32_t p = o[0] | (o[1] << 8) | (o[2] << 16);
+            const uint32_t d = quad_pack_bgr(p, m);          // every lane of the wave takes part in the shuffle
+            if (quad_in && ((((uintptr_t)orow) & 3) == 0)) {
+                if (m < 3) *(uint32_t*)((uint8_t*)orow + (size_t)(x & ~3) * 3 + 4 * m) = d;
+            } else if (x < w) {
+                orow[(size_t)x * 3] = (T)o[0];
+                orow[(size_t)x * 3 + 1] = (T)o[1];
+                orow[(size_t)x * 3 + 2] = (T)o[2];
+            }
+        } else {
+            uint32_t d0, d1;
+            pair_pack_bgr16(o, x & 1, d0, d1);
+            const bool pair_in = (x | 1) < w;
+            if (pair_in && ((((uintptr_t)orow) & 3) == 0)) {
+                uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
+                if (x & 1) q[2] = d0;
+                else { q[0] = d0; q[1] = d1; }
+            } else if (x < w) {
+                orow[(size_t)x * 3] = (T)o[0];
+                orow[(size_t)x * 3 + 1] = (T)o[1];
+                orow[(size_t)x * 3 + 2] = (T)o[2];
+            }
         }
     }
 }
@@ -271,22 +303,32 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_u8c3(const uint8_t* __restr
 
 namespace vsk {
 
-hipError_t bgr_warp_u8c3(const uint8_t* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border,
-                         uint8_t* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+template <typename T>
+static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border, T* dst,
+                            int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, hipStream_t s) {
     const int tiles_x = (w + WT_W - 1) / WT_W, tiles_y = (h + WT_H - 1) / WT_H;
     const long long total = (long long)tiles_x * tiles_y * n_frames;
     if (total > 0x3fffffffLL) return hipErrorNotSupported;
     const int chunk = (int)((total + 7) / 8);
     dim3 grid((unsigned)(chunk * 8)), block(256);
 #define VS_LAUNCH(M, Bd) \
-    hipLaunchKernelGGL((vs_k_bgr_warp_u8c3<M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs, \
-                       tiles_x, tiles_x * tiles_y, (int)total, chunk)
+    hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs, \
+                       tiles_x, tiles_x * tiles_y, (int)total, chunk, maxv)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
     else VS_LAUNCH(1, 1);
 #undef VS_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
+                       int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+    if (bits == 8)
+        return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, mode, border, (uint8_t*)dst, dst_stride, n_frames,
+                                  src_fs, dst_fs, (float)max_value, s);
+    return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, mode, border, (uint16_t*)dst, dst_stride, n_frames,
+                               src_fs, dst_fs, (float)max_value, s);
 }
 
 }  // namespace vsk
