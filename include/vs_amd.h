@@ -245,6 +245,13 @@ void vs_stabilizer_destroy(vs_stabilizer* s);
  * returns 1 when an output frame was written (0 for the first `lag` frames), <0 on error. */
 int  vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem,
                            void* out, int* out_w, int* out_h);
+/* Batched form: exactly n successive vs_stabilizer_process calls (one batched alignment, the reference's scalar
+ * bookkeeping in order on the host, batched warps).  frames: frame i at frames + i*frame_stride (elements);
+ * has_output[i] = 1 when input frame i produced an output, written dense at out + i*out_frame_stride (elements,
+ * >= out_w*out_h*3).  Returns the number of output frames, or <0. */
+int  vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
+                                 int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output,
+                                 int* out_w, int* out_h);
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 
 #ifdef __cplusplus

@@ -195,3 +195,25 @@ def test_stabilizer_matches_oracle(gpu_vs, oracle, mode):
             assert d.max() <= 1 and (d != 0).mean() < 1e-2
     assert produced == 16 - 4
     assert g.process(np.ascontiguousarray(frames[0][:200])) is None   # a size change restarts cleanly
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+def test_stabilizer_batch_equals_sequential(gpu_vs, oracle, bits):
+    # vs_stabilizer_process_batch is defined as n successive process calls: same outputs, bit for bit
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 17, seed=91, channels=3, bits=bits)
+    kw = dict(lag=4, smoother_memory=2, crop_pixels=16)
+    seq = gpu_vs.Stabilizer(device=0, **kw)
+    outs = [seq.process(f) for f in frames]
+    bat = gpu_vs.Stabilizer(device=0, **kw)
+    o1, h1 = bat.process_batch(frames[:7])       # state (queue, smoother, accum) carries across batches
+    o2, h2 = bat.process_batch(frames[7:9])
+    o3, h3 = bat.process_batch(frames[9:])
+    ob = np.concatenate([o1, o2, o3], 0)
+    hb = h1 + h2 + h3
+    for i in range(len(frames)):
+        assert bool(hb[i]) == (outs[i] is not None), i
+        if outs[i] is not None:
+            assert np.array_equal(ob[i], outs[i]), i
+    assert sum(hb) == 17 - 4
+    assert seq.state()[1].tup() == bat.state()[1].tup()

@@ -120,6 +120,7 @@ SIGNATURES = {
     "vs_stabilizer_create": (_vp, [C.POINTER(StabilizerParams), _i32]),
     "vs_stabilizer_destroy": (None, [_vp]),
     "vs_stabilizer_process": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _IP, _IP]),
+    "vs_stabilizer_process_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, C.POINTER(C.c_int32), _IP, _IP]),
     "vs_stabilizer_state": (None, [_vp, _TP, _TP, _IP]),
 }
 
@@ -536,6 +537,28 @@ class Stabilizer:
         ow, oh = C.c_int(), C.c_int()
         r = _check(lib().vs_stabilizer_process(self.h, _p(frame), ww, hh, ww * 3, fmt, MEM_HOST, _p(out), C.byref(ow), C.byref(oh)))
         return out if r == 1 else None
+
+    def process_batch(self, frames):
+        """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list)"""
+        frames = np.ascontiguousarray(frames)
+        n, hh, ww = frames.shape[:3]
+        fmt = _fmt_of(frames.dtype, 3)
+        c = max(self.params.crop_pixels, 0)
+        out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
+        has = (C.c_int32 * n)()
+        ow, oh = C.c_int(), C.c_int()
+        _check(lib().vs_stabilizer_process_batch(self.h, _p(frames), hh * ww * 3, n, ww, hh, ww * 3, fmt, MEM_HOST, _p(out),
+                                                 out[0].size, has, C.byref(ow), C.byref(oh)))
+        return out, list(has)
+
+    def process_batch_device(self, ptr, n, w, h, fmt, out_ptr):
+        """dense device-resident frames in, dense cropped frames out (raw device pointers)"""
+        c = max(self.params.crop_pixels, 0)
+        has = (C.c_int32 * n)()
+        ow, oh = C.c_int(), C.c_int()
+        r = _check(lib().vs_stabilizer_process_batch(self.h, _p(ptr), h * w * 3, n, w, h, w * 3, fmt, MEM_DEVICE, _p(out_ptr),
+                                                     (h - 2 * c) * (w - 2 * c) * 3, has, C.byref(ow), C.byref(oh)))
+        return r, list(has)
 
     def state(self):
         m, a, s = Transform(), Transform(), C.c_int()

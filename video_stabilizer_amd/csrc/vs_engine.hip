@@ -1044,14 +1044,25 @@ struct vs_stabilizer {
     vs_smoother* smoother = nullptr;
     int frame_index = 0;
     std::deque<vs_transform> measurements;
-    std::deque<void*> frames;      // device copies of the buffered input frames (stabilizer.cpp:15)
+    struct Held { void* ptr; bool owned; };   // owned: a buffer of ours; else a frame of the batch being processed
+    std::deque<Held> frames;       // the buffered input frames (stabilizer.cpp:15), dense, in device memory
     std::vector<void*> pool;       // recycled frame buffers
     size_t frame_bytes = 0;
-    void* warped = nullptr; size_t warped_bytes = 0;
+    void* batch_in = nullptr; size_t batch_in_bytes = 0;     // dense device copy of the current batch
+    void* batch_out = nullptr; size_t batch_out_bytes = 0;   // full-size warped frames of the current batch
+    std::vector<vs_transform> t_buf;
+    std::vector<int32_t> st_buf;
     vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
     int last_success = 0;
     int w = 0, h = 0, fmt = -1;
 };
+
+static void stab_drop_frames(vs_stabilizer* s) {
+    for (auto& f : s->frames) if (f.owned) (void)hipFree(f.ptr);
+    for (void* p : s->pool) (void)hipFree(p);
+    s->frames.clear();
+    s->pool.clear();
+}
 
 extern "C" {
 
@@ -1070,21 +1081,27 @@ vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int devi
 void vs_stabilizer_destroy(vs_stabilizer* s) {
     if (!s) return;
     (void)hipSetDevice(s->aligner->device);
-    for (void* p : s->frames) (void)hipFree(p);
-    for (void* p : s->pool) (void)hipFree(p);
-    if (s->warped) (void)hipFree(s->warped);
+    stab_drop_frames(s);
+    if (s->batch_in) (void)hipFree(s->batch_in);
+    if (s->batch_out) (void)hipFree(s->batch_out);
     vs_smoother_destroy(s->smoother);
     vs_aligner_destroy(s->aligner);
     delete s;
 }
 
-int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem, void* out,
-                          int* out_w, int* out_h) {
-    VS_ARG(s && frame && out && out_w && out_h);
+// n successive VideoStabilizer::processFrame calls (stabilizer.cpp:9-117) as one batch: one batched alignment,
+// the scalar bookkeeping on the host exactly as the reference orders it, then batched warps of every frame that
+// became due.  has_output[i] = 1 when input frame i produced an output, written to out + i*out_frame_stride.
+int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
+                                int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
+                                int* out_h) {
+    VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
     VS_ARG(format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
     VS_ARG(stride >= 3 * w);
     const int crop = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
     VS_ARG(w > 2 * crop && h > 2 * crop);
+    const int ow = w - 2 * crop, oh = h - 2 * crop;
+    VS_ARG(n == 1 || (frame_stride >= (size_t)(h - 1) * stride + (size_t)3 * w && out_frame_stride >= (size_t)ow * oh * 3));
     vs_aligner* a = s->aligner;
     VS_HIP(hipSetDevice(a->device));
     hipStream_t st = a->stream;
@@ -1092,84 +1109,138 @@ int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int
     const size_t fbytes = (size_t)w * h * 3 * esz;
     if (s->w != w || s->h != h || s->fmt != format) {
         // a size change restarts the aligner (alignment.cpp:155); buffered frames of the old size are dropped
-        for (void* p : s->frames) (void)hipFree(p);
-        for (void* p : s->pool) (void)hipFree(p);
-        s->frames.clear(); s->pool.clear(); s->measurements.clear();
+        stab_drop_frames(s);
+        s->measurements.clear();
         s->w = w; s->h = h; s->fmt = format; s->frame_bytes = fbytes;
     }
-    ++s->frame_index;
+    *out_w = ow; *out_h = oh;
 
-    // stabilizer.cpp:15: keep a private (device) copy of the frame, densely packed
-    void* copy = nullptr;
-    if (!s->pool.empty()) { copy = s->pool.back(); s->pool.pop_back(); }
-    else VS_HIP(hipMalloc(&copy, fbytes));
-    VS_HIP(hipMemcpy2DAsync(copy, (size_t)w * 3 * esz, frame, (size_t)stride * esz, (size_t)w * 3 * esz, h,
-                            mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
-    s->frames.push_back(copy);
-
-    // stabilizer.cpp:18-19 (aligning from the dense device copy: same bytes)
-    vs_transform meas{0, 0, 0, 0};
-    int r = vs_aligner_align_next(a, copy, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner, &meas);
-    if (r < 0) return r;
-    const bool success = r == 1;
-    s->last_meas = meas; s->last_success = success ? 1 : 0;
-
-    vs_transform earliest_smoothed{0, 0, 0, 0};
-    if (s->params.enable_smoother) (void)vs_smoother_update(s->smoother, &meas, &earliest_smoothed);   // :35
-    if (!success) s->accum = vs_transform{0, 0, 0, 0};                                                  // :39-41
-    s->measurements.push_back(meas);                                                                   // :44
-    int produced = 0;
-    if (s->measurements.size() > (size_t)s->params.lag) {                                              // :48
-        vs_transform earliest = s->measurements.front();
-        s->measurements.pop_front();
-        vs_transform jitter;
-        if (s->params.enable_smoother) {
-            vs_transform inv = vs_transform_inverse(&earliest_smoothed);
-            jitter = vs_transform_compose(&earliest, &inv);                                            // :60
-        } else {
-            jitter = earliest;
+    // stabilizer.cpp:15: a private dense copy of every input frame, in device memory
+    const uint8_t* dense = nullptr;
+    const bool already_dense = mem == VS_MEM_DEVICE && stride == 3 * w && (n == 1 || frame_stride == (size_t)h * stride);
+    if (already_dense) {
+        dense = (const uint8_t*)frames;      // read in place during this call; the tail is copied out below
+    } else {
+        if (s->batch_in_bytes < fbytes * n) {
+            if (s->batch_in) (void)hipFree(s->batch_in);
+            s->batch_in = nullptr; s->batch_in_bytes = 0;
+            VS_HIP(hipMalloc(&s->batch_in, fbytes * n));
+            s->batch_in_bytes = fbytes * n;
         }
-        vs_transform na = vs_transform_compose(&s->accum, &jitter);                                    // :66
-        const double disp = vs_transform_max_corner_displacement(&na, w, h);                           // :69-70
-        double decay;
-        if (disp > s->params.max_disp) {
-            decay = s->params.max_decay;
-        } else if (disp > s->params.min_disp) {
-            double f = (disp - s->params.min_disp) / (s->params.max_disp - s->params.min_disp);
-            f = std::max(0.0, std::min(1.0, f));
-            decay = s->params.min_decay * (1.0 - f) + s->params.max_decay * f;
-        } else {
-            decay = s->params.min_decay;
-        }
-        na.TX *= decay; na.TY *= decay; na.A *= decay; na.B *= decay;                                  // :88-91
-        s->accum = na;
-        if (!s->frames.empty()) {
-            void* src = s->frames.front();
-            s->frames.pop_front();
-            // :97-99: warpBySimilarityTransform(frame, accum^-1); cv::warpAffine without WARP_INVERSE_MAP
-            // inverts the matrix it is given (imgproc.cpp:472), so the sampling map is (accum^-1)^-1.
-            vs_transform correction = vs_transform_inverse(&na);
-            vs_transform sampling = vs_transform_inverse(&correction);
-            if (s->warped_bytes < fbytes) {
-                if (s->warped) (void)hipFree(s->warped);
-                s->warped = nullptr; s->warped_bytes = 0;
-                VS_HIP(hipMalloc(&s->warped, fbytes));
-                s->warped_bytes = fbytes;
+        for (int i = 0; i < n; i++)
+            VS_HIP(hipMemcpy2DAsync((uint8_t*)s->batch_in + (size_t)i * fbytes, (size_t)w * 3 * esz,
+                                    (const uint8_t*)frames + (size_t)i * frame_stride * esz, (size_t)stride * esz,
+                                    (size_t)w * 3 * esz, h, mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+        dense = (const uint8_t*)s->batch_in;
+    }
+
+    // stabilizer.cpp:18-19 for all n frames
+    s->t_buf.resize(n);
+    s->st_buf.resize(n);
+    {
+        int r = vs_aligner_align_batch(a, dense, (size_t)w * h * 3, n, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner,
+                                       s->t_buf.data(), s->st_buf.data());
+        if (r < 0) return r;
+    }
+
+    struct Job { const void* src; vs_transform sampling; int i; void* release; };
+    std::vector<Job> jobs;
+    for (int i = 0; i < n; i++) {
+        ++s->frame_index;
+        s->frames.push_back(vs_stabilizer::Held{(void*)(dense + (size_t)i * fbytes), false});
+        const vs_transform meas = s->t_buf[i];
+        const bool success = s->st_buf[i] == 1;
+        s->last_meas = meas; s->last_success = success ? 1 : 0;
+        has_output[i] = 0;
+
+        vs_transform earliest_smoothed{0, 0, 0, 0};
+        if (s->params.enable_smoother) (void)vs_smoother_update(s->smoother, &meas, &earliest_smoothed);   // :35
+        if (!success) s->accum = vs_transform{0, 0, 0, 0};                                                  // :39-41
+        s->measurements.push_back(meas);                                                                   // :44
+        if (s->measurements.size() > (size_t)s->params.lag) {                                              // :48
+            vs_transform earliest = s->measurements.front();
+            s->measurements.pop_front();
+            vs_transform jitter;
+            if (s->params.enable_smoother) {
+                vs_transform inv = vs_transform_inverse(&earliest_smoothed);
+                jitter = vs_transform_compose(&earliest, &inv);                                            // :60
+            } else {
+                jitter = earliest;
             }
-            int wr = vs_bgr_image_warp(src, w, h, w * 3, 3, (int)esz * 8, &sampling, s->params.warp_mode,
-                                       s->params.warp_border, esz == 1 ? 255 : 65535, s->warped, w * 3, VS_MEM_DEVICE, st);
-            if (wr < 0) return wr;
-            const int ow = w - 2 * crop, oh = h - 2 * crop;                                            // :102-109
-            VS_HIP(hipMemcpy2DAsync(out, (size_t)ow * 3 * esz, (const uint8_t*)s->warped + ((size_t)crop * w + crop) * 3 * esz,
-                                    (size_t)w * 3 * esz, (size_t)ow * 3 * esz, oh,
-                                    mem == VS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
-            VS_HIP(hipStreamSynchronize(st));
-            s->pool.push_back(src);
-            *out_w = ow; *out_h = oh;
-            produced = 1;
+            vs_transform na = vs_transform_compose(&s->accum, &jitter);                                    // :66
+            const double disp = vs_transform_max_corner_displacement(&na, w, h);                           // :69-70
+            double decay;
+            if (disp > s->params.max_disp) {
+                decay = s->params.max_decay;
+            } else if (disp > s->params.min_disp) {
+                double f = (disp - s->params.min_disp) / (s->params.max_disp - s->params.min_disp);
+                f = std::max(0.0, std::min(1.0, f));
+                decay = s->params.min_decay * (1.0 - f) + s->params.max_decay * f;
+            } else {
+                decay = s->params.min_decay;
+            }
+            na.TX *= decay; na.TY *= decay; na.A *= decay; na.B *= decay;                                  // :88-91
+            s->accum = na;
+            if (!s->frames.empty()) {
+                vs_stabilizer::Held src = s->frames.front();
+                s->frames.pop_front();
+                // :97-99: warpBySimilarityTransform(frame, accum^-1); cv::warpAffine without WARP_INVERSE_MAP
+                // inverts the matrix it is given (imgproc.cpp:472), so the sampling map is (accum^-1)^-1.
+                vs_transform correction = vs_transform_inverse(&na);
+                jobs.push_back(Job{src.ptr, vs_transform_inverse(&correction), i, src.owned ? src.ptr : nullptr});
+                has_output[i] = 1;
+            }
         }
     }
+
+    // warp every due frame: runs of consecutive batch frames go out as one launch
+    if (!jobs.empty()) {
+        if (s->batch_out_bytes < fbytes * jobs.size()) {
+            if (s->batch_out) (void)hipFree(s->batch_out);
+            s->batch_out = nullptr; s->batch_out_bytes = 0;
+            VS_HIP(hipMalloc(&s->batch_out, fbytes * jobs.size()));
+            s->batch_out_bytes = fbytes * jobs.size();
+        }
+        std::vector<vs_transform> ts;
+        for (size_t j = 0; j < jobs.size();) {
+            size_t e = j + 1;
+            while (e < jobs.size() && (const uint8_t*)jobs[e].src == (const uint8_t*)jobs[e - 1].src + fbytes) e++;
+            ts.clear();
+            for (size_t k = j; k < e; k++) ts.push_back(jobs[k].sampling);
+            int wr = vs_bgr_image_warp_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
+                                             s->params.warp_mode, s->params.warp_border, esz == 1 ? 255 : 65535,
+                                             (uint8_t*)s->batch_out + j * fbytes, (size_t)w * h * 3, w * 3, VS_MEM_DEVICE, st);
+            if (wr < 0) return wr;
+            j = e;
+        }
+        for (size_t j = 0; j < jobs.size(); j++) {                                                          // :102-109 crop
+            VS_HIP(hipMemcpy2DAsync((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz, (size_t)ow * 3 * esz,
+                                    (const uint8_t*)s->batch_out + j * fbytes + ((size_t)crop * w + crop) * 3 * esz,
+                                    (size_t)w * 3 * esz, (size_t)ow * 3 * esz, oh,
+                                    mem == VS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+            if (jobs[j].release) s->pool.push_back(jobs[j].release);   // reused only by later work on this stream
+        }
+    }
+    // frames of this batch that are still queued move into buffers of our own
+    for (auto& f : s->frames) {
+        if (f.owned) continue;
+        void* copy = nullptr;
+        if (!s->pool.empty()) { copy = s->pool.back(); s->pool.pop_back(); }
+        else VS_HIP(hipMalloc(&copy, fbytes));
+        VS_HIP(hipMemcpyAsync(copy, f.ptr, fbytes, hipMemcpyDeviceToDevice, st));
+        f.ptr = copy; f.owned = true;
+    }
+    VS_HIP(hipStreamSynchronize(st));
+    int produced = 0;
+    for (int i = 0; i < n; i++) produced += has_output[i];
     return produced;
+}
+
+int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem, void* out,
+                          int* out_w, int* out_h) {
+    int32_t has = 0;
+    int r = vs_stabilizer_process_batch(s, frame, 0, 1, w, h, stride, format, mem, out, 0, &has, out_w, out_h);
+    return r < 0 ? r : has;
 }
 
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success) {
