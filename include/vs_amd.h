@@ -252,6 +252,7 @@ int  vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, in
 int  vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
                                  int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output,
                                  int* out_w, int* out_h);
+int  vs_stabilizer_reset(vs_stabilizer* s);   /* start a new clip; device buffers are kept */
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 
 #ifdef __cplusplus

@@ -121,6 +121,7 @@ SIGNATURES = {
     "vs_stabilizer_destroy": (None, [_vp]),
     "vs_stabilizer_process": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _IP, _IP]),
     "vs_stabilizer_process_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, C.POINTER(C.c_int32), _IP, _IP]),
+    "vs_stabilizer_reset": (_i32, [_vp]),
     "vs_stabilizer_state": (None, [_vp, _TP, _TP, _IP]),
 }
 
@@ -537,6 +538,9 @@ class Stabilizer:
         ow, oh = C.c_int(), C.c_int()
         r = _check(lib().vs_stabilizer_process(self.h, _p(frame), ww, hh, ww * 3, fmt, MEM_HOST, _p(out), C.byref(ow), C.byref(oh)))
         return out if r == 1 else None
+
+    def reset(self):
+        _check(lib().vs_stabilizer_reset(self.h))
 
     def process_batch(self, frames):
         """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list)"""

@@ -1236,6 +1236,22 @@ int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t fra
     return produced;
 }
 
+// forget the clip: the next frame starts a new sequence (device buffers are kept)
+int vs_stabilizer_reset(vs_stabilizer* s) {
+    VS_ARG(s);
+    VS_HIP(hipSetDevice(s->aligner->device));
+    for (auto& f : s->frames) if (f.owned) s->pool.push_back(f.ptr);
+    s->frames.clear();
+    s->measurements.clear();
+    vs_smoother_destroy(s->smoother);
+    s->smoother = vs_smoother_create(s->params.lag, s->params.smoother_memory, s->params.lambda);
+    s->accum = vs_transform{0, 0, 0, 0};
+    s->last_meas = vs_transform{0, 0, 0, 0};
+    s->last_success = 0;
+    s->frame_index = 0;
+    return vs_aligner_reset(s->aligner);
+}
+
 int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem, void* out,
                           int* out_w, int* out_h) {
     int32_t has = 0;

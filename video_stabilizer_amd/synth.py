@@ -103,33 +103,46 @@ def make_clip(width, height, n_frames, seed, channels=1, bits=8, path=None, marg
     return frames, path
 
 
+class TorchClipFactory:
+    """Device-side twin of make_clip for full-size clips: the base textures (numpy, uploaded once) are shared by
+    every clip of the factory, each clip has its own camera path (path_seed); the per-frame bilinear resampling
+    runs as torch ops on `device`.  torch is plumbing here: it only produces the input bytes."""
+
+    def __init__(self, width, height, seed, device, channels=3, bits=8, margin=128):
+        import torch
+        self.torch = torch
+        self.w, self.h, self.channels, self.bits, self.margin, self.device = width, height, channels, bits, margin, device
+        self.max_value = 255 if bits == 8 else (1 << bits) - 1
+        self.texs = [torch.from_numpy(base_texture(width + 2 * margin, height + 2 * margin, seed + c, self.max_value)).to(device)
+                     for c in range(channels)]
+        self.ys = torch.arange(height, dtype=torch.float64, device=device)[:, None]
+        self.xs = torch.arange(width, dtype=torch.float64, device=device)[None, :]
+
+    def make(self, n_frames, path_seed, path=None, out=None, **path_kw):
+        torch = self.torch
+        if path is None:
+            path = camera_path(n_frames, path_seed, **path_kw)
+        th, tw = self.texs[0].shape
+        dt = torch.uint8 if self.bits == 8 else torch.int16      # int16 carries the u16 bit pattern (values < 32768)
+        if out is None:
+            out = torch.empty((n_frames, self.h, self.w, self.channels), dtype=dt, device=self.device)
+        cx, cy = self.w * 0.5, self.h * 0.5
+        px, py = self.xs - cx, self.ys - cy
+        for i, (A, B, TX, TY) in enumerate(path):
+            sx = (1 + A) * px - B * py + cx + TX + self.margin
+            sy = B * px + (1 + A) * py + cy + TY + self.margin
+            x0 = torch.clamp(torch.floor(sx).long(), 0, tw - 2)
+            y0 = torch.clamp(torch.floor(sy).long(), 0, th - 2)
+            fx = torch.clamp(sx - x0, 0, 1)
+            fy = torch.clamp(sy - y0, 0, 1)
+            i00 = y0 * tw + x0
+            for c in range(self.channels):
+                t = self.texs[c].reshape(-1)
+                v = (t[i00] * (1 - fx) + t[i00 + 1] * fx) * (1 - fy) + (t[i00 + tw] * (1 - fx) + t[i00 + tw + 1] * fx) * fy
+                out[i, :, :, c] = torch.clamp(torch.floor(v + 0.5), 0, self.max_value).to(dt)
+        return out, path
+
+
 def make_clip_torch(width, height, n_frames, seed, device, channels=3, bits=8, path=None, margin=128, **path_kw):
-    """Device-side twin of make_clip for full-size clips: same textures (numpy, uploaded once), the
-    per-frame bilinear resampling runs as torch ops on `device`.  Returns (uint8/int16-viewed tensor
-    (n,h,w,c), path).  torch is plumbing here: it only produces the input bytes."""
-    import torch
-    max_value = 255 if bits == 8 else (1 << bits) - 1
-    if path is None:
-        path = camera_path(n_frames, seed, **path_kw)
-    texs = [torch.from_numpy(base_texture(width + 2 * margin, height + 2 * margin, seed + c, max_value)).to(device)
-            for c in range(channels)]
-    th, tw = texs[0].shape
-    dt = torch.uint8 if bits == 8 else torch.int16      # int16 carries the u16 bit pattern (values < 32768)
-    out = torch.empty((n_frames, height, width, channels), dtype=dt, device=device)
-    ys = torch.arange(height, dtype=torch.float64, device=device)[:, None]
-    xs = torch.arange(width, dtype=torch.float64, device=device)[None, :]
-    cx, cy = width * 0.5, height * 0.5
-    px, py = xs - cx, ys - cy
-    for i, (A, B, TX, TY) in enumerate(path):
-        sx = (1 + A) * px - B * py + cx + TX + margin
-        sy = B * px + (1 + A) * py + cy + TY + margin
-        x0 = torch.clamp(torch.floor(sx).long(), 0, tw - 2)
-        y0 = torch.clamp(torch.floor(sy).long(), 0, th - 2)
-        fx = torch.clamp(sx - x0, 0, 1)
-        fy = torch.clamp(sy - y0, 0, 1)
-        i00 = y0 * tw + x0
-        for c in range(channels):
-            t = texs[c].reshape(-1)
-            v = (t[i00] * (1 - fx) + t[i00 + 1] * fx) * (1 - fy) + (t[i00 + tw] * (1 - fx) + t[i00 + tw + 1] * fx) * fy
-            out[i, :, :, c] = torch.clamp(torch.floor(v + 0.5), 0, max_value).to(dt)
-    return out, path
+    """one clip: (tensor (n,h,w,c) uint8 / int16-viewed u16, path)"""
+    return TorchClipFactory(width, height, seed, device, channels, bits, margin).make(n_frames, seed, path=path, **path_kw)
