@@ -118,7 +118,9 @@ def main():
     max_value = 255 if bits == 8 else (1 << bits) - 1
     # global clip index of local clip j = rank + j*world (clip i -> rank i mod N); textures per rank, path per clip
     factory = synth.TorchClipFactory(W, H, wl["seed"] + 1000 * rank, dev, channels=3, bits=bits)
-    clips = [factory.make(n, wl["seed"] + 1000 * (rank + j * world))[0] for j in range(n_clips)]
+    # the rank's clips live back to back in one tensor, so the aligner can take all of them in one call
+    all_frames = torch.empty((n_clips * n, H, W, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
+    clips = [factory.make(n, wl["seed"] + 1000 * (rank + j * world), out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
     torch.cuda.synchronize()
 
     params_kw = dict(pyramid_min_width=256)
@@ -141,25 +143,23 @@ def main():
     else:
         aligner = capi.Aligner(device=local_rank,
                                select_mode=capi.SELECT_DEVICE if args.select == "device" else capi.SELECT_STL_HOST, **params_kw)
-        warped = torch.empty_like(clips[0])
+        warped = torch.empty_like(all_frames)
+        N = n_clips * n
 
         def step(timed):
-            aligned = 0
-            for c in clips:
-                aligner.reset()
-                status, ts = aligner.align_batch_device(c.data_ptr(), n, W, H, fmt)
-                aligned += sum(status)
-                if not args.no_warp:
-                    if timed:
-                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        a.record(stream)
-                    capi.bgr_image_warp_batch_device(c.data_ptr(), n, W, H, 3, 8 if bits == 8 else 16, ts, warped.data_ptr(),
-                                                     capi.WARP_LANCZOS2, capi.BORDER_CLAMP, max_value=max_value,
-                                                     stream=stream.cuda_stream)
-                    if timed:
-                        b.record(stream)
-                        ev.append((a, b))
-            return aligned
+            # all clips of the rank in one call (vs_aligner_align_clips): every stage is one launch over all clips
+            status, ts = aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt)
+            if not args.no_warp:
+                if timed:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                capi.bgr_image_warp_batch_device(all_frames.data_ptr(), N, W, H, 3, 8 if bits == 8 else 16, ts, warped.data_ptr(),
+                                                 capi.WARP_LANCZOS2, capi.BORDER_CLAMP, max_value=max_value,
+                                                 stream=stream.cuda_stream)
+                if timed:
+                    b.record(stream)
+                    ev.append((a, b))
+            return sum(status)
 
     def timed_loop(fn, k):
         """k calls of fn between barrier + synchronize on both sides; seconds on this rank, last return value"""
@@ -188,9 +188,7 @@ def main():
     if aligner and not args.no_warp:
         # second, separately reported figure: the alignment stages alone (BASELINE configs[1] read literally)
         def fn():
-            for c in clips:
-                aligner.reset()
-                aligner.align_batch_device(c.data_ptr(), n, W, H, fmt)
+            aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt)
         aligner.enable_timing(True)
         dt_a, _ = timed_loop(fn, args.steps)
         dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=dev)
@@ -221,8 +219,8 @@ def main():
                                  "ms_per_step": round(1e3 * dt_a / args.steps, 4), "stages": stage_table(tm_a),
                                  "note": "same clips, alignment stages only (no warp launch competing for the CUs)"}
         if ev:
-            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per clip, n frames per launch
-            bytes_per_launch = W * H * 3 * 2 * (1 if bits == 8 else 2) * n  # W*H*3*(in+out) bytes per frame
+            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per step over all the rank's frames
+            bytes_per_launch = W * H * 3 * 2 * (1 if bits == 8 else 2) * n * n_clips  # W*H*3*(in+out) B per frame
             achieved = bytes_per_launch / (ms * 1e-3) / 1e9
             # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), scaled to
             # this launch's frame count; null when there is no profile for this frame format
@@ -230,7 +228,7 @@ def main():
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
                 key, per = {(1920, 8): ("c2_1080p_240_frames", 240), (3840, 8): ("c3_4k_32_frames", 32)}[(W, bits)]
-                traffic = int(tj[key]["traffic_bytes"] / per * n)
+                traffic = int(tj[key]["traffic_bytes"] / per * n * n_clips)
             except Exception:
                 pass
             out["roofline"] = {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm",

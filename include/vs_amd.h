@@ -206,6 +206,12 @@ int  vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int s
 int  vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n,
                             int w, int h, int stride, int format, int mem,
                             const vs_aligner_params* params, vs_transform* out, int32_t* status);
+/* Many independent clips at once: n_clips clips of frames_per_clip frames, back to back (clip c, frame k at index
+ * c*frames_per_clip + k).  Results = every clip aligned by its own fresh VideoAligner (frame 0 of each clip: status 0,
+ * fail_reason 1), computed together so that short clips still fill the GPU.  Resets the handle's running sequence. */
+int  vs_aligner_align_clips(vs_aligner* a, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip,
+                            int w, int h, int stride, int format, int mem,
+                            const vs_aligner_params* params, vs_transform* out, int32_t* status);
 /* detail for frame i of the most recent align_next (i = 0) / align_batch call */
 int  vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info);
 /* device pointers / dims of internal per-level state of the most recent call (parity tests) */

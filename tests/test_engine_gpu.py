@@ -217,3 +217,22 @@ def test_stabilizer_batch_equals_sequential(gpu_vs, oracle, bits):
             assert np.array_equal(ob[i], outs[i]), i
     assert sum(hb) == 17 - 4
     assert seq.state()[1].tup() == bat.state()[1].tup()
+
+
+@pytest.mark.parametrize("fpc", [4, 5])
+def test_align_clips_equals_fresh_aligner_per_clip(gpu_vs, fpc):
+    # vs_aligner_align_clips: every clip as if aligned by its own fresh VideoAligner (even and odd clip lengths)
+    from video_stabilizer_amd import synth
+    clips = [synth.make_clip(320, 240, fpc, seed=200 + c, channels=3)[0] for c in range(3)]
+    al = gpu_vs.Aligner(device=0)
+    st, ts = al.align_clips(np.concatenate(clips, 0), 3)
+    for c in range(3):
+        ref = gpu_vs.Aligner(device=0)
+        rs, rt = ref.align_batch(clips[c])
+        for k in range(fpc):
+            assert st[c * fpc + k] == rs[k]
+            assert ts[c * fpc + k].tup() == rt[k].tup()
+        assert st[c * fpc] == 0 and al.info(c * fpc).fail_reason == 1
+    # the handle is a plain sequential aligner again afterwards
+    s2, _ = al.align_batch(clips[0])
+    assert s2 == list(gpu_vs.Aligner(device=0).align_batch(clips[0])[0])

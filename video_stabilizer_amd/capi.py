@@ -110,6 +110,7 @@ SIGNATURES = {
     "vs_aligner_reset": (_i32, [_vp]),
     "vs_aligner_align_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP]),
     "vs_aligner_align_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP, C.POINTER(C.c_int32)]),
+    "vs_aligner_align_clips": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP, C.POINTER(C.c_int32)]),
     "vs_aligner_enable_timing": (_i32, [_vp, _i32]),
     "vs_aligner_get_timings": (_i32, [_vp, C.POINTER(StageTimings)]),
     "vs_aligner_get_info": (_i32, [_vp, _i32, C.POINTER(AlignInfo)]),
@@ -468,6 +469,24 @@ class Aligner:
         out = (Transform * n)()
         status = (C.c_int32 * n)()
         _check(lib().vs_aligner_align_batch(self.h, _p(ptr), frame_stride, n, w, h, stride, fmt, MEM_DEVICE,
+                                            C.byref(self.params), out, status))
+        return list(status), list(out)
+
+    def align_clips(self, frames, n_clips, mem_ptr=None, w=None, h=None, fmt=None):
+        """frames: numpy (n_clips*fpc, h, w[,3]) (host) -- or pass mem_ptr/w/h/fmt with frames = total frame count
+        for dense device-resident clips.  returns (status list, transforms list)"""
+        if mem_ptr is None:
+            frames = np.ascontiguousarray(frames)
+            n = frames.shape[0]
+            fmt = _fmt_of(frames.dtype, frames.ndim - 1)
+            h, w = frames.shape[1:3]
+            ptr, mem = _p(frames), MEM_HOST
+        else:
+            n, ptr, mem = int(frames), _p(mem_ptr), MEM_DEVICE
+        ch = 1 if fmt == FMT_GRAY8 else 3
+        out = (Transform * n)()
+        status = (C.c_int32 * n)()
+        _check(lib().vs_aligner_align_clips(self.h, ptr, h * w * ch, n_clips, n // n_clips, w, h, w * ch, fmt, mem,
                                             C.byref(self.params), out, status))
         return list(status), list(out)
 

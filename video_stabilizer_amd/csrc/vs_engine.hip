@@ -527,6 +527,7 @@ struct vs_aligner {
     int levels = 0;
     LevelDims L[kMaxLevels];
     long long seq = 0;          // frames consumed since (re)initialisation
+    int clip_len = 0;           // > 0 during vs_aligner_align_clips: the batch is independent clips of this many frames
     size_t pyr_frame = 0, lm_frame = 0, jac_frame = 0;   // bytes / u16 elements / f32 elements per slot
     int nt_max = 0;
 
@@ -752,40 +753,51 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
     t_end(levels - 1);
 
     // ---- ComputeKeyFrame (alignment.cpp:237-276) for the odd frames of the sequence -----------
-    // frame i of this chunk has sequence index g = seq + i and sits in slot i + 1
-    const int first_odd = (seq & 1) ? 0 : 1;   // smallest i with (seq + i) odd
-    const int n_odd = first_odd < n ? (n - first_odd + 1) / 2 : 0;
-    if (n_odd > 0) {
-        const size_t so = (size_t)(first_odd + 1);
-        t_begin(VS_STAGE_KEYFRAME);
-        for (int l = 0; l < levels; l++) {
-            uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
-            float* jx = jac + so * jac_frame + L[l].jac_off;
-            VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
-                                 lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
-                                 2 * lm_frame, 2 * jac_frame, s));
+    // frame i of this chunk sits in slot i + 1; its index in its sequence is g(i) = seq + i, or i mod clip_len
+    // when the batch is a set of independent clips (every clip starts its own sequence at 0)
+    auto gidx = [&](int i) -> long long { return clip_len > 0 ? (long long)(i % clip_len) : seq + i; };
+    {
+        // runs of frames (first, count) whose odd members form a stride-2 progression
+        std::vector<std::pair<int, int>> runs;
+        if (clip_len > 0 && (clip_len & 1)) for (int c0 = 0; c0 < n; c0 += clip_len) runs.emplace_back(c0, std::min(clip_len, n - c0));
+        else runs.emplace_back(0, n);
+        bool any = false;
+        for (auto& r : runs) {
+            const int first_odd = r.first + ((gidx(r.first) & 1) ? 0 : 1);
+            const int n_odd = first_odd < r.first + r.second ? (r.first + r.second - first_odd + 1) / 2 : 0;
+            if (n_odd <= 0) continue;
+            if (!any) { t_begin(VS_STAGE_KEYFRAME); any = true; }
+            const size_t so = (size_t)(first_odd + 1);
+            for (int l = 0; l < levels; l++) {
+                uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
+                float* jx = jac + so * jac_frame + L[l].jac_off;
+                VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
+                                     lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
+                                     2 * lm_frame, 2 * jac_frame, s));
+            }
         }
-        t_end(levels);
+        if (any) t_end(levels * (int)runs.size());
     }
 
     // ---- frame pairs --------------------------------------------------------------------------
-    // pair for chunk frame i exists when g = seq + i >= 1: frames (g-1, g) = slots (i, i+1)
-    const int first_pair = seq == 0 ? 1 : 0;
-    const int n_pairs = n - first_pair;
+    // a pair exists for chunk frame i when g(i) >= 1: frames (g-1, g) = slots (i, i+1)
+    std::vector<int> pair_frame;
+    pair_frame.reserve(n);
     for (int i = 0; i < n; i++) {
         memset(&infos[i], 0, sizeof(vs_align_info));
         infos[i].levels = levels;
         out[i] = vs_transform{0, 0, 0, 0};
         status[i] = 0;
+        if (gidx(i) >= 1) pair_frame.push_back(i);
+        else infos[i].fail_reason = 1;            // alignment.cpp:231-234: first frame of a sequence
     }
-    if (first_pair == 1) infos[0].fail_reason = 1;   // alignment.cpp:231-234: very first frame
+    const int n_pairs = (int)pair_frame.size();
     if (n_pairs > 0) {
         std::vector<PairDesc> hd(n_pairs);
         for (int q = 0; q < n_pairs; q++) {
-            const int i = first_pair + q;
-            const long long g = seq + i;
+            const int i = pair_frame[q];
             const int cur = i + 1, prev = i;
-            if (g & 1) { hd[q].key_slot = cur; hd[q].tmpl_slot = prev; }
+            if (gidx(i) & 1) { hd[q].key_slot = cur; hd[q].tmpl_slot = prev; }
             else { hd[q].key_slot = prev; hd[q].tmpl_slot = cur; }
         }
         for (int q = 0; q < n_pairs; q++) {
@@ -859,14 +871,14 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipStreamSynchronize(s));
         }
         for (int q = 0; q < n_pairs; q++) {
-            const int i = first_pair + q;
+            const int i = pair_frame[q];
             const PairState& st = h_states[q];
             vs_align_info& inf = infos[i];
             inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
             for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l]; }
             if (st.status == 1) {
                 vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
-                if (((seq + i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
+                if ((gidx(i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
                 out[i] = t;
                 status[i] = 1;
             }
@@ -962,7 +974,11 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
     a->info.assign(n, vs_align_info{});
     const size_t esz = format == VS_FMT_BGR16 ? 2 : 1;
     // chunking bounds device memory: at most ~6 GiB of pyramids per handle
-    const int max_chunk = (int)std::max<size_t>(2, std::min<size_t>(1024, ((size_t)6 << 30) / std::max<size_t>(1, a->pyr_frame)));
+    int max_chunk = (int)std::max<size_t>(2, std::min<size_t>(1024, ((size_t)6 << 30) / std::max<size_t>(1, a->pyr_frame)));
+    if (a->clip_len > 0) {   // whole clips per chunk
+        if (a->clip_len > max_chunk) return set_error(VS_ERR_UNSUPPORTED, "clips of %d frames exceed the %d-frame chunk", a->clip_len, max_chunk);
+        max_chunk -= max_chunk % a->clip_len;
+    }
     int aligned = 0;
     for (int off = 0; off < n; off += max_chunk) {
         const int m = std::min(max_chunk, n - off);
@@ -972,6 +988,22 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
     }
     for (int i = 0; i < n; i++) aligned += status[i];
     return aligned;
+}
+
+// n_clips independent clips of frames_per_clip frames each, back to back in memory: the results of aligning every
+// clip with its own fresh VideoAligner, computed together (every stage is one launch over all clips, so short
+// clips still fill the GPU).  The handle's running sequence is reset before and after.
+int vs_aligner_align_clips(vs_aligner* a, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip, int w,
+                           int h, int stride, int format, int mem, const vs_aligner_params* params, vs_transform* out,
+                           int32_t* status) {
+    VS_ARG(a && n_clips >= 1 && frames_per_clip >= 1);
+    a->seq = 0;
+    a->clip_len = frames_per_clip;
+    int r = vs_aligner_align_batch(a, frames, frame_stride, n_clips * frames_per_clip, w, h, stride, format, mem, params, out,
+                                   status);
+    a->clip_len = 0;
+    a->seq = 0;
+    return r;
 }
 
 int vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
