@@ -240,8 +240,8 @@ class Smoother:
         return bool(ok), out
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vs_smoother_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.vs_smoother_destroy(self.h)
             self.h = None
 
 
@@ -534,8 +534,8 @@ class Aligner:
         return out
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vs_aligner_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.vs_aligner_destroy(self.h)
             self.h = None
 
 
@@ -589,6 +589,6 @@ class Stabilizer:
         return m, a, bool(s.value)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().vs_stabilizer_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.vs_stabilizer_destroy(self.h)
             self.h = None

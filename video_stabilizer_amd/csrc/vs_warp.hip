@@ -57,6 +57,26 @@ __device__ __forceinline__ uint32_t store_u(float v, float maxv) {
 // generators.cpp:31-47 on an {x,y} pair: identical roundings per component, packed instructions.
 // EDGE = the argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]); for taps 2
 // and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
+// Three correctly rounded quotients over one denominator.  This is hipcc's own fp32 division expansion
+// (v_div_scale, v_rcp, two Newton steps on the reciprocal-quotient pair, v_div_fmas, v_div_fixup) with the
+// parts that are no-ops here removed: den is a sum of Lanczos weights (0.99..1.05) and the numerators are
+// bounded byte sums, so no operand scaling and no special-case fix-up ever applies; what is left is the
+// same fma sequence, and the reciprocal refinement is shared by the three channels (18 instructions
+// instead of 33).  Outside the safe range it falls back to operator/.
+__device__ __forceinline__ void div3_exact(float n0, float n1, float n2, float den, float& q0, float& q1, float& q2) {
+    if (den > 0.5f && den < 2.0f) {
+        float r = __builtin_amdgcn_rcpf(den);
+        const float e = __builtin_fmaf(-den, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        float q, t;
+        q = n0 * r; t = __builtin_fmaf(-den, q, n0); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n0); q0 = __builtin_fmaf(t, r, q);
+        q = n1 * r; t = __builtin_fmaf(-den, q, n1); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n1); q1 = __builtin_fmaf(t, r, q);
+        q = n2 * r; t = __builtin_fmaf(-den, q, n2); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n2); q2 = __builtin_fmaf(t, r, q);
+    } else {
+        q0 = n0 / den; q1 = n1 / den; q2 = n2 / den;
+    }
+}
+
 // u16 pixels: a pair of lanes owns 2 pixels = 12 bytes = 3 dwords {B0|G0, R0|B1, G1|R1}
 __device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, uint32_t& d0, uint32_t& d1) {
     const uint32_t bg = o[0] | (o[1] << 16);
@@ -65,7 +85,9 @@ __device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, ui
     d1 = o[2] | (nbg << 16);                           // even lane only: R0|B1
 }
 
-template <bool EDGE>
+// EDGE_X / EDGE_Y: that component's argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]);
+// for taps 2 and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
+template <bool EDGE_X, bool EDGE_Y>
 __device__ __forceinline__ f2 lanczos2_pk(f2 x) {
     f2 x2 = x * x;
     f2 v = 0.000858519f;
@@ -75,10 +97,8 @@ __device__ __forceinline__ f2 lanczos2_pk(f2 x) {
     v = 1.52229f + v * x2;
     v = -2.05238f + v * x2;
     v = 0.999861f + v * x2;
-    if (EDGE) {
-        v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
-        v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
-    }
+    if (EDGE_X) v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
+    if (EDGE_Y) v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
     return v;
 }
 
@@ -234,25 +254,32 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
                 const int ix = (int)flx, iy = (int)fly;
                 const f2 fr = {Wx - flx, Wy - fly};
                 if (MODE == 0) {
-                    // the four live taps of the 5-tap window (tap 0 has weight exactly 0), x and y together
-                    const f2 w0 = lanczos2_pk<true>(f2{-1.0f, -1.0f} - fr), w1 = lanczos2_pk<false>(f2{0.0f, 0.0f} - fr),
-                             w2 = lanczos2_pk<false>(f2{1.0f, 1.0f} - fr), w3 = lanczos2_pk<true>(f2{2.0f, 2.0f} - fr);
-                    const float wx[4] = {w0.x, w1.x, w2.x, w3.x}, wy[4] = {w0.y, w1.y, w2.y, w3.y};
+                    // the four live taps of the 5-tap window (tap 0 has weight exactly 0): four packed Horner chains,
+                    // each holding two adjacent taps of one axis, so the tap products below are packed too
+                    const f2 frx = {fr.x, fr.x}, fry = {fr.y, fr.y};
+                    const f2 wx01 = lanczos2_pk<true, false>(f2{-1.0f, 0.0f} - frx), wx23 = lanczos2_pk<false, true>(f2{1.0f, 2.0f} - frx);
+                    const f2 wy01 = lanczos2_pk<true, false>(f2{-1.0f, 0.0f} - fry), wy23 = lanczos2_pk<false, true>(f2{1.0f, 2.0f} - fry);
+                    const float wy[4] = {wy01.x, wy01.y, wy23.x, wy23.y};
                     const f4* t = tile + (iy - 1 - sy_lo) * WS_W + (ix - 1 - sx_lo);
                     f2 nbg = {0.f, 0.f}, nrd = {0.f, 0.f};
 #pragma unroll
-                    for (int ry = 0; ry < 4; ry++)
+                    for (int ry = 0; ry < 4; ry++) {
+                        const f2 wyy = {wy[ry], wy[ry]};
+                        const f2 p01 = wx01 * wyy, p23 = wx23 * wyy;              // w2d = wx[rx] * wy[ry]
+                        const float w2d[4] = {p01.x, p01.y, p23.x, p23.y};
 #pragma unroll
                         for (int rx = 0; rx < 4; rx++) {
                             const f4 v = t[ry * WS_W + rx];
-                            const float w2d = wx[rx] * wy[ry];
-                            const f2 ww = {w2d, w2d};
+                            const f2 ww = {w2d[rx], w2d[rx]};
                             nbg = nbg + ww * f2{v.x, v.y};       // num_B, num_G
                             nrd = nrd + ww * f2{v.z, v.w};       // num_R, den (v.w == 1: den + w2d*1 == den + w2d)
                         }
-                    o[0] = store_u(nbg.x / nrd.y, maxv);
-                    o[1] = store_u(nbg.y / nrd.y, maxv);
-                    o[2] = store_u(nrd.x / nrd.y, maxv);
+                    }
+                    float qb, qg, qr;
+                    div3_exact(nbg.x, nbg.y, nrd.x, nrd.y, qb, qg, qr);
+                    o[0] = store_u(qb, maxv);
+                    o[1] = store_u(qg, maxv);
+                    o[2] = store_u(qr, maxv);
                 } else {
                     const f4* t = tile + (iy - sy_lo) * WS_W + (ix - sx_lo);
                     const f4 a0 = t[0], a1 = t[1], b0 = t[WS_W], b1 = t[WS_W + 1];
