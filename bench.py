@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--select", default="device", choices=["host", "device"])
     ap.add_argument("--no-warp", action="store_true", help="alignment only (c2/c3/c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to rehearse the N>1 flow on one GPU")
+    ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -103,12 +106,15 @@ def main():
     from video_stabilizer_amd import dist as vsdist
 
     world, rank, local_rank = vsdist.env_world()
+    if args.device >= 0:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
-        dist = vsdist.init("nccl", rank, world, device_id=dev)
+        dist = vsdist.init(args.dist_backend, rank, world, device_id=dev if args.dist_backend == "nccl" else None)
+    red_dev = dev if args.dist_backend == "nccl" else None     # where the three report scalars are reduced
 
     wl = WORKLOADS[args.workload]
     W, H, bits = wl["w"], wl["h"], wl["bits"]
@@ -181,7 +187,7 @@ def main():
         aligner.enable_timing(True)
     dt, good = timed_loop(lambda: step(True), args.steps)
     # whole-job numbers: max seconds over ranks, frames summed over ranks (the only collectives of the run)
-    dt, total_frames, total_good = vsdist.aggregate(dt, n * n_clips * args.steps, int(good) * args.steps, device=dev)
+    dt, total_frames, total_good = vsdist.aggregate(dt, n * n_clips * args.steps, int(good) * args.steps, device=red_dev)
     tm = aligner.timings() if aligner else None
 
     align_only = None
@@ -191,7 +197,7 @@ def main():
             aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt)
         aligner.enable_timing(True)
         dt_a, _ = timed_loop(fn, args.steps)
-        dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=dev)
+        dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=red_dev)
         align_only = (dt_a, frames_a, aligner.timings())
 
     if rank == 0:

@@ -236,3 +236,84 @@ def test_align_clips_equals_fresh_aligner_per_clip(gpu_vs, fpc):
     # the handle is a plain sequential aligner again afterwards
     s2, _ = al.align_batch(clips[0])
     assert s2 == list(gpu_vs.Aligner(device=0).align_batch(clips[0])[0])
+
+
+@pytest.mark.parametrize("w,h", [(321, 243), (479, 271), (150, 97)])
+def test_ragged_sizes_and_strided_input(gpu_vs, oracle, w, h):
+    # odd widths / heights (tail tiles, unaligned rows, levels with floor-ed extents) and a row stride > width
+    import ctypes as C
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 4, seed=77, channels=3)
+    gpu, cpu, res = _run_both(gpu_vs, oracle, frames)
+    _check_seq(res)
+    # same frames embedded in a wider buffer: stride = (w+5)*3 elements
+    wide = np.zeros((4, h, w + 5, 3), np.uint8)
+    wide[:, :, :w] = frames
+    al = gpu_vs.Aligner(device=0)
+    out = (gpu_vs.Transform * 4)()
+    st = (C.c_int32 * 4)()
+    r = gpu_vs.lib().vs_aligner_align_batch(al.h, wide.ctypes.data_as(C.c_void_p), h * (w + 5) * 3, 4, w, h, (w + 5) * 3, gpu_vs.FMT_BGR8,
+                                            gpu_vs.MEM_HOST, C.byref(al.params), out, st)
+    assert r >= 0
+    for i in range(4):
+        assert bool(st[i]) == res[i][0] and out[i].tup() == res[i][1].tup()
+
+
+def test_two_handles_from_two_threads(gpu_vs):
+    # distinct handles are independent (instances run concurrently, grid_search_align.cpp:174)
+    import threading
+    from video_stabilizer_amd import synth
+    clips = [synth.make_clip(320, 240, 6, seed=300 + k, channels=3)[0] for k in range(2)]
+    ref = [gpu_vs.Aligner(device=0).align_batch(c) for c in clips]
+    got = [None, None]
+
+    def work(k):
+        al = gpu_vs.Aligner(device=0)
+        r = []
+        for f in clips[k]:
+            r.append(al.align_next(f))
+        got[k] = r
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        for i in range(6):
+            assert got[k][i][0] == bool(ref[k][0][i]) and got[k][i][1].tup() == ref[k][1][i].tup()
+
+
+def test_device_and_host_memory_give_the_same_result(gpu_vs):
+    # VS_MEM_DEVICE (frames already in HBM, as bench.py feeds them) vs VS_MEM_HOST.  torch provides the device buffer;
+    # it runs in a child process that imports torch BEFORE libvs_amd (the order bench.py uses: torch ships its own
+    # HIP runtime and must be the one that initialises it).
+    import subprocess
+    import sys
+    code = """
+import sys; sys.path.insert(0, %r)
+import torch
+from video_stabilizer_amd import capi, synth
+frames, _ = synth.make_clip(320, 240, 5, seed=88, channels=3)
+host = capi.Aligner(device=0).align_batch(frames)
+d = torch.from_numpy(frames).to("cuda:0"); torch.cuda.synchronize()
+dev = capi.Aligner(device=0).align_batch_device(d.data_ptr(), 5, 320, 240, capi.FMT_BGR8)
+assert host[0] == dev[0] and [t.tup() for t in host[1]] == [t.tup() for t in dev[1]] and sum(host[0]) == 4
+print("SAME")
+""" % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SAME" in out.stdout, out.stderr[-2000:]
+
+
+def test_params_change_per_call_like_the_reference(gpu_vs, oracle):
+    # VideoAlignerParams is an argument of every AlignNextFrame call (alignment.hpp:55-58)
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 4, seed=99)
+    g, c = gpu_vs.Aligner(device=0), oracle.Aligner()
+    for i, f in enumerate(frames):
+        for a in (g, c):
+            a.params.smallest_fraction = 0.8 if i < 2 else 0.5
+            a.params.threshold = 0.02 if i < 3 else 0.1
+        ok_g, t_g = g.align_next(f)
+        ok_c, t_c = c.align_next(f)
+        assert ok_g == ok_c
+        if ok_c:
+            assert _cmp_transform(t_g, t_c) < TOL
+            assert list(g.info(0).iterations[:5]) == list(c.debug().iterations[:5])
