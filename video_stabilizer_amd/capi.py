@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvs_amd.so")
+LIB_PATH = os.environ.get("VS_AMD_LIB", os.path.join(_HERE, "libvs_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2

@@ -146,10 +146,50 @@ __device__ __forceinline__ void ul_params_sparse(const double T[4], int w, int h
 }
 
 // ---- wave / block reductions ---------------------------------------------------------------
+// Cross-lane data movement uses DPP (row_shr / row_bcast: one VALU move each) instead of __shfl
+// (ds_bpermute through the LDS crossbar, ~100 cycles of latency per step): a 64-lane inclusive scan is
+// six dependent move+op pairs.  Lanes with no source lane receive 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov0(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, true);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov0(double v) {
+    const int lo = dpp_mov0<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_mov0<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// Kogge-Stone inside each row of 16 (row_shr 1,2,4,8), then row_bcast15 into rows 1,3 and row_bcast31 into rows 2,3
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += dpp_mov0<0x111>(v);
+    v += dpp_mov0<0x112>(v);
+    v += dpp_mov0<0x114>(v);
+    v += dpp_mov0<0x118>(v);
+    v += dpp_mov0<0x142, 0xa>(v);
+    v += dpp_mov0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_total(int incl_scan) { return __builtin_amdgcn_readlane(incl_scan, 63); }
+// sum over the wave; the result is valid in every lane (read back from lane 63 of the scan)
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-    return v;   // valid in lane 0
+    v += dpp_mov0<0x111>(v);
+    v += dpp_mov0<0x112>(v);
+    v += dpp_mov0<0x114>(v);
+    v += dpp_mov0<0x118>(v);
+    v += dpp_mov0<0x142, 0xa>(v);
+    v += dpp_mov0<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// min over the wave of non-negative ints (lanes without a source contribute INT_MAX)
+__device__ __forceinline__ int wave_min_nonneg(int v) {
+    // work on the complement so that the DPP fill value 0 is the identity of max
+    int c = 0x7fffffff - v;
+    c = max(c, dpp_mov0<0x111>(c));
+    c = max(c, dpp_mov0<0x112>(c));
+    c = max(c, dpp_mov0<0x114>(c));
+    c = max(c, dpp_mov0<0x118>(c));
+    c = max(c, dpp_mov0<0x142, 0xa>(c));
+    c = max(c, dpp_mov0<0x143, 0xc>(c));
+    return 0x7fffffff - __builtin_amdgcn_readlane(c, 63);
 }
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll

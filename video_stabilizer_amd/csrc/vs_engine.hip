@@ -309,14 +309,90 @@ struct SelShared {
     int red_k[kGnThreads / 64], red_c[kGnThreads / 64];
 };
 
-__device__ __forceinline__ int wave_incl_scan(int v) {
+// One wave finishes the job once the active range fits 64 lanes x 32 elements: the same partition rounds,
+// but every exchange is a wave shuffle and LDS accesses of a single wave execute in program order, so a round
+// costs no block barrier (most rounds of an introselect run are on small ranges: the block-wide rounds take
+// ~1.7 us each, these ~0.3 us).  Called by wave 0 only, with all 64 lanes.
+__device__ __forceinline__ void median_to_first(uint32_t* __restrict__ a, int first, int last) {
+    // __unguarded_partition_pivot: __move_median_to_first(first, first+1, mid, last-1)
+    const int mid = first + (last - first) / 2;
+    const int ia = first + 1, ib = mid, ic = last - 1;
+    const uint32_t A = a[ia] >> 16, B = a[ib] >> 16, C = a[ic] >> 16;
+    int m;
+    if (A < B) m = (B < C) ? ib : ((A < C) ? ic : ia);
+    else if (A < C) m = ia;
+    else if (B < C) m = ic;
+    else m = ib;
+    const uint32_t t = a[first]; a[first] = a[m]; a[m] = t;
+}
+
+__device__ __noinline__ int introselect_wave(uint32_t* __restrict__ a, uint16_t* __restrict__ posR, int first, int last,
+                                             int nth, int depth) {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
+    while (last - first > 3) {
+        if (depth == 0) return 1;
+        --depth;
+        if (lane == 0) median_to_first(a, first, last);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t pv = a[first] >> 16;
+        const int f0 = first + 1, m = last - f0;
+        const int chunk = (m + 63) >> 6;                  // <= 32
+        const int lo = min(f0 + lane * chunk, last), hi = min(lo + chunk, last);
+        uint32_t maskL = 0, maskR = 0;
+        for (int i = lo; i < hi; i++) {
+            const uint32_t k = a[i] >> 16;
+            maskL |= (uint32_t)(k >= pv) << (i - lo);
+            maskR |= (uint32_t)(k <= pv) << (i - lo);
+        }
+        const int cl = __popc(maskL), cr = __popc(maskR);
+        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
+        const int nR = wave_total(ir);
+        {
+            int rk = nR - ir;
+            uint32_t mr = maskR;
+            while (mr) {
+                const int e = 31 - __clz(mr);
+                mr &= ~(1u << e);
+                posR[rk++] = (uint16_t)(lo + e);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int swaps = 0, cand = 0x7fffffff;
+        {
+            int k = il - cl;
+            uint32_t ml = maskL;
+            while (ml) {
+                const int e = __ffs(ml) - 1;
+                ml &= ml - 1;
+                const int i = lo + e;
+                const int j = k < nR ? (int)posR[k] : -1;
+                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
+                else if (cand == 0x7fffffff) cand = i;
+                k++;
+            }
+        }
+        swaps = wave_total(wave_incl_scan(swaps));
+        cand = wave_min_nonneg(cand);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int RK = swaps > 0 ? (int)posR[swaps - 1] : last;
+        const int cut = (cand != 0x7fffffff && cand < RK) ? cand : RK;
+        if (cut <= nth) first = cut; else last = cut;
     }
-    return v;
+    // __insertion_sort(first, last) on <= 3 elements
+    if (lane == 0) {
+        for (int i = first + 1; i < last; i++) {
+            const uint32_t v = a[i];
+            if ((v >> 16) < (a[first] >> 16)) {
+                for (int j = i; j > first; j--) a[j] = a[j - 1];
+                a[first] = v;
+            } else {
+                int j = i;
+                while ((v >> 16) < (a[j - 1] >> 16)) { a[j] = a[j - 1]; j--; }
+                a[j] = v;
+            }
+        }
+    }
+    return 0;
 }
 
 // returns 0 on success, 1 when libstdc++ would have fallen back to heap-select (depth limit): the
@@ -327,26 +403,32 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
     int first = 0, last = n;
     int depth = 2 * (31 - __clz(n));                  // std::__lg(n) * 2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    while (last - first > 3) {
-        if (depth == 0) return 1;
+#ifndef VS_SEL_WAVE_RANGE
+#define VS_SEL_WAVE_RANGE 256
+#endif
+#ifndef VS_SEL_THREADS
+#define VS_SEL_THREADS 256
+#endif
+    constexpr int kWaveRange = VS_SEL_WAVE_RANGE;
+    constexpr int kSelThreadsSmall = VS_SEL_THREADS;   // threads that own elements in the block-wide rounds ...
+    bool fail = false;
+    // block-wide rounds while the range is large.  Round structure: [median swap by thread 0] barrier
+    // [classify + count] barrier [rank table] barrier [swaps + reduce] barrier; the next round's median swap
+    // rides in front of the following barrier.
+    bool median_done = false;
+    while (last - first > 3 && last - first - 1 > kWaveRange) {
+        if (depth == 0) { fail = true; break; }
         --depth;
-        // __unguarded_partition_pivot: __move_median_to_first(first, first+1, mid, last-1)
-        if (tid == 0) {
-            const int mid = first + (last - first) / 2;
-            const int ia = first + 1, ib = mid, ic = last - 1;
-            const uint32_t A = a[ia] >> 16, B = a[ib] >> 16, C = a[ic] >> 16;
-            int m;
-            if (A < B) m = (B < C) ? ib : ((A < C) ? ic : ia);
-            else if (A < C) m = ia;
-            else if (B < C) m = ic;
-            else m = ib;
-            const uint32_t t = a[first]; a[first] = a[m]; a[m] = t;
+        if (!median_done) {
+            if (tid == 0) median_to_first(a, first, last);
+            __syncthreads();
         }
-        __syncthreads();
         const uint32_t pv = a[first] >> 16;
         const int f0 = first + 1, m = last - f0;
-        const int chunk = (m + kGnThreads - 1) / kGnThreads;   // <= 32: the caller caps n at 32*kGnThreads
-        const int lo = min(f0 + tid * chunk, last), hi = min(lo + chunk, last);
+        // ... unless a 32-element chunk per thread would not cover the range (a chunk must fit the 32-bit masks)
+        const int kSelThreads = m > 32 * kSelThreadsSmall ? kGnThreads : kSelThreadsSmall;
+        const int chunk = (m + kSelThreads - 1) / kSelThreads;   // <= 32: the caller caps n at 32*kGnThreads
+        const int lo = min(f0 + min(tid, kSelThreads) * chunk, last), hi = tid < kSelThreads ? min(lo + chunk, last) : lo;
         // classify my chunk once, from the unmodified values: bit e of maskL / maskR = element lo+e stops the
         // left / right scan.  Later passes use only the masks, so swaps by other threads cannot disturb them.
         uint32_t maskL = 0, maskR = 0;
@@ -360,7 +442,7 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
         if (lane == 63) { ss.wl[wave] = il; ss.wr[wave] = ir; }
         __syncthreads();
         int pre_l = il - cl, pre_r_incl = ir, nR = 0;
-        for (int wv = 0; wv < kGnThreads / 64; wv++) {
+        for (int wv = 0; wv < kSelThreads / 64; wv++) {
             const int a_l = ss.wl[wv], a_r = ss.wr[wv];
             if (wv < wave) { pre_l += a_l; pre_r_incl += a_r; }
             nR += a_r;
@@ -393,36 +475,30 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
             }
         }
         // K = total swaps; cand = position of the first left stopper that did not swap
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            swaps += __shfl_down(swaps, off, 64);
-            cand = min(cand, __shfl_down(cand, off, 64));
-        }
+        swaps = wave_total(wave_incl_scan(swaps));
+        cand = wave_min_nonneg(cand);
         if (lane == 0) { ss.red_k[wave] = swaps; ss.red_c[wave] = cand; }
         __syncthreads();
         int K = 0, c = 0x7fffffff;
-        for (int wv = 0; wv < kGnThreads / 64; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
+        for (int wv = 0; wv < kSelThreads / 64; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
         const int RK = K > 0 ? (int)posR[K - 1] : last;
         const int cut = (c != 0x7fffffff && c < RK) ? c : RK;
         if (cut <= nth) first = cut; else last = cut;
-        __syncthreads();   // posR / ss are rewritten by the next round
-    }
-    // __insertion_sort(first, last) on <= 3 elements
-    if (tid == 0) {
-        for (int i = first + 1; i < last; i++) {
-            const uint32_t v = a[i];
-            if ((v >> 16) < (a[first] >> 16)) {
-                for (int j = i; j > first; j--) a[j] = a[j - 1];
-                a[first] = v;
-            } else {
-                int j = i;
-                while ((v >> 16) < (a[j - 1] >> 16)) { a[j] = a[j - 1]; j--; }
-                a[j] = v;
-            }
+        // every swap of this round is complete (barrier above): thread 0 may already place the next round's
+        // pivot; the barrier that closes this round (posR / ss are rewritten next) then also publishes it
+        median_done = false;
+        if (last - first > 3 && last - first - 1 > kWaveRange && depth > 0) {
+            if (tid == 0) median_to_first(a, first, last);
+            median_done = true;
         }
+        __syncthreads();
+    }
+    // the rest (including the final insertion sort) on one wave
+    if (!fail && wave == 0) {
+        if (introselect_wave(a, posR, first, last, nth, depth)) ss.red_k[0] = -1; else ss.red_k[0] = 0;
     }
     __syncthreads();
-    return 0;
+    return fail || ss.red_k[0] < 0 ? 1 : 0;
 }
 
 // Kernel-level selection op (one block per array): out_idx[0..nsel) = tile indices in the order
