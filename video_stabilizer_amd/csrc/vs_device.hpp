@@ -229,6 +229,17 @@ __device__ __forceinline__ void block_sum(double v[K], double* lds) {
     }
 }
 
+// first half of block_sum only: per-wave sums parked in LDS (lds[wave*K + k]); the caller puts a barrier behind it
+template <int K>
+__device__ __forceinline__ void wave_partials(const double v[K], double* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) lds[wave * K + k] = s;
+    }
+}
+
 // ---- 4x4 symmetric eigen-solver + conditioned pseudo-inverse --------------------------------
 // alignment.cpp:555-583 uses cv::SVD and Mat::inv(DECOMP_SVD) on the symmetric PSD Hessian.
 // Singular values of such a matrix are its eigenvalues; a cyclic Jacobi sweep (fixed order
@@ -247,16 +258,19 @@ __device__ __noinline__ void jacobi_eig4(const double* Hin, double* eval, double
 #pragma unroll
             for (int j = i + 1; j < 4; j++) off += a[i][j] * a[i][j];
         }
-        if (off <= 1e-300 || off <= 1e-34 * diag) break;
+        if (off <= 1e-300 || off <= 1e-32 * diag) break;   // off-diagonal mass below 1e-16 of the diagonal's
 #pragma unroll
         for (int p = 0; p < 3; p++) {
 #pragma unroll
             for (int q = p + 1; q < 4; q++) {
                 double apq = a[p][q];
                 if (apq == 0.0) continue;
-                double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-                double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                // t = tan of the rotation angle = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq-app)/(2 apq),
+                // written with d = aqq - app so that it costs one sqrt and one divide; c = 1/sqrt(t^2+1) by rsqrt
+                const double d = a[q][q] - a[p][p];
+                const double r = sqrt(d * d + 4.0 * apq * apq);
+                const double tt = (d >= 0.0 ? 2.0 * apq : -2.0 * apq) / (fabs(d) + r);
+                const double c = rsqrt(tt * tt + 1.0), s = tt * c;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     double akp = a[k][p], akq = a[k][q];
@@ -344,14 +358,16 @@ __device__ __forceinline__ void warp_corners(const double t[4], int w, int h, do
     warp_center(t, 0.0, y1, cx, cy, c[4], c[5]);
     warp_center(t, x1, y1, cx, cy, c[6], c[7]);
 }
+// max over the four corners of Point::distance (alignment.cpp:647-649).  sqrt is correctly rounded, hence monotone:
+// max_k sqrt(d_k) == sqrt(max_k d_k) bit for bit, so one square root instead of four.
 __device__ __forceinline__ double corner_move(const double a[8], const double b[8]) {
     double m = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         double dx = a[2 * k] - b[2 * k], dy = a[2 * k + 1] - b[2 * k + 1];
-        m = fmax(m, sqrt(dx * dx + dy * dy));
+        m = fmax(m, dx * dx + dy * dy);
     }
-    return m;
+    return sqrt(m);
 }
 
 }  // namespace vsd

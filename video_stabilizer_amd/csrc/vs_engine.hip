@@ -55,6 +55,9 @@ struct PairState {
     int32_t pad;
     int32_t iterations[kMaxLevels];
     double condition[kMaxLevels];
+#ifdef VS_PROFILE_STAMPS
+    unsigned long long stamps[kMaxLevels][6];   // diagnostic build only: shader-clock ticks per phase of a level
+#endif
 };
 
 struct PairDesc {
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
 struct GnShared {
     double red[2][(kGnThreads / 64) * 10];
     double hinv[17];
-    double c0[8];   // corners at level start (block-uniform; parked here instead of 16 VGPRs)
+    double c0[8];   // corners at level start
+    double T[4];    // the transform after the current iteration, published by wave 0
+    int flag;       // 0 iterate on / 1 converged / 2 out of iterations / 3 over max_displacement
 };
 
 __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ key, int w, int h, int nsel,
@@ -194,16 +199,19 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
         }
         __syncthreads();
     }
-    // Hinv is block-uniform: it stays in LDS, not in 32 VGPRs
+    // The scalar part of an iteration (dt = Hinv b, compose, corner test: ~300 dependent fp64 instructions) runs on
+    // wave 0 only and is published through LDS; the other 15 waves only sample.  Two barriers per iteration.
+    const bool w0 = threadIdx.x < 64;
     double c1[8];
-    warp_corners(T, w, h, c1);
-    if (threadIdx.x == 0) {
+    if (w0) {
+        warp_corners(T, w, h, c1);
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) sh.c0[i] = c1[i];   // read back after the loop (>= 1 barrier in between)
+            for (int i = 0; i < 8; i++) sh.c0[i] = c1[i];
+        }
     }
-
     const double scale = 1.0 / w;   // alignment.cpp:629
-    int iters = 0, fail = 0;
+    int iters = 0, flag = 0;
     for (int iter = 0; iter < gp.max_iters; iter++) {
         iters++;
         float P[4];
@@ -226,42 +234,56 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
                 a[3] += (double)(jf.w * residual);
             }
         }
-        block_sum<8>(acc, sh.red[(iter & 1) ^ 1]);
-        double b[4];
+        wave_partials<8>(acc, sh.red[0]);
+        __syncthreads();
+        if (w0) {
+            double b[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) b[c] = (acc[c] + acc[4 + c]) * 0.5f;   // generators.cpp:595
-        double dt[4];
+            for (int c = 0; c < 4; c++) {
+                double sx = 0.0, sy = 0.0;
+                for (int wv = 0; wv < kGnThreads / 64; wv++) { sx += sh.red[0][wv * 8 + c]; sy += sh.red[0][wv * 8 + 4 + c]; }
+                b[c] = (sx + sy) * 0.5f;   // generators.cpp:595
+            }
+            double dt[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            double s = 0.0;
+            for (int r = 0; r < 4; r++) {
+                double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) s += sh.hinv[r * 4 + k] * b[k];
-            dt[r] = s;
+                for (int k = 0; k < 4; k++) s += sh.hinv[r * 4 + k] * b[k];
+                dt[r] = s;
+            }
+            double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
+            double Tn[4];
+            compose(delta, T, Tn);   // alignment.cpp:639
+            double c2[8];
+            warp_corners(Tn, w, h, c2);
+            const double disp12 = corner_move(c2, c1);
+#pragma unroll
+            for (int i = 0; i < 8; i++) c1[i] = c2[i];
+            int f = 0;
+            if (disp12 < gp.threshold) f = 1;
+            else if (iter >= gp.max_iters - 1) f = 2;
+            if (f == 1) {   // alignment.cpp:670-677: total corner move of the level
+                double c0[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) c0[i] = sh.c0[i];
+                if (corner_move(c0, c1) > gp.max_displacement) f = 3;
+            }
+            if (threadIdx.x == 0) {
+                sh.T[0] = Tn[0]; sh.T[1] = Tn[1]; sh.T[2] = Tn[2]; sh.T[3] = Tn[3];
+                sh.flag = f;
+            }
         }
-        double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
-        double Tn[4];
-        compose(delta, T, Tn);   // alignment.cpp:639
-#pragma unroll
-        for (int i = 0; i < 4; i++) T[i] = Tn[i];
-        double c2[8];
-        warp_corners(T, w, h, c2);
-        double disp12 = corner_move(c2, c1);
-#pragma unroll
-        for (int i = 0; i < 8; i++) c1[i] = c2[i];
-        if (disp12 < gp.threshold) break;
-        if (iter >= gp.max_iters - 1) { fail = 2; break; }
+        __syncthreads();
+        T[0] = sh.T[0]; T[1] = sh.T[1]; T[2] = sh.T[2]; T[3] = sh.T[3];
+        flag = sh.flag;
+        if (flag) break;
     }
-    if (!fail) {
-        double c0[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) c0[i] = sh.c0[i];
-        double disp01 = corner_move(c0, c1);
-        if (disp01 > gp.max_displacement) fail = 3;
-    }
+    const int fail = flag == 1 ? 0 : flag;
     if (!fail && level > 0) { T[2] *= 2.0; T[3] *= 2.0; }   // alignment.cpp:683-687
     *iters_out = iters;
     *cond_out = sh.hinv[16];
-    // sh.hinv / sh.red are rewritten by the next level only after its own barriers
+    __syncthreads();   // sh.T / sh.flag / sh.red are rewritten by the next level
     return fail;
 }
 
@@ -304,6 +326,14 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
 // prefix counts, so one partition is a few block-wide scans.  tests/test_select_gpu.py checks the
 // permutation against the host's std::nth_element on tie-heavy inputs.
 // Elements are packed (abs_delta << 16) | tile_index; only abs_delta takes part in comparisons.
+// selection tuning (tools/select_bench.py): ranges up to VS_SEL_WAVE_RANGE elements are finished by one wave; the
+// block-wide rounds give elements to VS_SEL_THREADS threads (more only when a 32-element chunk would not cover the range)
+#ifndef VS_SEL_WAVE_RANGE
+#define VS_SEL_WAVE_RANGE 256
+#endif
+#ifndef VS_SEL_THREADS
+#define VS_SEL_THREADS 256
+#endif
 struct SelShared {
     int wl[kGnThreads / 64], wr[kGnThreads / 64];   // per-wave stopper counts
     int red_k[kGnThreads / 64], red_c[kGnThreads / 64];
@@ -403,12 +433,6 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
     int first = 0, last = n;
     int depth = 2 * (31 - __clz(n));                  // std::__lg(n) * 2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifndef VS_SEL_WAVE_RANGE
-#define VS_SEL_WAVE_RANGE 256
-#endif
-#ifndef VS_SEL_THREADS
-#define VS_SEL_THREADS 256
-#endif
     constexpr int kWaveRange = VS_SEL_WAVE_RANGE;
     constexpr int kSelThreadsSmall = VS_SEL_THREADS;   // threads that own elements in the block-wide rounds ...
     bool fail = false;
@@ -501,6 +525,100 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
     return fail || ss.red_k[0] < 0 ? 1 : 0;
 }
 
+// Both point sets of a level at once: threads 0..511 select the x-set, threads 512..1023 the y-set, each half
+// running the rounds of introselect_block on its own arrays.  The block barriers are shared, so the halves advance
+// in lock step and a half that has finished its block-wide rounds idles through the other's; the wave-level tails
+// then run side by side on wave 0 and wave 8.  Wall time = max instead of sum of the two selections.
+__device__ __noinline__ int introselect_dual(uint32_t* __restrict__ aX, uint16_t* __restrict__ pRX, uint32_t* __restrict__ aY,
+                                             uint16_t* __restrict__ pRY, SelShared* ss2, int n, int nth) {
+    if (n == 0 || nth == n) return 0;                 // std::nth_element's early return (same n, nth for both sets)
+    const int tid = threadIdx.x, half = tid >> 9, gt = tid & 511, lane = tid & 63, gw = gt >> 6;
+    uint32_t* __restrict__ a = half ? aY : aX;
+    uint16_t* __restrict__ posR = half ? pRY : pRX;
+    SelShared& ss = ss2[half];
+    constexpr int kWaveRange = VS_SEL_WAVE_RANGE, kSmall = VS_SEL_THREADS, kHalf = kGnThreads / 2, kHalfWaves = kHalf / 64;
+    int first = 0, last = n;
+    int depth = 2 * (31 - __clz(n));
+    bool fail = false;
+    // does my half need another block-wide round?  if so take its depth token and place its pivot
+    auto begin_round = [&]() -> bool {
+        if (fail || !(last - first > 3 && last - first - 1 > kWaveRange)) return false;
+        if (depth == 0) { fail = true; return false; }
+        --depth;
+        if (gt == 0) median_to_first(a, first, last);
+        return true;
+    };
+    bool need = begin_round();
+    while (__syncthreads_or(need)) {                 // also publishes the pivot swaps
+        uint32_t maskL = 0, maskR = 0, pv = 0;
+        int lo = 0, f0 = first + 1;
+        if (need) {
+            pv = a[first] >> 16;
+            const int m = last - f0;
+            const int nthr = m > 32 * kSmall ? kHalf : kSmall;      // a chunk must fit the 32-bit masks
+            const int chunk = (m + nthr - 1) / nthr;
+            lo = min(f0 + min(gt, nthr) * chunk, last);
+            const int hi = gt < nthr ? min(lo + chunk, last) : lo;
+            for (int i = lo; i < hi; i++) {
+                const uint32_t k = a[i] >> 16;
+                maskL |= (uint32_t)(k >= pv) << (i - lo);
+                maskR |= (uint32_t)(k <= pv) << (i - lo);
+            }
+        }
+        const int cl = __popc(maskL), cr = __popc(maskR);
+        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
+        if (lane == 63) { ss.wl[gw] = il; ss.wr[gw] = ir; }
+        __syncthreads();
+        int pre_l = il - cl, pre_r_incl = ir, nR = 0;
+        for (int wv = 0; wv < kHalfWaves; wv++) {
+            const int a_l = ss.wl[wv], a_r = ss.wr[wv];
+            if (wv < gw) { pre_l += a_l; pre_r_incl += a_r; }
+            nR += a_r;
+        }
+        {
+            int rk = nR - pre_r_incl;
+            uint32_t mr = maskR;
+            while (mr) {
+                const int e = 31 - __clz(mr);
+                mr &= ~(1u << e);
+                posR[rk++] = (uint16_t)(lo + e);
+            }
+        }
+        __syncthreads();
+        int swaps = 0, cand = 0x7fffffff;
+        {
+            int k = pre_l;
+            uint32_t ml = maskL;
+            while (ml) {
+                const int e = __ffs(ml) - 1;
+                ml &= ml - 1;
+                const int i = lo + e;
+                const int j = k < nR ? (int)posR[k] : -1;
+                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
+                else if (cand == 0x7fffffff) cand = i;
+                k++;
+            }
+        }
+        swaps = wave_total(wave_incl_scan(swaps));
+        cand = wave_min_nonneg(cand);
+        if (lane == 0) { ss.red_k[gw] = swaps; ss.red_c[gw] = cand; }
+        __syncthreads();
+        if (need) {
+            int K = 0, c = 0x7fffffff;
+            for (int wv = 0; wv < kHalfWaves; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
+            const int RK = K > 0 ? (int)posR[K - 1] : last;
+            const int cut = (c != 0x7fffffff && c < RK) ? c : RK;
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        need = begin_round();     // all swaps of this round completed before the barrier above
+    }
+    int r = 0;
+    if (!fail && gw == 0) r = introselect_wave(a, posR, first, last, nth, depth);
+    if (gt == 0) ss.red_k[0] = (fail || r) ? -1 : 0;
+    __syncthreads();
+    return (ss2[0].red_k[0] < 0 || ss2[1].red_k[0] < 0) ? 1 : 0;
+}
+
 // Kernel-level selection op (one block per array): out_idx[0..nsel) = tile indices in the order
 // std::nth_element leaves them.  status[b] = 1 when the depth limit was hit.
 __global__ __launch_bounds__(kGnThreads) void vs_k_select(const uint16_t* __restrict__ wd, int nt, int nsel,
@@ -531,9 +649,9 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
                                                                const uint16_t* __restrict__ lm_tab, size_t lm_frame,
                                                                const float* __restrict__ jac_tab, size_t jac_frame,
                                                                uint8_t* __restrict__ recs, size_t recs_pair,
-                                                               int nt_cap, FusedLevels fl, GnParams gp) {
+                                                               int nt_cap, int dyn_bytes, FusedLevels fl, GnParams gp) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    __shared__ SelShared ss;
+    __shared__ SelShared ss2[2];
     __shared__ GnShared sh;
     uint32_t* a = (uint32_t*)dyn;
     uint16_t* posR = (uint16_t*)(a + nt_cap);
@@ -550,31 +668,67 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
         float P[4];
         ul_params_sparse(T, w, h, P);
         const float A1 = 1.0f + P[0];
-        for (int set = 0; set < 2 && !fail; set++) {
-            const uint16_t* lm = lm_tab + (size_t)d.key_slot * lm_frame + fl.lm_off[l] + (size_t)set * 2 * nt;
-            const float* jac = jac_tab + (size_t)d.key_slot * jac_frame + fl.jac_off[l] + (size_t)set * 4 * nt;
-            // sparse_warpdiff (generators.cpp:646-700) straight into the selection array, row-major tile order
-            for (int i = threadIdx.x; i < nt; i += kGnThreads) {
-                int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
-                float ox = (float)tile_x, oy = (float)tile_y;
-                float Wx = A1 * ox - P[1] * oy + P[2];
-                float Wy = P[1] * ox + A1 * oy + P[3];
-                float v = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
-                float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
-                diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
-                a[i] = ((uint32_t)(uint16_t)diff << 16) | (uint32_t)i;
+#ifdef VS_PROFILE_STAMPS
+        unsigned long long tk[6];
+        tk[0] = __builtin_amdgcn_s_memtime();
+#define VS_STAMP(k) tk[k] = __builtin_amdgcn_s_memtime()
+#else
+#define VS_STAMP(k)
+#endif
+        const uint16_t* lm0 = lm_tab + (size_t)d.key_slot * lm_frame + fl.lm_off[l];
+        const float* jac0 = jac_tab + (size_t)d.key_slot * jac_frame + fl.jac_off[l];
+        // sparse_warpdiff (generators.cpp:646-700) of tile keypoint i of a set, packed for the selection
+        auto warpdiff_packed = [&](const uint16_t* __restrict__ lm, int i) -> uint32_t {
+            int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
+            float ox = (float)tile_x, oy = (float)tile_y;
+            float Wx = A1 * ox - P[1] * oy + P[2];
+            float Wy = P[1] * ox + A1 * oy + P[3];
+            float v = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
+            float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
+            diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
+            return ((uint32_t)(uint16_t)diff << 16) | (uint32_t)i;
+        };
+        if (12 * nt <= dyn_bytes && nt <= 32 * (kGnThreads / 2)) {
+            // both sets side by side: aX | aY | posRX | posRY inside the same dynamic LDS block
+            uint32_t* aX = a;
+            uint32_t* aY = a + nt;
+            uint16_t* pRX = (uint16_t*)(a + 2 * nt);
+            uint16_t* pRY = pRX + nt;
+            for (int i = threadIdx.x; i < 2 * nt; i += kGnThreads) {
+                const int set = i >= nt, t = i - set * nt;
+                (set ? aY : aX)[t] = warpdiff_packed(lm0 + (size_t)set * 2 * nt, t);
             }
             __syncthreads();
-            if (introselect_block(a, posR, ss, nt, nsel)) { fail = 100; fail_level = l; }
+            VS_STAMP(1);
+            if (introselect_dual(aX, pRX, aY, pRY, ss2, nt, nsel)) { fail = 100; fail_level = l; }
+            VS_STAMP(2);
             // gather (alignment.cpp:523-546) in the order nth_element left the survivors
-            for (int j = threadIdx.x; j < nsel; j += kGnThreads)
-                write_rec(rc, set * nsel + j, lm, jac, nt, (int)(a[j] & 0xffffu), tmpl, w, h);
-            __syncthreads();   // a[] is refilled by the next set; the record stores are visible block-wide
+            for (int j = threadIdx.x; j < 2 * nsel; j += kGnThreads) {
+                const int set = j >= nsel, q = j - set * nsel;
+                write_rec(rc, j, lm0 + (size_t)set * 2 * nt, jac0 + (size_t)set * 4 * nt, nt, (int)((set ? aY : aX)[q] & 0xffffu), tmpl, w, h);
+            }
+            __syncthreads();
+        } else {
+            for (int set = 0; set < 2 && !fail; set++) {
+                const uint16_t* lm = lm0 + (size_t)set * 2 * nt;
+                const float* jac = jac0 + (size_t)set * 4 * nt;
+                for (int i = threadIdx.x; i < nt; i += kGnThreads) a[i] = warpdiff_packed(lm, i);
+                __syncthreads();
+                if (introselect_block(a, posR, ss2[0], nt, nsel)) { fail = 100; fail_level = l; }
+                for (int j = threadIdx.x; j < nsel; j += kGnThreads)
+                    write_rec(rc, set * nsel + j, lm, jac, nt, (int)(a[j] & 0xffffu), tmpl, w, h);
+                __syncthreads();   // a[] is refilled by the next set; the record stores are visible block-wide
+            }
         }
         if (fail) break;
+        VS_STAMP(3);
         int iters;
         double cond;
         const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond);
+        VS_STAMP(4);
+#ifdef VS_PROFILE_STAMPS
+        if (threadIdx.x == 0) for (int k = 0; k < 5; k++) st.stamps[l][k] = tk[k];
+#endif
         if (threadIdx.x == 0) { st.iterations[l] = iters; st.condition[l] = cond; }
         if (f) { fail = f; fail_level = l; }
         __syncthreads();
@@ -895,11 +1049,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 fl.w[l] = L[l].w; fl.h[l] = L[l].h; fl.nt[l] = L[l].nt; fl.nsel[l] = L[l].nsel;
                 fl.img_off[l] = L[l].img_off; fl.lm_off[l] = L[l].lm_off; fl.jac_off[l] = L[l].jac_off;
             }
-            const size_t dyn = (((size_t)nt_max * 6 + 15) & ~(size_t)15);
+            // selection arrays in LDS: 6 B per tile for one point set; 12 B when both sets fit, so that they are selected
+            // side by side (introselect_dual) -- always for 1080p, for every level but the finest at 4K
+            const size_t dyn = (((size_t)nt_max * ((size_t)nt_max * 12 <= 150 * 1024 ? 12 : 6) + 15) & ~(size_t)15);
             VS_HIP(hipFuncSetAttribute((const void*)vs_k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             t_begin(VS_STAGE_GN);
             hipLaunchKernelGGL(vs_k_align_pairs, dim3(n_pairs), dim3(kGnThreads), dyn, s, states, descs, pyr, pyr_frame, lm,
-                               lm_frame, jac, jac_frame, recs, recs_pair, nt_max, fl, gp);
+                               lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp);
             VS_HIP(hipGetLastError());
             t_end(1);
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -946,6 +1102,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
             VS_HIP(hipStreamSynchronize(s));
         }
+#ifdef VS_PROFILE_STAMPS
+        for (int l = levels - 1; l >= 0; l--) {
+            const unsigned long long* t = h_states[0].stamps[l];
+            fprintf(stderr, "[stamps] level %d: warpdiff %llu select %llu gather %llu gn(hessian+%d iters) %llu ticks\n", l, t[1] - t[0],
+                    t[2] - t[1], t[3] - t[2], h_states[0].iterations[l], t[4] - t[3]);
+        }
+#endif
         for (int q = 0; q < n_pairs; q++) {
             const int i = pair_frame[q];
             const PairState& st = h_states[q];
