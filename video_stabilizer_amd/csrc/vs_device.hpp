@@ -244,7 +244,9 @@ __device__ __forceinline__ void wave_partials(const double v[K], double* lds) {
 // alignment.cpp:555-583 uses cv::SVD and Mat::inv(DECOMP_SVD) on the symmetric PSD Hessian.
 // Singular values of such a matrix are its eigenvalues; a cyclic Jacobi sweep (fixed order
 // (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)) delivers them to ~1e-16 relative.
-__device__ __noinline__ void jacobi_eig4(const double* Hin, double* eval, double* V) {
+// Fully unrolled with compile-time indices so that a[][] and V[] live in registers (behind a pointer they would
+// be scratch memory: ~500 cycles per element access).
+__device__ __forceinline__ void jacobi_eig4(const double* Hin, double* eval, double* V) {
     double a[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -295,7 +297,10 @@ __device__ __noinline__ void jacobi_eig4(const double* Hin, double* eval, double
 
 // cond = smax/(smin+1e-10); cond > 1e6 => H += 1e-6*smax*I (alignment.cpp:561-572);
 // Hinv = V diag(1/w) V^T dropping w <= 2*eps*sum(w) (OpenCV's DECOMP_SVD back-substitution).
-__device__ __noinline__ double condition_and_invert(double* H, double* Hinv) {
+__device__ __noinline__ double condition_and_invert(double* Hio, double* Hinv_out) {
+    double H[16], Hinv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) H[i] = Hio[i];
     double ev[4], V[16];
     jacobi_eig4(H, ev, V);
     double max_sv = 0.0, min_sv = 1e300;
@@ -322,6 +327,8 @@ __device__ __noinline__ double condition_and_invert(double* H, double* Hinv) {
                 if (fabs(ev[k]) > thresh) s += V[r * 4 + k] * V[c * 4 + k] / ev[k];
             Hinv[r * 4 + c] = s;
         }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { Hio[i] = H[i]; Hinv_out[i] = Hinv[i]; }
     return cond;
 }
 

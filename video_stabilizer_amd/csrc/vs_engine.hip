@@ -166,7 +166,17 @@ struct GnShared {
 
 __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ key, int w, int h, int nsel,
                                         const PointRecs& rc, int level, const GnParams& gp, double T[4], int* iters_out,
-                                        double* cond_out) {
+                                        double* cond_out
+#ifdef VS_PROFILE_STAMPS
+                                        , unsigned long long* gtk
+#endif
+                                        ) {
+#ifdef VS_PROFILE_STAMPS
+    gtk[0] = __builtin_amdgcn_s_memtime();
+#define VS_GSTAMP(k) gtk[k] = __builtin_amdgcn_s_memtime()
+#else
+#define VS_GSTAMP(k)
+#endif
     const uint32_t* __restrict__ rxy = rc.xy;
     const float* __restrict__ rtv = rc.tv;
     const float4* __restrict__ rj = rc.j;
@@ -182,8 +192,16 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
 #pragma unroll
                 for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
         }
-        block_sum<10>(hacc, sh.red[0]);
-        if (threadIdx.x < 64) {   // one wave does the 4x4 eigen work; the others wait at the barrier
+        wave_partials<10>(hacc, sh.red[0]);
+        __syncthreads();
+        VS_GSTAMP(1);
+        if (threadIdx.x < 64) {   // one wave adds the per-wave partials and does the 4x4 eigen work; the others wait
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                double t = 0.0;
+                for (int wv = 0; wv < kGnThreads / 64; wv++) t += sh.red[0][wv * 10 + k];
+                hacc[k] = t;
+            }
             double H[16], Hinv[16];
             int k = 0;
 #pragma unroll
@@ -199,6 +217,7 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
         }
         __syncthreads();
     }
+    VS_GSTAMP(2);
     // The scalar part of an iteration (dt = Hinv b, compose, corner test: ~300 dependent fp64 instructions) runs on
     // wave 0 only and is published through LDS; the other 15 waves only sample.  Two barriers per iteration.
     const bool w0 = threadIdx.x < 64;
@@ -234,8 +253,10 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
                 a[3] += (double)(jf.w * residual);
             }
         }
+        if (iter == 0) VS_GSTAMP(3);
         wave_partials<8>(acc, sh.red[0]);
         __syncthreads();
+        if (iter == 0) VS_GSTAMP(4);
         if (w0) {
             double b[4];
 #pragma unroll
@@ -275,6 +296,7 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
             }
         }
         __syncthreads();
+        if (iter == 0) VS_GSTAMP(5);
         T[0] = sh.T[0]; T[1] = sh.T[1]; T[2] = sh.T[2]; T[3] = sh.T[3];
         flag = sh.flag;
         if (flag) break;
@@ -304,7 +326,12 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restric
     double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
     int iters;
     double cond;
+#ifdef VS_PROFILE_STAMPS
+    unsigned long long gtk[6];
+    const int fail = gn_level(sh, key, w, h, nsel, rc, level, gp, T, &iters, &cond, gtk);
+#else
     const int fail = gn_level(sh, key, w, h, nsel, rc, level, gp, T, &iters, &cond);
+#endif
     __syncthreads();   // every thread has read st.T before thread 0 rewrites it
     if (threadIdx.x == 0) {
         st.iterations[level] = iters;
@@ -724,7 +751,15 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
         VS_STAMP(3);
         int iters;
         double cond;
+#ifdef VS_PROFILE_STAMPS
+        unsigned long long gtk[6];
+        const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond, gtk);
+        if (threadIdx.x == 0)
+            printf("[gn stamps] level %d: hessian-sum %llu jacobi+barrier %llu sample0 %llu partials+barrier %llu update+barrier %llu\n", l,
+                   gtk[1] - gtk[0], gtk[2] - gtk[1], gtk[3] - gtk[2], gtk[4] - gtk[3], gtk[5] - gtk[4]);
+#else
         const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond);
+#endif
         VS_STAMP(4);
 #ifdef VS_PROFILE_STAMPS
         if (threadIdx.x == 0) for (int k = 0; k < 5; k++) st.stamps[l][k] = tk[k];
