@@ -154,7 +154,7 @@ def main():
 
         def step(timed):
             # all clips of the rank in one call (vs_aligner_align_clips): every stage is one launch over all clips
-            status, ts = aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt)
+            status, ts = aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
             if not args.no_warp:
                 if timed:
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,7 +194,7 @@ def main():
     if aligner and not args.no_warp:
         # second, separately reported figure: the alignment stages alone (BASELINE configs[1] read literally)
         def fn():
-            aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt)
+            aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
         aligner.enable_timing(True)
         dt_a, _ = timed_loop(fn, args.steps)
         dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=red_dev)

@@ -405,7 +405,7 @@ def bgr_image_warp_batch_device(src_ptr, n, w, h, c, bits, ts, dst_ptr, mode=WAR
     """device-resident form: dense frames, enqueue only"""
     if max_value is None:
         max_value = 255 if bits == 8 else 65535
-    arr = (Transform * n)(*ts)
+    arr = ts if isinstance(ts, C.Array) else (Transform * n)(*ts)     # a ctypes array from align_* is passed through as is
     _check(lib().vs_bgr_image_warp_batch(_p(src_ptr), h * w * c, n, w, h, w * c, c, bits, arr, mode, border, max_value,
                                          _p(dst_ptr), h * w * c, w * c, MEM_DEVICE, stream))
 
@@ -472,7 +472,7 @@ class Aligner:
                                             C.byref(self.params), out, status))
         return list(status), list(out)
 
-    def align_clips(self, frames, n_clips, mem_ptr=None, w=None, h=None, fmt=None):
+    def align_clips(self, frames, n_clips, mem_ptr=None, w=None, h=None, fmt=None, raw=False):
         """frames: numpy (n_clips*fpc, h, w[,3]) (host) -- or pass mem_ptr/w/h/fmt with frames = total frame count
         for dense device-resident clips.  returns (status list, transforms list)"""
         if mem_ptr is None:
@@ -488,6 +488,8 @@ class Aligner:
         status = (C.c_int32 * n)()
         _check(lib().vs_aligner_align_clips(self.h, ptr, h * w * ch, n_clips, n // n_clips, w, h, w * ch, fmt, mem,
                                             C.byref(self.params), out, status))
+        if raw:
+            return status, out       # ctypes arrays: no per-frame Python objects (bench.py hands `out` to the warp call)
         return list(status), list(out)
 
     def reset(self):
