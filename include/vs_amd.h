@@ -195,7 +195,9 @@ int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
 /* forget the sequence: the next frame is treated as the first frame of a new clip (device memory is kept) */
 int  vs_aligner_reset(vs_aligner* a);
 /* VideoAligner::AlignNextFrame (alignment.hpp:55-58, alignment.cpp:334-704).
- * returns 1 aligned / 0 not aligned (first frame, no convergence, over displacement) / <0 error.
+ * returns 1 aligned / 0 not aligned (first frame, no convergence, over displacement) / <0 error.  When not aligned,
+ * *out holds what the reference leaves in `transform`: identity for the first frame, else the estimate reached when the
+ * level gave up (VideoStabilizer passes it on to the smoother regardless, stabilizer.cpp:18-44).
  * `params` may change per call like the reference's third argument (NULL = the creation params). */
 int  vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
                            const vs_aligner_params* params, vs_transform* out);

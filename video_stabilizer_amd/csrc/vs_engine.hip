@@ -1150,12 +1150,15 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             vs_align_info& inf = infos[i];
             inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
             for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l]; }
+            vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
             if (st.status == 1) {
-                vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
                 if ((gidx(i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
-                out[i] = t;
                 status[i] = 1;
             }
+            // on failure the reference returns false with `transform` left at the estimate it had reached
+            // (alignment.cpp:661-667,674-677: no level rescale, no inversion) -- and VideoStabilizer feeds that value to
+            // the smoother all the same (stabilizer.cpp:18-44), so it is part of the observable behaviour
+            out[i] = t;
         }
     } else {
         VS_HIP(hipStreamSynchronize(s));

@@ -55,7 +55,8 @@ private:
         if (!h_) return false;
         vs_transform t{0, 0, 0, 0};
         const int r = vs_aligner_align_next(h_, data, w, h, stride, fmt, VS_MEM_HOST, &p, &t);
-        if (r == 1) transform = SimilarityTransform::from(t);
+        // like the reference, a failed call leaves the estimate it had reached in `transform` (identity for the first frame)
+        if (r >= 0) transform = SimilarityTransform::from(t);
         return r == 1;
     }
     vs_aligner* h_ = nullptr;
