@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to rehearse the N>1 flow on one GPU")
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +112,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
         dist = vsdist.init(args.dist_backend, rank, world, device_id=dev if args.dist_backend == "nccl" else None)
     red_dev = dev if args.dist_backend == "nccl" else None     # where the three report scalars are reduced

@@ -29,7 +29,7 @@ def aggregate(seconds, frames, aligned, device=None):
     """whole-job numbers: (max seconds over ranks, total frames, total aligned).  Works on any backend."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(seconds), int(frames), int(aligned)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     c = torch.tensor([int(frames), int(aligned)], dtype=torch.int64, device=device)
