@@ -48,10 +48,10 @@ __device__ __forceinline__ float lerpf(float a, float b, float t) { return a * (
 
 __device__ __forceinline__ float ub(uint32_t q, int k) { return (float)((q >> (8 * k)) & 0xffu); }
 
+// build rule: round half up, saturate = clamp(floor(v + 0.5), 0, maxv).  maxv is an integer, so clamping first and
+// then truncating (float -> u32 conversion truncates, = floor for non-negative values) gives the same integer.
 __device__ __forceinline__ uint32_t store_u(float v, float maxv) {
-    float r = floorf(v + 0.5f);                 // build rule: round half up, saturate
-    r = fminf(fmaxf(r, 0.0f), maxv);
-    return (uint32_t)r;
+    return (uint32_t)__builtin_amdgcn_fmed3f(v + 0.5f, 0.0f, maxv);
 }
 
 // generators.cpp:31-47 on an {x,y} pair: identical roundings per component, packed instructions.
@@ -80,7 +80,7 @@ __device__ __forceinline__ void div3_exact(float n0, float n1, float n2, float d
 // u16 pixels: a pair of lanes owns 2 pixels = 12 bytes = 3 dwords {B0|G0, R0|B1, G1|R1}
 __device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, uint32_t& d0, uint32_t& d1) {
     const uint32_t bg = o[0] | (o[1] << 16);
-    const uint32_t nbg = (uint32_t)__shfl_down((int)bg, 1, 64);
+    const uint32_t nbg = (uint32_t)dpp_mov0<0x101>((int)bg);   // row_shl:1 (only even lanes use it)
     d0 = odd ? (o[1] | (o[2] << 16)) : bg;            // odd lane: G1|R1 ; even lane: B0|G0
     d1 = o[2] | (nbg << 16);                           // even lane only: R0|B1
 }
@@ -105,7 +105,7 @@ __device__ __forceinline__ f2 lanczos2_pk(f2 x) {
 // 4 adjacent lanes hold one BGR pixel each (p = B | G<<8 | R<<16); lanes 0..2 of the quad assemble the three
 // dwords of the 12-byte group from their own pixel and their right neighbour's: bytes m..m+3 of {own, next}.
 __device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, int m) {
-    const uint32_t q = (uint32_t)__shfl_down((int)p, 1, 64);
+    const uint32_t q = (uint32_t)dpp_mov0<0x101>((int)p);   // row_shl:1 = the right neighbour's pixel (lane 3 of a quad ignores it)
     const uint32_t lo = p | (q << 24), hi = q >> 8;
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)m);
 }
@@ -186,9 +186,10 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
         if (fits) {
             // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4
             const int rows = sy_hi - sy_lo + 1;
-            const int groups = (sx_hi - sx_lo + 4) >> 2;
+            const int groups = (sx_hi - sx_lo + 4) >> 2;              // <= 20
+            const uint32_t inv_groups = 65536u / (uint32_t)groups + 1u;  // i / groups == (i * inv) >> 16 for i < 24*20
             for (int i = threadIdx.x; i < rows * groups; i += 256) {
-                const int r = i / groups, g = i - r * groups;
+                const int r = (int)(((uint32_t)i * inv_groups) >> 16), g = i - r * groups;
                 const int sy = sy_lo + r, sx = sx_lo + 4 * g;
                 f4* t = tile + r * WS_W + 4 * g;
                 const bool row_in = sy >= 0 && sy < h;
