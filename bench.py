@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to rehearse the N>1 flow on one GPU")
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
+    ap.add_argument("--default-levels", action="store_true",
+                    help="reference default pyramid_min_width/height = 20 (6 levels at 1080p, 7 at 4K) instead of 256")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     args = ap.parse_args()
 
@@ -130,7 +132,7 @@ def main():
     clips = [factory.make(n, wl["seed"] + 1000 * (rank + j * world), out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
     torch.cuda.synchronize()
 
-    params_kw = dict(pyramid_min_width=256)
+    params_kw = {} if args.default_levels else dict(pyramid_min_width=256)
     stream = torch.cuda.current_stream()
     ev = []   # (start, end) events around the warp launches of the timed steps
 
@@ -210,7 +212,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if bits == 8 else "u16", "data": "synthetic",
-            "config": {"workload": wl["name"], "frames_per_clip": n, "clips_per_gpu": n_clips, "width": W, "height": H,
+            "config": {"workload": wl["name"] if not args.default_levels else
+                       wl["name"].split(",")[0] + ", reference default pyramid (pyramid_min_width = pyramid_min_height = 20)",
+                       "frames_per_clip": n, "clips_per_gpu": n_clips, "width": W, "height": H,
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
@@ -242,7 +246,7 @@ def main():
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                                "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
-                               "note": "VALU-issue-bound, not HBM-bound: ~270 VALU instructions per output pixel in the "
+                               "note": "VALU-issue-bound, not HBM-bound: ~240 VALU instructions per output pixel in the "
                                        "reference's exact fp32 order (DESIGN.md, profiles/r01_bgr_image_warp_pmc.md); launches "
                                        "overlap the next clip's aligner kernels"}
         if not args.no_cpu_baseline and world == 1:
