@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
     ap.add_argument("--default-levels", action="store_true",
                     help="reference default pyramid_min_width/height = 20 (6 levels at 1080p, 7 at 4K) instead of 256")
+    ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     args = ap.parse_args()
 
@@ -133,6 +134,8 @@ def main():
     torch.cuda.synchronize()
 
     params_kw = {} if args.default_levels else dict(pyramid_min_width=256)
+    if args.phase_correlate:
+        params_kw["phase_correlate"] = 1
     stream = torch.cuda.current_stream()
     ev = []   # (start, end) events around the warp launches of the timed steps
 
@@ -218,6 +221,7 @@ def main():
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
+                       "phase_correlate": bool(args.phase_correlate),
                        "warp": None if (args.no_warp and not wl["stabilizer"]) else "bgr_image_warp lanczos2", "resident": "HBM"},
             ("outputs_per_step" if wl["stabilizer"] else "aligned_per_step"): total_good // args.steps,
         }

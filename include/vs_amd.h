@@ -49,7 +49,7 @@ typedef struct vs_point { double x, y; } vs_point;
 
 /* alignment.hpp:5-41 VideoAlignerParams -- same fields, same defaults */
 typedef struct vs_aligner_params {
-    int    phase_correlate;            /* must stay 0 (phase correlation: SURVEY 8f-4, not built) */
+    int    phase_correlate;            /* alignment.hpp:11: start TX,TY from cv::phaseCorrelate on pyramid level 2 */
     double phase_correlate_threshold;
     double threshold;
     float  smallest_fraction;
@@ -145,6 +145,14 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
  * heap-select fallback for array a (not replicated; callers then use the host).  Returns count. */
 int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction,
                        int32_t* out_idx, int32_t* status, int mem, void* stream);
+/* cv::phaseCorrelate(a, b, cv::noArray(), &response) as VideoAligner calls it (alignment.cpp:372-374) on the CV_32F copy
+ * of pyramid level 2 (alignment.cpp:225-229): two w x h u8 images -> result[3] = {shift.x, shift.y, response} in host
+ * memory (the call synchronises).  Images are zero-padded to vs_optimal_dft_size (cv::getOptimalDFTSize: 2^a 3^b 5^c);
+ * surface: NULL, or M*N floats (M, N = padded h, w; in `mem`) receiving the unshifted, unscaled correlation surface.
+ * OpenCV is not part of the reference tree: the transform specification is this build's (oracle/vs_phase.cpp). */
+int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int stride, int mem, void* stream, float* surface,
+                       double* result);
+int vs_optimal_dft_size(int n);
 /* int image_warp(in, A, B, TX, TY, out)                   imgproc.cpp:131, generators.cpp:126-164 */
 int vs_image_warp(const uint8_t* in, int w, int h, int stride,
                   float A, float B, float TX, float TY, float* out, int ow, int oh, int mem, void* stream);
@@ -187,6 +195,7 @@ typedef struct vs_align_info {
     int32_t levels;
     int32_t iterations[16];
     double  condition[16];
+    double  phase_dx, phase_dy, phase_response;   /* cv::phaseCorrelate result of the pair (phase_correlate only, else 0) */
 } vs_align_info;
 
 vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);
@@ -234,7 +243,8 @@ enum {
     VS_STAGE_SELECT = 4,     /* keep-best-80% incl. its copies              "NthElement_i"       */
     VS_STAGE_GATHER = 5,     /*                                             "JacobianSetup_i"    */
     VS_STAGE_GN = 6,         /* Hessian + solve + all iterations            "ICAIteration_i_iter" */
-    VS_STAGE_COUNT = 7
+    VS_STAGE_PHASE = 7,      /* level-2 spectra + cross-power/inverse/peak  "PhaseCorrelation"   */
+    VS_STAGE_COUNT = 8
 };
 typedef struct vs_stage_timings {
     double ms[VS_STAGE_COUNT];        /* accumulated milliseconds per stage */

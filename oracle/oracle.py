@@ -47,7 +47,8 @@ class AlignDebug(C.Structure):
     _fields_ = [("levels", C.c_int), ("fail_reason", C.c_int), ("fail_level", C.c_int),
                 ("iterations", C.c_int * 16), ("tile_size", C.c_int * 16),
                 ("selected_x", C.c_int * 16), ("selected_y", C.c_int * 16),
-                ("condition", C.c_double * 16), ("level_transform", Transform * 16)]
+                ("condition", C.c_double * 16), ("level_transform", Transform * 16),
+                ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
 
 
 WARP_LANCZOS2, WARP_BILINEAR = 0, 1
@@ -95,6 +96,13 @@ def lib():
         "vso_select_smallest": (i32, [vp, i32, i32, f32, vp]),
         "vso_hessian": (None, [vp, i32, vp, i32, vp]),
         "vso_condition_and_invert": (f64, [vp, vp]),
+        "vso_optimal_dft_size": (i32, [i32]),
+        "vso_fft_plan": (i32, [i32, C.POINTER(i32)]),
+        "vso_fft_c2c": (i32, [vp, i32, i32]),
+        "vso_phase_surface": (i32, [vp, vp, i32, i32, vp, C.POINTER(i32), C.POINTER(i32)]),
+        "vso_phase_peak": (None, [vp, i32, i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+        "vso_phase_correlate": (i32, [vp, vp, i32, i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+        "vso_phase_correlate_u8": (i32, [vp, vp, i32, i32, i32, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
         "vso_tvl1_smooth": (None, [vp, i32, f64, i32, vp]),
         "vso_smoother_create": (vp, [i32, i32, f64]),
         "vso_smoother_destroy": (None, [vp]),
@@ -320,6 +328,59 @@ def select_smallest(warpdiff, fraction=0.8):
     idx = np.empty(tx * ty, np.int32)
     n = lib().vso_select_smallest(_p(wd), tx, ty, fraction, _p(idx))
     return idx[:n].copy()
+
+
+def optimal_dft_size(n):
+    return lib().vso_optimal_dft_size(int(n))
+
+
+def fft_plan(n):
+    r = (C.c_int * 32)()
+    k = lib().vso_fft_plan(int(n), r)
+    return None if k < 0 else list(r[:k])
+
+
+def fft_c2c(x, inverse=False):
+    """the build's mixed-radix transform on a complex64 vector (inverse unscaled)"""
+    x = np.array(x, np.complex64, copy=True)
+    if lib().vso_fft_c2c(_p(x), x.size, 1 if inverse else 0) != 0:
+        raise ValueError("size %d has a prime factor other than 2, 3, 5" % x.size)
+    return x
+
+
+def phase_surface(a, b):
+    """unshifted, unscaled correlation surface (M, N) of two equal-size float images"""
+    a = _c(a, np.float32)
+    b = _c(b, np.float32)
+    h, w = a.shape
+    M, N = C.c_int(), C.c_int()
+    lib().vso_phase_surface(_p(a), _p(b), w, h, None, C.byref(M), C.byref(N))
+    out = np.empty((M.value, N.value), np.float32)
+    lib().vso_phase_surface(_p(a), _p(b), w, h, _p(out), C.byref(M), C.byref(N))
+    return out
+
+
+def phase_peak(surface):
+    s = _c(surface, np.float32)
+    dx, dy, r = C.c_double(), C.c_double(), C.c_double()
+    lib().vso_phase_peak(_p(s), s.shape[0], s.shape[1], C.byref(dx), C.byref(dy), C.byref(r))
+    return dx.value, dy.value, r.value
+
+
+def phase_correlate(a, b):
+    """cv::phaseCorrelate(a, b) -> (dx, dy, response); u8 or float images"""
+    dx, dy, r = C.c_double(), C.c_double(), C.c_double()
+    if np.asarray(a).dtype == np.uint8:
+        a = _c(a, np.uint8)
+        b = _c(b, np.uint8)
+        rc = lib().vso_phase_correlate_u8(_p(a), _p(b), a.shape[1], a.shape[0], a.shape[1], C.byref(dx), C.byref(dy), C.byref(r))
+    else:
+        a = _c(a, np.float32)
+        b = _c(b, np.float32)
+        rc = lib().vso_phase_correlate(_p(a), _p(b), a.shape[1], a.shape[0], C.byref(dx), C.byref(dy), C.byref(r))
+    if rc != 0:
+        raise ValueError("vso_phase_correlate failed")
+    return dx.value, dy.value, r.value
 
 
 def hessian(jacx, jacy):

@@ -545,6 +545,8 @@ struct vso_aligner {
     /* alignment.hpp:61-94 */
     int CurrFrameIndex = 0, PrevFrameIndex = 1, FramesAccumulated = 0;
     static constexpr int KeyframeIndex = 1, NonKeyframeIndex = 0;
+    static constexpr int PhaseLevel = 2;                 /* alignment.hpp:69 */
+    std::vector<float> PhaseImage[2];
     int PyramidLevels = -1;
     int LastWidth = -1, LastHeight = -1;
     struct Level {
@@ -602,7 +604,12 @@ bool vso_aligner::ComputePyramid(const void* frame, int width0, int height0, int
     for (int i = 1; i < PyramidLevels; i++)
         vso_pyr_down(L[i - 1].img[CurrFrameIndex].data(), L[i - 1].w, L[i - 1].h, L[i - 1].w,
                      L[i].img[CurrFrameIndex].data(), L[i].w, L[i].h, L[i].w);
-    /* :225-229 PhaseImage conversion is dead work unless phase_correlate; skipped */
+    /* :225-229 PhaseImage = level PhaseLevel (2) as CV_32F, made for every frame whatever phase_correlate says */
+    {
+        const Level& pl = L[PhaseLevel];
+        PhaseImage[CurrFrameIndex].resize((size_t)pl.w * pl.h);
+        for (size_t i = 0; i < PhaseImage[CurrFrameIndex].size(); i++) PhaseImage[CurrFrameIndex][i] = (float)pl.img[CurrFrameIndex][i];
+    }
     if (FramesAccumulated >= 2) return true;
     return ++FramesAccumulated >= 2;
 }
@@ -632,6 +639,23 @@ int vso_aligner::Align(const void* frame, int w, int h, int stride, int format, 
     dbg.levels = PyramidLevels;
     if (CurrFrameIndex == KeyframeIndex) {
         if (!ComputeKeyFrame()) { LastWidth = -1; return 0; }
+    }
+    /* :369-388 */
+    if (params.phase_correlate) {
+        const Level& pl = L[PhaseLevel];
+        const std::vector<float>& prev = PhaseImage[PrevFrameIndex];
+        const std::vector<float>& curr = PhaseImage[CurrFrameIndex];
+        {
+            double sx = 0.0, sy = 0.0, response = 0.0;
+            vso_phase_correlate(prev.data(), curr.data(), pl.w, pl.h, &sx, &sy, &response);
+            dbg.phase_dx = sx; dbg.phase_dy = sy; dbg.phase_response = response;
+            if (response > params.phase_correlate_threshold) {
+                const float phase_layer_scale = (1 << PhaseLevel) / float(1 << PyramidLevels);
+                transform.TX = sx * phase_layer_scale;
+                transform.TY = sy * phase_layer_scale;
+                if (CurrFrameIndex == KeyframeIndex) { transform.TX = -transform.TX; transform.TY = -transform.TY; }
+            }
+        }
     }
     for (int i = PyramidLevels - 1; i >= 0; i--) {
         Level& l = L[i];
@@ -715,7 +739,6 @@ int vso_aligner_align_next(vso_aligner* a, const void* frame, int w, int h, int 
     if (!a || !frame || !out || w < 8 || h < 8) return -1;
     vso_aligner_params p;
     if (params) p = *params; else vso_aligner_params_default(&p);
-    if (p.phase_correlate) return -2;
     /* PhaseLevel = 2 is indexed unconditionally (alignment.cpp:227): >=3 levels required */
     { int lv = 0, ww = w, hh = h; do { lv++; ww /= 2; hh /= 2; } while (ww >= p.pyramid_min_width && hh >= p.pyramid_min_height); if (lv < 3 || lv > 16) return -3; }
     return a->Align(frame, w, h, stride, format, p, *out);

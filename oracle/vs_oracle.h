@@ -32,7 +32,7 @@ typedef struct vso_point { double x, y; } vso_point;
 
 /* alignment.hpp:5-41 (same field order, same defaults via vso_aligner_params_default) */
 typedef struct vso_aligner_params {
-    int    phase_correlate;            /* must be 0: phase correlation is out of scope */
+    int    phase_correlate;            /* alignment.hpp:11: initialise TX,TY from cv::phaseCorrelate (vs_phase.cpp) */
     double phase_correlate_threshold;
     double threshold;
     float  smallest_fraction;
@@ -123,6 +123,15 @@ void vso_hessian(const float* jacx, int nx, const float* jacy, int ny, double H[
  * eigen-solver (H is symmetric PSD).  Returns the condition number. */
 double vso_condition_and_invert(double H[16], double Hinv[16]);
 
+/* ---- phase correlation (vs_phase.cpp; cv::phaseCorrelate as called at alignment.cpp:374) -- */
+int  vso_optimal_dft_size(int n);                       /* cv::getOptimalDFTSize */
+int  vso_fft_plan(int n, int* radix /* [32] */);        /* the build's radix plan; passes or -1 */
+int  vso_fft_c2c(float* interleaved, int n, int inverse);
+int  vso_phase_surface(const float* a, const float* b, int w, int h, float* surface, int* M, int* N);
+void vso_phase_peak(const float* surface, int M, int N, double* dx, double* dy, double* response);
+int  vso_phase_correlate(const float* a, const float* b, int w, int h, double* dx, double* dy, double* response);
+int  vso_phase_correlate_u8(const uint8_t* a, const uint8_t* b, int w, int h, int stride, double* dx, double* dy, double* response);
+
 /* ---- L1 smoother (smoother.cpp) --------------------------------------------------------- */
 void vso_tvl1_smooth(const double* data, int n, double lambda, int iterations, double* out); /* :18-65 */
 typedef struct vso_smoother vso_smoother;
@@ -141,6 +150,7 @@ typedef struct vso_align_debug {
     int selected_x[16], selected_y[16];
     double condition[16];
     vso_transform level_transform[16];   /* transform at the end of each level (before TX,TY *= 2) */
+    double phase_dx, phase_dy, phase_response;   /* cv::phaseCorrelate result of the pair (phase_correlate only) */
 } vso_align_debug;
 
 vso_aligner* vso_aligner_create(void);

@@ -52,14 +52,15 @@ class StabilizerParams(C.Structure):
 
 class AlignInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("fail_reason", C.c_int32), ("fail_level", C.c_int32),
-                ("levels", C.c_int32), ("iterations", C.c_int32 * 16), ("condition", C.c_double * 16)]
+                ("levels", C.c_int32), ("iterations", C.c_int32 * 16), ("condition", C.c_double * 16),
+                ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
 
 
-STAGES = ["ingest", "pyr_down", "keyframe", "warpdiff", "select", "gather", "gn"]
+STAGES = ["ingest", "pyr_down", "keyframe", "warpdiff", "select", "gather", "gn", "phase"]
 
 
 class StageTimings(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_int64 * 7), ("frames", C.c_int64), ("gn_iterations", C.c_int64)]
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8), ("frames", C.c_int64), ("gn_iterations", C.c_int64)]
 
 
 class VsError(RuntimeError):
@@ -99,6 +100,8 @@ SIGNATURES = {
     "vs_sparse_warpdiff": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "vs_sparse_ica": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "vs_select_smallest": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "vs_phase_correlate": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vs_optimal_dft_size": (_i32, [_i32]),
     "vs_image_warp": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _i32, _i32, _vp]),
     "vs_bgr_image_warp": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vs_bgr_image_warp_batch": (_i32, [_vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _sz, _i32, _i32, _vp]),
@@ -352,6 +355,21 @@ def select_smallest(warpdiff, fraction=0.8):
     status = np.empty(n, np.int32)
     cnt = _check(lib().vs_select_smallest(_p(wd), n, tx, ty, fraction, _p(idx), _p(status), MEM_HOST, None))
     return [idx[i, :cnt].copy() for i in range(n)], status
+
+
+def optimal_dft_size(n):
+    return lib().vs_optimal_dft_size(int(n))
+
+
+def phase_correlate(a, b, want_surface=False):
+    """cv::phaseCorrelate on two u8 images -> (dx, dy, response[, unshifted surface (M, N)])"""
+    a = _c(a, np.uint8)
+    b = _c(b, np.uint8)
+    h, w = a.shape
+    res = np.zeros(3, np.float64)
+    surf = np.empty((optimal_dft_size(h), optimal_dft_size(w)), np.float32) if want_surface else None
+    _check(lib().vs_phase_correlate(_p(a), _p(b), w, h, w, MEM_HOST, None, _p(surf) if want_surface else None, _p(res)))
+    return (res[0], res[1], res[2], surf) if want_surface else (res[0], res[1], res[2])
 
 
 def image_warp_raw(img, A, B, TX, TY, out_shape=None):

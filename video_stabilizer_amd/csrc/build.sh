@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../libvs_amd.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 ${VS_RESOURCE_REPORT:+-Rpass-analysis=kernel-resource-usage} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result"
-SRCS="vs_kernels.hip vs_warp.hip vs_capi.hip vs_engine.hip vs_host.cpp"
+SRCS="vs_kernels.hip vs_warp.hip vs_phase.hip vs_capi.hip vs_engine.hip vs_host.cpp"
 mkdir -p "$HERE/build"
 objs=""
 pids=""

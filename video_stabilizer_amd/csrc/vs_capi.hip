@@ -4,6 +4,7 @@
 // VS_MEM_DEVICE only enqueues on the caller's stream.
 #include "vs_internal.hpp"
 #include "vs_kernels.hpp"
+#include "vs_phase.hpp"
 
 #include <cstring>
 #include <deque>
@@ -150,6 +151,41 @@ int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, in
     VS_HIP(vsk::pyr_down(a.as<uint8_t>(), w, h, in_stride, b.as<uint8_t>(), ow, oh, out_stride, 1, 0, 0, s));
     VS_TRY(b.finish(s));
     return finish_host(mem, s);
+}
+
+int vs_optimal_dft_size(int n) { return vsp::optimal_dft_size(n); }
+
+int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int stride, int mem, void* stream, float* surface,
+                       double* result) {
+    VS_ARG(a && b && result && w > 0 && h > 0 && stride >= w);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    vsp::Context ctx;
+    struct Guard { vsp::Context& c; ~Guard() { c.destroy(); } } guard{ctx};
+    if (ctx.configure(w, h, s) != hipSuccess)
+        return set_error(VS_ERR_UNSUPPORTED, "phase correlation: padded extent over %d (%dx%d image)", vsp::kMaxLine, w, h);
+    Staged ia, ib, surf;
+    VS_TRY(ia.in(a, img_span(w, h, stride, 1), mem, s));
+    VS_TRY(ib.in(b, img_span(w, h, stride, 1), mem, s));
+    vsi::DevBuf spec, G, surf_own, pairs, res;
+    VS_HIP(spec.alloc(2 * ctx.spec_frame() * sizeof(float2)));
+    VS_HIP(G.alloc(ctx.spec_frame() * sizeof(float2)));
+    VS_HIP(pairs.alloc(sizeof(vsp::Pair)));
+    VS_HIP(res.alloc(sizeof(vsp::Result)));
+    float* d_surf;
+    if (surface) { VS_TRY(surf.out(surface, ctx.surface_elems() * sizeof(float), mem)); d_surf = surf.as<float>(); }
+    else { VS_HIP(surf_own.alloc(ctx.surface_elems() * sizeof(float))); d_surf = surf_own.as<float>(); }
+    const vsp::Pair pr{0, 1};
+    VS_HIP(hipMemcpyAsync(pairs.p, &pr, sizeof pr, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx.spectra(ia.as<uint8_t>(), 0, stride, 1, spec.as<float2>(), s));
+    VS_HIP(ctx.spectra(ib.as<uint8_t>(), 0, stride, 1, spec.as<float2>() + ctx.spec_frame(), s));
+    VS_HIP(ctx.correlate(spec.as<float2>(), pairs.as<vsp::Pair>(), 1, G.as<float2>(), d_surf, res.as<vsp::Result>(), s));
+    if (surface) VS_TRY(surf.finish(s));
+    vsp::Result r;
+    VS_HIP(hipMemcpyAsync(&r, res.p, sizeof r, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));        // the result is a host value: this call always synchronises
+    result[0] = r.dx; result[1] = r.dy; result[2] = r.response;
+    return VS_OK;
 }
 
 int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream) {

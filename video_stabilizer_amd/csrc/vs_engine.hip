@@ -15,6 +15,7 @@
 //   * The transform algebra inside the loop is fp64 on the device, written exactly as imgproc.cpp.
 #include "vs_internal.hpp"
 #include "vs_kernels.hpp"
+#include "vs_phase.hpp"
 #include "vs_device.hpp"
 
 #include <algorithm>
@@ -69,6 +70,22 @@ struct GnParams {
     double threshold, max_displacement;
     int max_iters;
 };
+
+// ---- phase-correlation start value (alignment.cpp:376-387) -----------------------------------------
+// detected_shift of the level-2 images scaled by (1 << PhaseLevel) / float(1 << PyramidLevels) becomes the initial TX,TY
+// (negated when the current frame is the keyframe), if the response clears the threshold.
+__global__ void vs_k_phase_apply(PairState* __restrict__ states, const vsp::Result* __restrict__ res,
+                                 const uint8_t* __restrict__ negate, int n_pairs, double threshold, float scale) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_pairs) return;
+    const vsp::Result r = res[q];
+    if (r.response > threshold) {
+        double tx = r.dx * scale, ty = r.dy * scale;
+        if (negate[q]) { tx = -tx; ty = -ty; }
+        states[q].T[2] = tx;
+        states[q].T[3] = ty;
+    }
+}
 
 // ---- batched sparse_warpdiff: generators.cpp:646-700 for every (pair, set) ---------------------
 __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __restrict__ states,
@@ -685,7 +702,8 @@ __global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __rest
     const int p = blockIdx.x;
     PairState& st = states[p];
     const PairDesc d = descs[p];
-    double T[4] = {0.0, 0.0, 0.0, 0.0};     // alignment.cpp:344 identity
+    // alignment.cpp:344 identity, or the phase-correlation start value the host side put into the state (:376-387)
+    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
     int fail = 0, fail_level = 0;
     for (int l = fl.levels - 1; l >= 0 && !fail; l--) {
         const int w = fl.w[l], h = fl.h[l], nt = fl.nt[l], nsel = fl.nsel[l];
@@ -807,6 +825,16 @@ struct vs_aligner {
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
     void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area
+    // phase-correlation mode (allocated on first use): level-2 half spectra per slot, per-pair scratch and results
+    vsp::Context phase;
+    int phase_cap = 0;
+    float2* pspec = nullptr;
+    float2* pG = nullptr;
+    float* psurf = nullptr;
+    vsp::Pair* ppairs = nullptr;
+    uint8_t* pneg = nullptr;
+    vsp::Result* pres = nullptr;
+    std::vector<vsp::Result> h_pres;
     // pinned host mirrors
     uint16_t* h_wd = nullptr;
     int32_t* h_idx = nullptr;
@@ -849,12 +877,45 @@ struct vs_aligner {
     void release();
     int configure(int w, int h, int format, const vs_aligner_params& p);
     int ensure_capacity(int n);
+    int ensure_phase();
+    void release_phase();
     int run_chunk(const void* frames, size_t frame_stride, int n, int stride, int mem, const vs_aligner_params& p,
                   vs_transform* out, int32_t* status, vs_align_info* infos);
     int select_host(int n_pairs, const LevelDims& l);
 };
 
+void vs_aligner::release_phase() {
+    void* d[] = {pspec, pG, psurf, ppairs, pneg, pres};
+    for (void* p : d) if (p) (void)hipFree(p);
+    pspec = nullptr; pG = nullptr; psurf = nullptr; ppairs = nullptr; pneg = nullptr; pres = nullptr;
+    phase_cap = 0;
+    phase.destroy();
+}
+
+// buffers of the phase-correlation mode for the current chunk capacity (PhaseLevel = 2, alignment.hpp:69)
+int vs_aligner::ensure_phase() {
+    const LevelDims& pl = L[2];
+    if (phase.w != pl.w || phase.h != pl.h) {
+        release_phase();
+        if (phase.configure(pl.w, pl.h, stream) != hipSuccess)
+            return set_error(VS_ERR_UNSUPPORTED, "phase_correlate: level 2 is %dx%d, padded extent over %d", pl.w, pl.h, vsp::kMaxLine);
+    }
+    if (phase_cap >= cap) return VS_OK;
+    void* d[] = {pspec, pG, psurf, ppairs, pneg, pres};
+    for (void* p : d) if (p) (void)hipFree(p);
+    pspec = nullptr; pG = nullptr; psurf = nullptr; ppairs = nullptr; pneg = nullptr; pres = nullptr; phase_cap = 0;
+    VS_HIP(hipMalloc((void**)&pspec, ((size_t)cap + 1) * phase.spec_frame() * sizeof(float2)));
+    VS_HIP(hipMalloc((void**)&pG, (size_t)cap * phase.spec_frame() * sizeof(float2)));
+    VS_HIP(hipMalloc((void**)&psurf, (size_t)cap * phase.surface_elems() * sizeof(float)));
+    VS_HIP(hipMalloc((void**)&ppairs, (size_t)cap * sizeof(vsp::Pair)));
+    VS_HIP(hipMalloc((void**)&pneg, (size_t)cap));
+    VS_HIP(hipMalloc((void**)&pres, (size_t)cap * sizeof(vsp::Result)));
+    phase_cap = cap;
+    return VS_OK;
+}
+
 void vs_aligner::release() {
+    release_phase();
     void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, stage};
     for (void* p : d) if (p) (void)hipFree(p);
     void* hp[] = {h_wd, h_idx, h_states};
@@ -1017,6 +1078,16 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                              L[l].h, L[l].w, n, pyr_frame, pyr_frame, s));
     t_end(levels - 1);
 
+    // ---- PhaseImage (alignment.cpp:225-229): half spectra of level 2, for the carry-over slot too ------------
+    if (p.phase_correlate) {
+        VS_TRY(ensure_phase());
+        t_begin(VS_STAGE_PHASE);
+        const int first = (seq > 0 && clip_len == 0) ? 0 : 1;
+        VS_HIP(phase.spectra(pyr + (size_t)first * pyr_frame + L[2].img_off, pyr_frame, L[2].w, n + 1 - first,
+                             pspec + (size_t)first * phase.spec_frame(), s));
+        t_end(2);
+    }
+
     // ---- ComputeKeyFrame (alignment.cpp:237-276) for the odd frames of the sequence -----------
     // frame i of this chunk sits in slot i + 1; its index in its sequence is g(i) = seq + i, or i mod clip_len
     // when the batch is a set of independent clips (every clip starts its own sequence at 0)
@@ -1071,7 +1142,33 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         }
         VS_HIP(hipMemcpyAsync(descs, hd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
         VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
-        VS_HIP(hipStreamSynchronize(s));   // hd goes out of scope; also orders the pinned h_states reuse below
+        // alignment.cpp:369-388: cv::phaseCorrelate(PhaseImage[Prev], PhaseImage[Curr]) starts TX,TY of every pair
+        std::vector<vsp::Pair> hp;
+        std::vector<uint8_t> hneg;
+        const float phase_scale = (1 << 2) / float(1 << levels);
+        auto apply_phase = [&]() -> int {
+            hipLaunchKernelGGL(vs_k_phase_apply, dim3((n_pairs + 255) / 256), dim3(256), 0, s, states, pres, pneg, n_pairs,
+                               p.phase_correlate_threshold, phase_scale);
+            VS_HIP(hipGetLastError());
+            return VS_OK;
+        };
+        if (p.phase_correlate) {
+            hp.resize(n_pairs); hneg.resize(n_pairs);
+            for (int q = 0; q < n_pairs; q++) {
+                const int i = pair_frame[q];
+                hp[q] = vsp::Pair{i, i + 1};
+                hneg[q] = (gidx(i) & 1) ? 1 : 0;          // CurrFrameIndex == KeyframeIndex
+            }
+            VS_HIP(hipMemcpyAsync(ppairs, hp.data(), sizeof(vsp::Pair) * n_pairs, hipMemcpyHostToDevice, s));
+            VS_HIP(hipMemcpyAsync(pneg, hneg.data(), (size_t)n_pairs, hipMemcpyHostToDevice, s));
+            t_begin(VS_STAGE_PHASE);
+            VS_HIP(phase.correlate(pspec, ppairs, n_pairs, pG, psurf, pres, s));
+            VS_TRY(apply_phase());
+            t_end(4);
+            h_pres.resize(n_pairs);
+            VS_HIP(hipMemcpyAsync(h_pres.data(), pres, sizeof(vsp::Result) * n_pairs, hipMemcpyDeviceToHost, s));
+        }
+        VS_HIP(hipStreamSynchronize(s));   // hd, hp, hneg go out of use; also orders the pinned h_states reuse below
 
         const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 24;
         GnParams gp{p.threshold, p.max_displacement, p.max_iters};
@@ -1100,6 +1197,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             if (use_host) {
                 for (int q = 0; q < n_pairs; q++) { memset(&h_states[q], 0, sizeof(PairState)); h_states[q].status = 1; }
                 VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
+                if (p.phase_correlate) VS_TRY(apply_phase());
                 VS_HIP(hipStreamSynchronize(s));
             }
         }
@@ -1150,6 +1248,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             vs_align_info& inf = infos[i];
             inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
             for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l]; }
+            if (p.phase_correlate) { inf.phase_dx = h_pres[q].dx; inf.phase_dy = h_pres[q].dy; inf.phase_response = h_pres[q].response; }
             vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
             if (st.status == 1) {
                 if ((gidx(i) & 1) == 0) t = vs_transform_inverse(&t);   // alignment.cpp:690-693
@@ -1241,7 +1340,6 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
     VS_ARG(stride >= w * ch);
     VS_ARG(n == 1 || frame_stride >= (size_t)(h - 1) * stride + (size_t)w * ch);
     const vs_aligner_params& p = params ? *params : a->params;
-    if (p.phase_correlate) return set_error(VS_ERR_UNSUPPORTED, "phase_correlate is not built (off by default in the reference)");
     VS_ARG(p.max_iters >= 1 && p.smallest_fraction > 0.0f && p.smallest_fraction <= 1.0f);
     VS_HIP(hipSetDevice(a->device));
     if (a->W != w || a->H != h || a->fmt != format) VS_TRY(a->configure(w, h, format, p));   // alignment.cpp:155
