@@ -170,6 +170,14 @@ int vs_bgr_image_warp_batch(const void* src, size_t src_frame_stride, int n_fram
                             int w, int h, int src_stride, int channels, int bits,
                             const vs_transform* t /* host array, n_frames */, int mode, int border, int max_value,
                             void* dst, size_t dst_frame_stride, int dst_stride, int mem, void* stream);
+/* The same, but only the window [roi_x, roi_x+roi_w) x [roi_y, roi_y+roi_h) of every output frame is computed and
+ * stored (dst holds roi_w x roi_h pixels per frame, row stride dst_stride, frame stride dst_frame_stride): bit-identical
+ * to cropping the full warp.  This is how the stabilizer applies crop_pixels (stabilizer.cpp:102-109) without warping the
+ * margin or copying the frame. */
+int vs_bgr_image_warp_roi_batch(const void* src, size_t src_frame_stride, int n_frames, int w, int h, int src_stride,
+                                int channels, int bits, const vs_transform* t, int mode, int border, int max_value,
+                                int roi_x, int roi_y, int roi_w, int roi_h,
+                                void* dst, size_t dst_frame_stride, int dst_stride, int mem, void* stream);
 /* same sampling, float output (typed like image_warp); dst interleaved f32 */
 int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits,
                           const vs_transform* t, int mode, int border,
@@ -270,6 +278,12 @@ int  vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, in
 int  vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
                                  int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output,
                                  int* out_w, int* out_h);
+/* Many independent clips at once: n_clips clips of frames_per_clip frames back to back (clip c, frame k at index
+ * c*frames_per_clip + k, outputs at the same index).  Results = every clip through its own fresh VideoStabilizer, with the
+ * alignment and the warps of all clips batched together.  The handle is reset before the first and after the last clip. */
+int  vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip,
+                                 int w, int h, int stride, int format, int mem, void* out, size_t out_frame_stride,
+                                 int32_t* has_output, int* out_w, int* out_h);
 int  vs_stabilizer_reset(vs_stabilizer* s);   /* start a new clip; device buffers are kept */
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 

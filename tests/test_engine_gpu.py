@@ -349,3 +349,27 @@ def test_stabilizer_decay_and_reset_branches(gpu_vs, oracle, kw):
             assert d.max() <= 1 and (d != 0).mean() < 2e-2, i
     assert fails >= 2          # first frame + the scene cut
     assert big > 4.0           # the correction really grew
+
+
+def test_stabilizer_process_clips_equals_fresh_stabilizers(gpu_vs):
+    """vs_stabilizer_process_clips: every clip through its own fresh VideoStabilizer, batched together"""
+    from video_stabilizer_amd import synth
+    fpc, n_clips = 9, 3
+    clips = [synth.make_clip(256, 192, fpc, seed=60 + c, channels=3)[0] for c in range(n_clips)]
+    kw = dict(lag=3, crop_pixels=8)
+    want, want_has = [], []
+    for c in clips:
+        s = gpu_vs.Stabilizer(device=0, **kw)
+        for f in c:
+            o = s.process(f)
+            want_has.append(0 if o is None else 1)
+            want.append(np.zeros((192 - 16, 256 - 16, 3), np.uint8) if o is None else o)
+    s = gpu_vs.Stabilizer(device=0, **kw)
+    s.process(clips[0][0])                           # stale state from earlier use must not leak into the clips
+    out, has = s.process_clips(np.concatenate(clips), n_clips)
+    assert has == want_has and sum(has) == n_clips * (fpc - 3)
+    assert np.array_equal(out, np.stack(want))
+    # the handle is left reset: the next frame is a first frame again
+    assert s.process(clips[1][0]) is None and s.state()[2] is False
+    out2, has2 = s.process_clips(np.concatenate(clips), n_clips)
+    assert has2 == want_has and np.array_equal(out2, out)

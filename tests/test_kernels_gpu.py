@@ -282,3 +282,27 @@ def test_bgr_to_gray_bit_exact(gpu_vs, oracle, bits):
 def test_bad_arguments_are_errors(gpu_vs):
     with pytest.raises(gpu_vs.VsError):
         gpu_vs.bgr_image_warp(np.zeros((4, 4, 5), np.uint8), gpu_vs.Transform.of())
+
+
+@pytest.mark.parametrize("dtype,c", [(np.uint8, 3), (np.uint16, 3), (np.uint8, 1), (np.uint8, 4)])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("border", [0, 1])
+def test_bgr_image_warp_window_equals_cropped_full_warp(gpu_vs, dtype, c, mode, border):
+    """vs_bgr_image_warp_roi_batch (the stabilizer's crop, stabilizer.cpp:102-109): any window of the output, computed
+    alone, is bit-identical to the same rows / columns of the full warp"""
+    rng = np.random.default_rng(11)
+    n, h, w = 3, 157, 211
+    hi = 255 if dtype == np.uint8 else 1023
+    src = rng.integers(0, hi + 1, (n, h, w, c)).astype(dtype)
+    ts = [gpu_vs.Transform.of(0.01, -0.02, 3.3, -2.7), gpu_vs.Transform.of(-0.03, 0.015, -40.0, 25.5),
+          gpu_vs.Transform.of(0.0, 0.0, 0.0, 0.0)]
+    full = gpu_vs.bgr_image_warp_batch(src, ts, mode=mode, border=border, max_value=hi)
+    for roi in [(0, 0, w, h), (32, 32, w - 64, h - 64), (1, 2, 64, 16), (5, 7, 65, 17), (w - 3, h - 2, 3, 2), (13, 0, 1, h),
+                (0, 150, w, 1), (64, 16, 128, 32)]:
+        x, y, rw, rh = roi
+        got = gpu_vs.bgr_image_warp_roi_batch(src, ts, roi, mode=mode, border=border, max_value=hi)
+        assert got.shape == (n, rh, rw, c)
+        assert np.array_equal(got, full[:, y:y + rh, x:x + rw]), roi
+    for bad in [(-1, 0, 4, 4), (0, 0, w + 1, 4), (w - 2, 0, 3, 4), (0, 0, 0, 4)]:
+        with pytest.raises(gpu_vs.VsError):
+            gpu_vs.bgr_image_warp_roi_batch(src, ts, bad)

@@ -105,6 +105,8 @@ SIGNATURES = {
     "vs_image_warp": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _i32, _i32, _vp]),
     "vs_bgr_image_warp": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vs_bgr_image_warp_batch": (_i32, [_vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32, _vp, _sz, _i32, _i32, _vp]),
+    "vs_bgr_image_warp_roi_batch": (_i32, [_vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _i32,
+                                           _i32, _i32, _i32, _i32, _vp, _sz, _i32, _i32, _vp]),
     "vs_bgr_image_warp_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _TP, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vs_bgr_to_gray": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "vs_aligner_create": (_vp, [C.POINTER(AlignerParams), _i32]),
@@ -125,6 +127,7 @@ SIGNATURES = {
     "vs_stabilizer_destroy": (None, [_vp]),
     "vs_stabilizer_process": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _IP, _IP]),
     "vs_stabilizer_process_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, C.POINTER(C.c_int32), _IP, _IP]),
+    "vs_stabilizer_process_clips": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, C.POINTER(C.c_int32), _IP, _IP]),
     "vs_stabilizer_reset": (_i32, [_vp]),
     "vs_stabilizer_state": (None, [_vp, _TP, _TP, _IP]),
 }
@@ -418,6 +421,21 @@ def bgr_image_warp_batch(src, ts, mode=WARP_LANCZOS2, border=BORDER_CLAMP, max_v
     return out
 
 
+def bgr_image_warp_roi_batch(src, ts, roi, mode=WARP_LANCZOS2, border=BORDER_CLAMP, max_value=None):
+    """only the window roi = (x, y, w, h) of every warped frame: (n, roi_h, roi_w, c)"""
+    src = np.ascontiguousarray(src)
+    n, h, w, c = src.shape
+    bits = 8 if src.dtype == np.uint8 else 16
+    if max_value is None:
+        max_value = 255 if bits == 8 else 65535
+    rx, ry, rw, rh = roi
+    arr = (Transform * n)(*ts)
+    out = np.empty((n, rh, rw, c), src.dtype)
+    _check(lib().vs_bgr_image_warp_roi_batch(_p(src), h * w * c, n, w, h, w * c, c, bits, arr, mode, border, max_value,
+                                             rx, ry, rw, rh, _p(out), rh * rw * c, rw * c, MEM_HOST, None))
+    return out
+
+
 def bgr_image_warp_batch_device(src_ptr, n, w, h, c, bits, ts, dst_ptr, mode=WARP_LANCZOS2, border=BORDER_CLAMP,
                                 max_value=None, stream=None):
     """device-resident form: dense frames, enqueue only"""
@@ -601,6 +619,28 @@ class Stabilizer:
         ow, oh = C.c_int(), C.c_int()
         r = _check(lib().vs_stabilizer_process_batch(self.h, _p(ptr), h * w * 3, n, w, h, w * 3, fmt, MEM_DEVICE, _p(out_ptr),
                                                      (h - 2 * c) * (w - 2 * c) * 3, has, C.byref(ow), C.byref(oh)))
+        return r, list(has)
+
+    def process_clips(self, frames, n_clips):
+        """frames (n_clips*fpc, h, w, 3) numpy: every clip through a fresh stabilizer, batched together"""
+        frames = np.ascontiguousarray(frames)
+        n, hh, ww = frames.shape[:3]
+        fmt = _fmt_of(frames.dtype, 3)
+        c = max(self.params.crop_pixels, 0)
+        out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
+        has = (C.c_int32 * n)()
+        ow, oh = C.c_int(), C.c_int()
+        _check(lib().vs_stabilizer_process_clips(self.h, _p(frames), hh * ww * 3, n_clips, n // n_clips, ww, hh, ww * 3, fmt, MEM_HOST,
+                                                 _p(out), out[0].size, has, C.byref(ow), C.byref(oh)))
+        return out, list(has)
+
+    def process_clips_device(self, ptr, n_clips, frames_per_clip, w, h, fmt, out_ptr):
+        c = max(self.params.crop_pixels, 0)
+        n = n_clips * frames_per_clip
+        has = (C.c_int32 * n)()
+        ow, oh = C.c_int(), C.c_int()
+        r = _check(lib().vs_stabilizer_process_clips(self.h, _p(ptr), h * w * 3, n_clips, frames_per_clip, w, h, w * 3, fmt, MEM_DEVICE,
+                                                     _p(out_ptr), (h - 2 * c) * (w - 2 * c) * 3, has, C.byref(ow), C.byref(oh)))
         return r, list(has)
 
     def state(self):

@@ -309,15 +309,18 @@ int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B,
     return finish_host(mem, s);
 }
 
+// roi = NULL: the whole w x h output.  Otherwise dst holds only the window (roi->w x roi->h pixels per frame).
 static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
                            int bits, const vs_transform* t, int mode, int border, int max_value, void* dst,
-                           size_t dst_fs, int dst_stride, bool f32out, int mem, hipStream_t s) {
+                           size_t dst_fs, int dst_stride, bool f32out, int mem, hipStream_t s, const vsk::Roi* roi_in = nullptr) {
     VS_ARG(src && dst && t && n_frames >= 1 && w > 0 && h > 0 && channels >= 1 && channels <= 4);
     VS_ARG(bits == 8 || bits == 16);
-    VS_ARG(src_stride >= w * channels && dst_stride >= w * channels);
+    const vsk::Roi roi = roi_in ? *roi_in : vsk::Roi{0, 0, w, h};
+    VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.x + roi.w <= w && roi.y + roi.h <= h);
+    VS_ARG(src_stride >= w * channels && dst_stride >= roi.w * channels);
     VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR);
     VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
-    VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(w, h, dst_stride, channels)));
+    VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(roi.w, roi.h, dst_stride, channels)));
     if (!vsi::device_ready()) return VS_ERR_HIP;
     const size_t esz = bits / 8, osz = f32out ? 4 : esz;
     std::vector<float> P((size_t)n_frames * 4);
@@ -328,16 +331,16 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     VS_TRY(g_param_ring.upload(P.data(), (size_t)n_frames, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
-    const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(w, h, dst_stride, channels)) * osz;
+    const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(roi.w, roi.h, dst_stride, channels)) * osz;
     VS_TRY(a.in(src, in_bytes, mem, s));
     VS_TRY(o.out(dst, out_bytes, mem));
     hipError_t e = hipErrorNotSupported;
     if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
         e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
-                             dst_fs, s);
+                             dst_fs, roi, s);
     if (e == hipErrorNotSupported)
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
-                                  o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, s);
+                                  o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);
     VS_HIP(e);
     VS_TRY(g_param_ring.fence(pdev, (size_t)n_frames, s));
     VS_TRY(o.finish(s));
@@ -355,6 +358,14 @@ int vs_bgr_image_warp_batch(const void* src, size_t src_fs, int n_frames, int w,
                             size_t dst_fs, int dst_stride, int mem, void* stream) {
     return bgr_warp_common(src, src_fs, n_frames, w, h, src_stride, channels, bits, t, mode, border, max_value, dst,
                            dst_fs, dst_stride, false, mem, (hipStream_t)stream);
+}
+
+int vs_bgr_image_warp_roi_batch(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
+                                int bits, const vs_transform* t, int mode, int border, int max_value, int roi_x, int roi_y,
+                                int roi_w, int roi_h, void* dst, size_t dst_fs, int dst_stride, int mem, void* stream) {
+    const vsk::Roi roi{roi_x, roi_y, roi_w, roi_h};
+    return bgr_warp_common(src, src_fs, n_frames, w, h, src_stride, channels, bits, t, mode, border, max_value, dst,
+                           dst_fs, dst_stride, false, mem, (hipStream_t)stream, &roi);
 }
 
 int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,

@@ -1499,9 +1499,12 @@ void vs_stabilizer_destroy(vs_stabilizer* s) {
 // n successive VideoStabilizer::processFrame calls (stabilizer.cpp:9-117) as one batch: one batched alignment,
 // the scalar bookkeeping on the host exactly as the reference orders it, then batched warps of every frame that
 // became due.  has_output[i] = 1 when input frame i produced an output, written to out + i*out_frame_stride.
-int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
-                                int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
-                                int* out_h) {
+int vs_stabilizer_reset(vs_stabilizer* s);
+
+// n successive processFrame calls; clip_len > 0: the n frames are n / clip_len independent clips, each run through a
+// fresh stabilizer (reset before every clip and after the last), all of them aligned and warped together.
+static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
+                    int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h) {
     VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
     VS_ARG(format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
     VS_ARG(stride >= 3 * w);
@@ -1545,14 +1548,17 @@ int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t fra
     s->t_buf.resize(n);
     s->st_buf.resize(n);
     {
-        int r = vs_aligner_align_batch(a, dense, (size_t)w * h * 3, n, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner,
-                                       s->t_buf.data(), s->st_buf.data());
+        int r = clip_len > 0 ? vs_aligner_align_clips(a, dense, (size_t)w * h * 3, n / clip_len, clip_len, w, h, w * 3, format,
+                                                      VS_MEM_DEVICE, &s->params.aligner, s->t_buf.data(), s->st_buf.data())
+                             : vs_aligner_align_batch(a, dense, (size_t)w * h * 3, n, w, h, w * 3, format, VS_MEM_DEVICE,
+                                                      &s->params.aligner, s->t_buf.data(), s->st_buf.data());
         if (r < 0) return r;
     }
 
     struct Job { const void* src; vs_transform sampling; int i; void* release; };
     std::vector<Job> jobs;
     for (int i = 0; i < n; i++) {
+        if (clip_len > 0 && i % clip_len == 0) VS_TRY(vs_stabilizer_reset(s));   // a new clip: frames still queued are dropped
         ++s->frame_index;
         s->frames.push_back(vs_stabilizer::Held{(void*)(dense + (size_t)i * fbytes), false});
         const vs_transform meas = s->t_buf[i];
@@ -1600,34 +1606,41 @@ int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t fra
         }
     }
 
-    // warp every due frame: runs of consecutive batch frames go out as one launch
+    // warp every due frame, runs of consecutive batch frames as one launch.  The crop of stabilizer.cpp:102-109 is the
+    // output window of the warp: the margin is never computed and no full-size intermediate frame exists.  Device callers
+    // get the window written straight into `out`; host callers through a dense staging buffer and one copy per frame.
     if (!jobs.empty()) {
-        if (s->batch_out_bytes < fbytes * jobs.size()) {
+        const size_t obytes = (size_t)ow * oh * 3 * esz;
+        if (mem == VS_MEM_HOST && s->batch_out_bytes < obytes * jobs.size()) {
             if (s->batch_out) (void)hipFree(s->batch_out);
             s->batch_out = nullptr; s->batch_out_bytes = 0;
-            VS_HIP(hipMalloc(&s->batch_out, fbytes * jobs.size()));
-            s->batch_out_bytes = fbytes * jobs.size();
+            VS_HIP(hipMalloc(&s->batch_out, obytes * jobs.size()));
+            s->batch_out_bytes = obytes * jobs.size();
         }
         std::vector<vs_transform> ts;
         for (size_t j = 0; j < jobs.size();) {
             size_t e = j + 1;
-            while (e < jobs.size() && (const uint8_t*)jobs[e].src == (const uint8_t*)jobs[e - 1].src + fbytes) e++;
+            while (e < jobs.size() && (const uint8_t*)jobs[e].src == (const uint8_t*)jobs[e - 1].src + fbytes &&
+                   jobs[e].i == jobs[e - 1].i + 1) e++;
             ts.clear();
             for (size_t k = j; k < e; k++) ts.push_back(jobs[k].sampling);
-            int wr = vs_bgr_image_warp_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
-                                             s->params.warp_mode, s->params.warp_border, esz == 1 ? 255 : 65535,
-                                             (uint8_t*)s->batch_out + j * fbytes, (size_t)w * h * 3, w * 3, VS_MEM_DEVICE, st);
+            void* dst = mem == VS_MEM_HOST ? (void*)((uint8_t*)s->batch_out + j * obytes)
+                                           : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
+            const size_t dst_fs = mem == VS_MEM_HOST ? (size_t)ow * oh * 3 : out_frame_stride;
+            int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
+                                                 s->params.warp_mode, s->params.warp_border, esz == 1 ? 255 : 65535, crop, crop, ow, oh,
+                                                 dst, dst_fs, ow * 3, VS_MEM_DEVICE, st);
             if (wr < 0) return wr;
             j = e;
         }
-        for (size_t j = 0; j < jobs.size(); j++) {                                                          // :102-109 crop
-            VS_HIP(hipMemcpy2DAsync((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz, (size_t)ow * 3 * esz,
-                                    (const uint8_t*)s->batch_out + j * fbytes + ((size_t)crop * w + crop) * 3 * esz,
-                                    (size_t)w * 3 * esz, (size_t)ow * 3 * esz, oh,
-                                    mem == VS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+        for (size_t j = 0; j < jobs.size(); j++) {
+            if (mem == VS_MEM_HOST)
+                VS_HIP(hipMemcpyAsync((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz, (const uint8_t*)s->batch_out + j * obytes,
+                                      obytes, hipMemcpyDeviceToHost, st));
             if (jobs[j].release) s->pool.push_back(jobs[j].release);   // reused only by later work on this stream
         }
     }
+    if (clip_len > 0) VS_TRY(vs_stabilizer_reset(s));   // nothing carries over from the last clip
     // frames of this batch that are still queued move into buffers of our own
     for (auto& f : s->frames) {
         if (f.owned) continue;
@@ -1641,6 +1654,20 @@ int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t fra
     int produced = 0;
     for (int i = 0; i < n; i++) produced += has_output[i];
     return produced;
+}
+
+int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
+                                int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
+                                int* out_h) {
+    return stab_run(s, frames, frame_stride, n, 0, w, h, stride, format, mem, out, out_frame_stride, has_output, out_w, out_h);
+}
+
+int vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip,
+                                int w, int h, int stride, int format, int mem, void* out, size_t out_frame_stride,
+                                int32_t* has_output, int* out_w, int* out_h) {
+    VS_ARG(n_clips >= 1 && frames_per_clip >= 1 && (long long)n_clips * frames_per_clip <= 0x7fffffff);
+    return stab_run(s, frames, frame_stride, n_clips * frames_per_clip, frames_per_clip, w, h, stride, format, mem, out,
+                    out_frame_stride, has_output, out_w, out_h);
 }
 
 // forget the clip: the next frame starts a new sequence (device buffers are kept)

@@ -455,14 +455,15 @@ template <typename T, int MODE, int BORDER, bool F32OUT>
 __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict__ src, int w, int h, int src_stride,
                                                              int channels, const float4* __restrict__ params,
                                                              int max_value, void* __restrict__ dstv, int dst_stride,
-                                                             size_t src_frame_stride, size_t dst_frame_stride) {
+                                                             size_t src_frame_stride, size_t dst_frame_stride, vsk::Roi roi) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    if (x >= roi.w) return;
     const float4 P = params[blockIdx.z];
     src += blockIdx.z * src_frame_stride;
     const float A = P.x, B = P.y, TX = P.z, TY = P.w;
-    float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
-    float Wy = B * (float)x + (1.0f + A) * (float)y + TY;
+    const float fx = (float)(x + roi.x), fy = (float)(y + roi.y);   // full-frame coordinate of this window pixel
+    float Wx = (1.0f + A) * fx - B * fy + TX;
+    float Wy = B * fx + (1.0f + A) * fy + TY;
     float flx = floorf(Wx), fly = floorf(Wy);
     int ix = (int)flx, iy = (int)fly;
     float frx = Wx - flx, fry = Wy - fly;
@@ -630,11 +631,11 @@ hipError_t image_warp(const uint8_t* in, int w, int h, int stride, float A, floa
 template <typename T, bool F32OUT>
 static void launch_generic(const T* src, int w, int h, int src_stride, int channels, const float4* params, int mode,
                            int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs,
-                           size_t dst_fs, hipStream_t s) {
-    dim3 grid(cdiv(w, 256), h, n_frames), block(256);
+                           size_t dst_fs, vsk::Roi roi, hipStream_t s) {
+    dim3 grid(cdiv(roi.w, 256), roi.h, n_frames), block(256);
 #define VS_LAUNCH(M, Bd)                                                                                          \
     hipLaunchKernelGGL((vs_k_bgr_warp_generic<T, M, Bd, F32OUT>), grid, block, 0, s, src, w, h, src_stride, channels, \
-                       params, max_value, dst, dst_stride, src_fs, dst_fs)
+                       params, max_value, dst, dst_stride, src_fs, dst_fs, roi)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
@@ -644,13 +645,13 @@ static void launch_generic(const T* src, int w, int h, int src_stride, int chann
 
 hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int channels, int bits,
                             const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
-                            bool f32out, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+                            bool f32out, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
     if (bits == 8) {
-        if (f32out) launch_generic<uint8_t, true>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
-        else launch_generic<uint8_t, false>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+        if (f32out) launch_generic<uint8_t, true>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
+        else launch_generic<uint8_t, false>((const uint8_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
     } else {
-        if (f32out) launch_generic<uint16_t, true>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
-        else launch_generic<uint16_t, false>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, s);
+        if (f32out) launch_generic<uint16_t, true>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
+        else launch_generic<uint16_t, false>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
     }
     return hipGetLastError();
 }

@@ -8,6 +8,9 @@
 
 namespace vsk {
 
+// output window of a warp: output pixel (x, y), x < w, y < h, is pixel (x + Roi.x, y + Roi.y) of the full output frame
+struct Roi { int x, y, w, h; };
+
 hipError_t calib_copy12(const void* src, void* dst, size_t bytes, hipStream_t s);
 
 hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride,
@@ -35,10 +38,10 @@ hipError_t image_warp(const uint8_t* in, int w, int h, int stride, float A, floa
 // params_dev: n_frames float4 {A,B,TX,TY} (upper-left based kernel arguments) in device memory
 hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int channels, int bits,
                             const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
-                            bool f32out, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, hipStream_t s);
+                            bool f32out, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, Roi roi, hipStream_t s);
 // tuned interleaved 3-channel path, u8 or u16 (vs_warp.hip); hipErrorNotSupported when the grid would overflow
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
                        int max_value, void* dst, int dst_stride, int n_frames, size_t src_frame_stride,
-                       size_t dst_frame_stride, hipStream_t s);
+                       size_t dst_frame_stride, Roi roi, hipStream_t s);
 
 }  // namespace vsk

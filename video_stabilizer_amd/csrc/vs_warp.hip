@@ -150,7 +150,8 @@ template <typename T, int MODE, int BORDER>
 __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ src, int w, int h, int src_stride,
                                                         const float4* __restrict__ params, T* __restrict__ dst,
                                                         int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x,
-                                                        int tiles_per_frame, int total_tiles, int chunk, float maxv) {
+                                                        int tiles_per_frame, int total_tiles, int chunk, float maxv,
+                                                        vsk::Roi roi) {
     __shared__ f4 tile[WS_H * WS_W];                       // {B,G,R,1} per staged source pixel
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
     // workgroup b works on logical tile (b % 8) * chunk + b / 8: every XCD walks one contiguous run of
@@ -163,12 +164,14 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
     src += (size_t)frame * src_fs;
     dst += (size_t)frame * dst_fs;
     const float A1 = 1.0f + P.x, B = P.y, TX = P.z, TY = P.w;
+    // output pixel (x, y) of the window is pixel (x + roi.x, y + roi.y) of the full frame: the sampling position is
+    // computed from the full-frame coordinate, so a window equals the same rows / columns cut out of the whole warp
     const int x0 = txi * WT_W, y0 = tyi * WT_H;
-    const int x1 = min(x0 + WT_W, w) - 1, y1 = min(y0 + WT_H, h) - 1;
+    const int x1 = min(x0 + WT_W, roi.w) - 1, y1 = min(y0 + WT_H, roi.h) - 1;
 
     // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is
     // monotone), so its extremes over the tile sit at corners chosen by the signs of A1 and B: 4 evaluations.
-    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)y0, fy1 = (float)y1;
+    const float fx0 = (float)(x0 + roi.x), fx1 = (float)(x1 + roi.x), fy0 = (float)(y0 + roi.y), fy1 = (float)(y1 + roi.y);
     const float xa = A1 >= 0.f ? fx0 : fx1, xb = A1 >= 0.f ? fx1 : fx0;     // x minimising / maximising A1*x
     const float ya = B >= 0.f ? fy0 : fy1, yb = B >= 0.f ? fy1 : fy0;       // y minimising / maximising B*y
     const float mnx = A1 * xa - B * yb + TX, mxx = A1 * xb - B * ya + TX;
@@ -233,19 +236,19 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
 
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = x0 + lx;
-    const float fx = (float)x;
+    const float fx = (float)(x + roi.x);
     const float A1x = A1 * fx, Bx = B * fx;
     // a quad of lanes owns 4 pixels = 12 output bytes; it stores them as 3 aligned dwords when the whole
     // quad is inside the row and the row is dword aligned, else byte by byte
     const int m = lx & 3;
-    const bool quad_in = (x | 3) < w;
+    const bool quad_in = (x | 3) < roi.w;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int y = y0 + wv * 4 + k;
-        if (y >= h) break;                               // wave-uniform
+        if (y >= roi.h) break;                           // wave-uniform
         uint32_t o[3] = {0, 0, 0};
-        if (x < w) {
-            const float fy = (float)y;
+        if (x < roi.w) {
+            const float fy = (float)(y + roi.y);
             const float Wx = A1x - B * fy + TX;          // generators.cpp:141
             const float Wy = Bx + A1 * fy + TY;          // generators.cpp:142
             if (!fits) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
             const uint32_t d = quad_pack_bgr(p, m);          // every lane of the wave takes part in the shuffle
             if (quad_in && ((((uintptr_t)orow) & 3) == 0)) {
                 if (m < 3) *(uint32_t*)((uint8_t*)orow + (size_t)(x & ~3) * 3 + 4 * m) = d;
-            } else if (x < w) {
+            } else if (x < roi.w) {
                 orow[(size_t)x * 3] = (T)o[0];
                 orow[(size_t)x * 3 + 1] = (T)o[1];
                 orow[(size_t)x * 3 + 2] = (T)o[2];
@@ -313,12 +316,12 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
         } else {
             uint32_t d0, d1;
             pair_pack_bgr16(o, x & 1, d0, d1);
-            const bool pair_in = (x | 1) < w;
+            const bool pair_in = (x | 1) < roi.w;
             if (pair_in && ((((uintptr_t)orow) & 3) == 0)) {
                 uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
                 if (x & 1) q[2] = d0;
                 else { q[0] = d0; q[1] = d1; }
-            } else if (x < w) {
+            } else if (x < roi.w) {
                 orow[(size_t)x * 3] = (T)o[0];
                 orow[(size_t)x * 3 + 1] = (T)o[1];
                 orow[(size_t)x * 3 + 2] = (T)o[2];
@@ -333,15 +336,15 @@ namespace vsk {
 
 template <typename T>
 static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border, T* dst,
-                            int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, hipStream_t s) {
-    const int tiles_x = (w + WT_W - 1) / WT_W, tiles_y = (h + WT_H - 1) / WT_H;
+                            int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
+    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + WT_H - 1) / WT_H;
     const long long total = (long long)tiles_x * tiles_y * n_frames;
     if (total > 0x3fffffffLL) return hipErrorNotSupported;
     const int chunk = (int)((total + 7) / 8);
     dim3 grid((unsigned)(chunk * 8)), block(256);
 #define VS_LAUNCH(M, Bd) \
     hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs, \
-                       tiles_x, tiles_x * tiles_y, (int)total, chunk, maxv)
+                       tiles_x, tiles_x * tiles_y, (int)total, chunk, maxv, roi)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
@@ -351,12 +354,12 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
 }
 
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
-                       int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, hipStream_t s) {
+                       int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
     if (bits == 8)
         return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, mode, border, (uint8_t*)dst, dst_stride, n_frames,
-                                  src_fs, dst_fs, (float)max_value, s);
+                                  src_fs, dst_fs, (float)max_value, roi, s);
     return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, mode, border, (uint16_t*)dst, dst_stride, n_frames,
-                               src_fs, dst_fs, (float)max_value, s);
+                               src_fs, dst_fs, (float)max_value, roi, s);
 }
 
 }  // namespace vsk
