@@ -154,45 +154,69 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
     g1 += (size_t)frame * pyr_frame_stride;
     const int x0 = txi * PD_TW, y0 = tyi * PD_TH;          // level-1 tile origin
     const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;          // level-0 origin of the staged tile
+    // gray = (B*3735 + G*19235 + R*9798 + 16384) >> 15 on the dot-product units.  u8: the pixel's bytes {B,G,R,x} against the
+    // weights split into high and low bytes (x meets weight 0): two v_dot4_u32_u8 + one shift-add; the four pixels of a
+    // 12-byte group are three v_alignbyte away.  u16: {B,G} . {3735,19235} is one v_dot2_u32_u16, R one multiply-add.
+    constexpr uint32_t kWLo = (3735u & 255u) | ((19235u & 255u) << 8) | ((9798u & 255u) << 16);
+    constexpr uint32_t kWHi = (3735u >> 8) | ((19235u >> 8) << 8) | ((9798u >> 8) << 16);
+    const bool frame_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * sizeof(T))) & 3u) == 0;   // uniform
+    const bool g0_aligned = ((((uintptr_t)g0) | (uintptr_t)w) & 3u) == 0;
     for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
         const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
         const int gy = clampi(iy0 + r, 0, h - 1), gx = ix0 + c4;
         const T* row = src + (size_t)gy * src_stride;
         uint32_t v;
-        if (sizeof(T) == 1 && gx >= 0 && gx + 3 < w && ((((uintptr_t)(row + gx * 3)) & 3) == 0)) {
-            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-            const u32x3 q = *(const u32x3*)((const uint8_t*)row + gx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-            const uint32_t px[12] = {q.x & 255, (q.x >> 8) & 255, (q.x >> 16) & 255, q.x >> 24, q.y & 255, (q.y >> 8) & 255,
-                                     (q.y >> 16) & 255, q.y >> 24, q.z & 255, (q.z >> 8) & 255, (q.z >> 16) & 255, q.z >> 24};
-            v = 0;
+        if (frame_aligned && gx >= 0 && gx + 3 < w) {       // gx is a multiple of 4 pixels: 12 / 24 bytes, dword aligned
+            uint32_t g[4];
+            if (sizeof(T) == 1) {
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                const u32x3 q = *(const u32x3*)((const uint8_t*)row + gx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                const uint32_t px[4] = {q.x, __builtin_amdgcn_alignbyte(q.y, q.x, 3), __builtin_amdgcn_alignbyte(q.z, q.y, 2), q.z >> 8};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t g = (px[3 * k] * 3735u + px[3 * k + 1] * 19235u + px[3 * k + 2] * 9798u + 16384u) >> 15;
-                g >>= shift_to_8;
-                v |= (g > 255u ? 255u : g) << (8 * k);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t hi = __builtin_amdgcn_udot4(px[k], kWHi, 0u, false);
+                    const uint32_t lo = __builtin_amdgcn_udot4(px[k], kWLo, 16384u, false);
+                    g[k] = ((hi << 8) + lo) >> 15;            // <= 255 for 8-bit input: no clamp
+                    g[k] >>= shift_to_8;
+                }
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 qa = *(const u32x4*)((const uint16_t*)row + gx * 3);          // B0G0 R0B1 G1R1 B2G2
+                const u32x2 qb = *(const u32x2*)((const uint16_t*)row + gx * 3 + 8);      // R2B3 G3R3
+                const uint32_t bg[4] = {qa.x, __builtin_amdgcn_alignbyte(qa.z, qa.y, 2), qa.w, __builtin_amdgcn_alignbyte(qb.y, qb.x, 2)};
+                const uint32_t rr[4] = {qa.y & 0xffffu, qa.z >> 16, qb.x & 0xffffu, qb.y >> 16};
+                constexpr uint32_t kWBG = 3735u | (19235u << 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bg[k]), __builtin_bit_cast(us2, kWBG), 16384u, false);
+                    g[k] = (t + rr[k] * 9798u) >> 15;
+                    g[k] >>= shift_to_8;
+                    g[k] = g[k] > 255u ? 255u : g[k];
+                }
             }
+            v = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
         } else {
             v = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) v |= gray_of(row + (size_t)clampi(gx + k, 0, w - 1) * 3, shift_to_8) << (8 * k);
         }
         *(uint32_t*)&tile[r][c4] = v;
-    }
-    __syncthreads();
-    // level 0: this workgroup's own 128 x 32 block = tile rows 2..33, columns 4..131
-    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
-        const int r = i >> 5, c4 = (i & 31) * 4;
-        const int gy = 2 * y0 + r, gx = 2 * x0 + c4;
-        if (gy < h && gx < w) {
-            const uint32_t v = *(const uint32_t*)&tile[r + 2][c4 + 4];
-            uint8_t* dst = g0 + (size_t)gy * w + gx;
-            if (gx + 3 < w && ((((uintptr_t)dst) & 3) == 0)) {
-                *(uint32_t*)dst = v;
-            } else {
-                for (int k = 0; k < 4 && gx + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
+        // level 0: the part of the staged tile that is this workgroup's own 128 x 32 block (rows 2..33, columns 4..131)
+        if (r >= 2 && r < 34 && c4 >= 4 && c4 < 132) {
+            const int oy = iy0 + r, ox = gx;                  // = 2*y0 + (r-2), 2*x0 + (c4-4): never negative here
+            if (oy < h && ox < w) {
+                uint8_t* dst = g0 + (size_t)oy * w + ox;
+                if (g0_aligned && ox + 3 < w) {
+                    *(uint32_t*)dst = v;
+                } else {
+                    for (int k = 0; k < 4 && ox + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
+                }
             }
         }
     }
+    __syncthreads();
     pyr_passes(tile, vsum, x0, y0, g1, ow, oh, ow);
 }
 
