@@ -98,10 +98,17 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     __builtin_memcpy(&r, p, 4);
     return r;
 }
+// The same load through a pointer known to address global memory.  Inside a function that is not inlined into its kernel
+// a plain pointer is generic and every access becomes a flat_load (aperture check, both wait counters); the cast keeps
+// the gathers on global_load.
+#define VS_GLOBAL_AS __attribute__((address_space(1)))
+typedef const VS_GLOBAL_AS uint8_t* vs_gbytes;
+struct __attribute__((packed)) vs_packed_u32 { uint32_t v; };
+__device__ __forceinline__ uint32_t load_u32_unaligned(vs_gbytes p) { return ((const VS_GLOBAL_AS vs_packed_u32*)p)->v; }
 
-// requires w >= 4
-__device__ __forceinline__ float lanczos_sample_u8_fast(const uint8_t* __restrict__ img, int w, int h, int stride,
-                                                        float Wx, float Wy) {
+// requires w >= 4.  P: const uint8_t* (generic) or vs_gbytes (global)
+template <typename P>
+__device__ __forceinline__ float lanczos_sample_u8_fast(P img, int w, int h, int stride, float Wx, float Wy) {
     const float flx = floorf(Wx), fly = floorf(Wy);
     const int ix = (int)flx, iy = (int)fly;
     const f2v fr = {Wx - flx, Wy - fly};

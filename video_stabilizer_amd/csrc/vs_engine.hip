@@ -123,6 +123,14 @@ __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __re
 //   xy  u32    x | y << 16                       (SelectedPixels, alignment.cpp:530-531)
 //   tv  f32    float(template(min(x,w-1), min(y,h-1)))   -- constant over the iterations (generators.cpp:554-556)
 //   j   float4 the four Jacobian components     (SelectedJacobian, alignment.cpp:532-534)
+// a value that is the same in every lane, moved to the scalar registers (see gn_level)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 struct PointRecs {
     uint32_t* xy;
     float* tv;
@@ -177,6 +185,7 @@ struct GnShared {
     double red[2][(kGnThreads / 64) * 10];
     double hinv[17];
     double c0[8];   // corners at level start
+    double c1[8];   // corners after the previous iteration (only wave 0 needs them: kept out of everybody's registers)
     double T[4];    // the transform after the current iteration, published by wave 0
     int flag;       // 0 iterate on / 1 converged / 2 out of iterations / 3 over max_displacement
 };
@@ -194,14 +203,21 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
 #else
 #define VS_GSTAMP(k)
 #endif
-    const uint32_t* __restrict__ rxy = rc.xy;
-    const float* __restrict__ rtv = rc.tv;
-    const float4* __restrict__ rj = rc.j;
+    // This function is not inlined, so its arguments arrive as per-lane values and generic pointers.  They are the same
+    // in every lane and all point to device memory: say so (readfirstlane -> SGPRs; address space 1 -> global_load with a
+    // scalar base instead of flat_load with a 64-bit address per lane).
+    const vs_gbytes gkey = (vs_gbytes)uniform_ptr(key);
+    w = __builtin_amdgcn_readfirstlane(w); h = __builtin_amdgcn_readfirstlane(h);
+    nsel = __builtin_amdgcn_readfirstlane(nsel); level = __builtin_amdgcn_readfirstlane(level);
+    const VS_GLOBAL_AS uint32_t* __restrict__ rxy = (const VS_GLOBAL_AS uint32_t*)uniform_ptr(rc.xy);
+    const VS_GLOBAL_AS float* __restrict__ rtv = (const VS_GLOBAL_AS float*)uniform_ptr(rc.tv);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));     // float4 records, read as a plain vector (HIP's float4 is a class)
+    const VS_GLOBAL_AS f32x4* __restrict__ rj = (const VS_GLOBAL_AS f32x4*)uniform_ptr(rc.j);
     // Hessian (alignment.cpp:278-332): upper triangle of sum j j^T over both sets, in fp64
     {
         double hacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int r = threadIdx.x; r < 2 * nsel; r += kGnThreads) {
-            const float4 jf = rj[r];
+            const f32x4 jf = rj[r];
             const double j[4] = {(double)jf.x, (double)jf.y, (double)jf.z, (double)jf.w};
             int k = 0;
 #pragma unroll
@@ -238,12 +254,12 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
     // The scalar part of an iteration (dt = Hinv b, compose, corner test: ~300 dependent fp64 instructions) runs on
     // wave 0 only and is published through LDS; the other 15 waves only sample.  Two barriers per iteration.
     const bool w0 = threadIdx.x < 64;
-    double c1[8];
     if (w0) {
+        double c1[8];
         warp_corners(T, w, h, c1);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) sh.c0[i] = c1[i];
+            for (int i = 0; i < 8; i++) { sh.c0[i] = c1[i]; sh.c1[i] = c1[i]; }
         }
     }
     const double scale = 1.0 / w;   // alignment.cpp:629
@@ -258,11 +274,11 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
             double* a = acc + 4 * set;
             for (int r = set * nsel + threadIdx.x; r < (set + 1) * nsel; r += kGnThreads) {
                 const uint32_t xy = rxy[r];
-                const float4 jf = rj[r];
+                const f32x4 jf = rj[r];
                 const float ox = (float)(xy & 0xffffu), oy = (float)(xy >> 16);
                 const float Wx = A1 * ox - P[1] * oy + P[2];
                 const float Wy = P[1] * ox + A1 * oy + P[3];
-                const float warped = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
+                const float warped = lanczos_sample_u8_fast(gkey, w, h, w, Wx, Wy);
                 const float residual = rtv[r] - warped;
                 a[0] += (double)(jf.x * residual);
                 a[1] += (double)(jf.y * residual);
@@ -293,11 +309,17 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
             double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
             double Tn[4];
             compose(delta, T, Tn);   // alignment.cpp:639
-            double c2[8];
+            double c1[8], c2[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) c1[i] = sh.c1[i];      // wave 0 only: LDS accesses of one wave are in program order
             warp_corners(Tn, w, h, c2);
             const double disp12 = corner_move(c2, c1);
 #pragma unroll
             for (int i = 0; i < 8; i++) c1[i] = c2[i];
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) sh.c1[i] = c2[i];
+            }
             int f = 0;
             if (disp12 < gp.threshold) f = 1;
             else if (iter >= gp.max_iters - 1) f = 2;
@@ -387,7 +409,15 @@ struct SelShared {
 // but every exchange is a wave shuffle and LDS accesses of a single wave execute in program order, so a round
 // costs no block barrier (most rounds of an introselect run are on small ranges: the block-wide rounds take
 // ~1.7 us each, these ~0.3 us).  Called by wave 0 only, with all 64 lanes.
-__device__ __forceinline__ void median_to_first(uint32_t* __restrict__ a, int first, int last) {
+// The selection arrays live in LDS.  The functions below are not inlined, so their pointer arguments arrive generic (every
+// access a flat_load / flat_store) and their scalars per lane; each function re-types them on entry: address space 3 for
+// the arrays (ds_read / ds_write), readfirstlane for the wave-uniform scalars.
+#define VS_LDS_AS __attribute__((address_space(3)))
+typedef VS_LDS_AS uint32_t lds_u32;
+typedef VS_LDS_AS uint16_t lds_u16;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void median_to_first(lds_u32* __restrict__ a, int first, int last) {
     // __unguarded_partition_pivot: __move_median_to_first(first, first+1, mid, last-1)
     const int mid = first + (last - first) / 2;
     const int ia = first + 1, ib = mid, ic = last - 1;
@@ -400,8 +430,11 @@ __device__ __forceinline__ void median_to_first(uint32_t* __restrict__ a, int fi
     const uint32_t t = a[first]; a[first] = a[m]; a[m] = t;
 }
 
-__device__ __noinline__ int introselect_wave(uint32_t* __restrict__ a, uint16_t* __restrict__ posR, int first, int last,
+__device__ __noinline__ int introselect_wave(uint32_t* __restrict__ a_g, uint16_t* __restrict__ posR_g, int first, int last,
                                              int nth, int depth) {
+    lds_u32* __restrict__ a = (lds_u32*)a_g;
+    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
+    first = uni(first); last = uni(last); nth = uni(nth); depth = uni(depth);
     const int lane = threadIdx.x & 63;
     while (last - first > 3) {
         if (depth == 0) return 1;
@@ -471,8 +504,12 @@ __device__ __noinline__ int introselect_wave(uint32_t* __restrict__ a, uint16_t*
 
 // returns 0 on success, 1 when libstdc++ would have fallen back to heap-select (depth limit): the
 // caller then re-runs the pair through the host path.
-__device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t* __restrict__ posR, SelShared& ss,
+__device__ __noinline__ int introselect_block(uint32_t* __restrict__ a_g, uint16_t* __restrict__ posR_g, SelShared& ss_g,
                                               int n, int nth) {
+    lds_u32* __restrict__ a = (lds_u32*)a_g;
+    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
+    VS_LDS_AS SelShared& ss = *(VS_LDS_AS SelShared*)&ss_g;
+    n = uni(n); nth = uni(nth);
     if (n == 0 || nth == n) return 0;                 // std::nth_element's early return
     int first = 0, last = n;
     int depth = 2 * (31 - __clz(n));                  // std::__lg(n) * 2
@@ -563,7 +600,7 @@ __device__ __noinline__ int introselect_block(uint32_t* __restrict__ a, uint16_t
     }
     // the rest (including the final insertion sort) on one wave
     if (!fail && wave == 0) {
-        if (introselect_wave(a, posR, first, last, nth, depth)) ss.red_k[0] = -1; else ss.red_k[0] = 0;
+        if (introselect_wave(a_g, posR_g, first, last, nth, depth)) ss.red_k[0] = -1; else ss.red_k[0] = 0;
     }
     __syncthreads();
     return fail || ss.red_k[0] < 0 ? 1 : 0;
@@ -577,9 +614,12 @@ __device__ __noinline__ int introselect_dual(uint32_t* __restrict__ aX, uint16_t
                                              uint16_t* __restrict__ pRY, SelShared* ss2, int n, int nth) {
     if (n == 0 || nth == n) return 0;                 // std::nth_element's early return (same n, nth for both sets)
     const int tid = threadIdx.x, half = tid >> 9, gt = tid & 511, lane = tid & 63, gw = gt >> 6;
-    uint32_t* __restrict__ a = half ? aY : aX;
-    uint16_t* __restrict__ posR = half ? pRY : pRX;
-    SelShared& ss = ss2[half];
+    n = uni(n); nth = uni(nth);
+    uint32_t* a_g = half ? aY : aX;                   // uniform per wave (a half is 8 whole waves)
+    uint16_t* posR_g = half ? pRY : pRX;
+    lds_u32* __restrict__ a = (lds_u32*)a_g;
+    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
+    VS_LDS_AS SelShared& ss = *(VS_LDS_AS SelShared*)&ss2[half];
     constexpr int kWaveRange = VS_SEL_WAVE_RANGE, kSmall = VS_SEL_THREADS, kHalf = kGnThreads / 2, kHalfWaves = kHalf / 64;
     int first = 0, last = n;
     int depth = 2 * (31 - __clz(n));
@@ -657,7 +697,7 @@ __device__ __noinline__ int introselect_dual(uint32_t* __restrict__ aX, uint16_t
         need = begin_round();     // all swaps of this round completed before the barrier above
     }
     int r = 0;
-    if (!fail && gw == 0) r = introselect_wave(a, posR, first, last, nth, depth);
+    if (!fail && gw == 0) r = introselect_wave(a_g, posR_g, first, last, nth, depth);
     if (gt == 0) ss.red_k[0] = (fail || r) ? -1 : 0;
     __syncthreads();
     return (ss2[0].red_k[0] < 0 || ss2[1].red_k[0] < 0) ? 1 : 0;
