@@ -272,18 +272,27 @@ __device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ k
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int set = 0; set < 2; set++) {
             double* a = acc + 4 * set;
-            for (int r = set * nsel + threadIdx.x; r < (set + 1) * nsel; r += kGnThreads) {
-                const uint32_t xy = rxy[r];
+            // the point's coordinates are fetched one point ahead: the gathers need them for their addresses, so without
+            // the prefetch every point pays two dependent memory round trips (record, then pixels)
+            const int end = (set + 1) * nsel;
+            int r = set * nsel + threadIdx.x;
+            uint32_t xy_next = r < end ? rxy[r] : 0u;
+            while (r < end) {
+                const uint32_t xy = xy_next;
+                const int rn = r + kGnThreads;
+                if (rn < end) xy_next = rxy[rn];
                 const f32x4 jf = rj[r];
+                const float tv = rtv[r];
                 const float ox = (float)(xy & 0xffffu), oy = (float)(xy >> 16);
                 const float Wx = A1 * ox - P[1] * oy + P[2];
                 const float Wy = P[1] * ox + A1 * oy + P[3];
                 const float warped = lanczos_sample_u8_fast(gkey, w, h, w, Wx, Wy);
-                const float residual = rtv[r] - warped;
+                const float residual = tv - warped;
                 a[0] += (double)(jf.x * residual);
                 a[1] += (double)(jf.y * residual);
                 a[2] += (double)(jf.z * residual);
                 a[3] += (double)(jf.w * residual);
+                r = rn;
             }
         }
         if (iter == 0) VS_GSTAMP(3);
