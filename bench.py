@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
     ap.add_argument("--default-levels", action="store_true",
                     help="reference default pyramid_min_width/height = 20 (6 levels at 1080p, 7 at 4K) instead of 256")
+    ap.add_argument("--warp-mode", default="exact", choices=["exact", "fast"],
+                    help="exact = VS_WARP_LANCZOS2 (bit-identical to the CPU restatement, the default and the parity claim); "
+                         "fast = VS_WARP_LANCZOS2_FAST (opt-in fused-multiply-add variant, within 1 LSB)")
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     args = ap.parse_args()
@@ -164,7 +167,8 @@ def main():
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
                 capi.bgr_image_warp_batch_device(all_frames.data_ptr(), N, W, H, 3, 8 if bits == 8 else 16, ts, warped.data_ptr(),
-                                                 capi.WARP_LANCZOS2, capi.BORDER_CLAMP, max_value=max_value,
+                                                 capi.WARP_LANCZOS2 if args.warp_mode == "exact" else capi.WARP_LANCZOS2_FAST,
+                                                 capi.BORDER_CLAMP, max_value=max_value,
                                                  stream=stream.cuda_stream)
                 if timed:
                     b.record(stream)
@@ -220,7 +224,8 @@ def main():
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
                        "phase_correlate": bool(args.phase_correlate),
-                       "warp": None if (args.no_warp and not wl["stabilizer"]) else "bgr_image_warp lanczos2", "resident": "HBM"},
+                       "warp": None if (args.no_warp and not wl["stabilizer"]) else
+                       ("bgr_image_warp lanczos2" if args.warp_mode == "exact" else "bgr_image_warp lanczos2, opt-in fast mode (<= 1 LSB from exact)"), "resident": "HBM"},
             ("outputs_per_step" if wl["stabilizer"] else "aligned_per_step"): total_good // args.steps,
         }
         if tm:

@@ -35,7 +35,11 @@ extern "C" {
 
 enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
 enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR16 = 2 };
-enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1 };
+/* VS_WARP_LANCZOS2: the reference sampler's exact sequence of fp32 roundings (bit-identical to the CPU restatement).
+ * VS_WARP_LANCZOS2_FAST: opt-in, same sampler with fused multiply-adds and one refined reciprocal; integer outputs stay
+ * within 1 LSB of the exact mode (> 99.9 % identical), ~1.4x faster.  Tuned for 3-channel integer frames; other
+ * layouts are served by the exact arithmetic. */
+enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1, VS_WARP_LANCZOS2_FAST = 2 };
 enum { VS_BORDER_CLAMP = 0, VS_BORDER_CONSTANT = 1 };
 /* how the per-level "keep the best 80 %" subset is chosen (alignment.cpp:460-486) */
 enum {

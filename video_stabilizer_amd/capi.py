@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VS_AMD_LIB", os.path.join(_HERE, "libvs_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
-WARP_LANCZOS2, WARP_BILINEAR = 0, 1
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE = 0, 1
 

@@ -318,7 +318,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     const vsk::Roi roi = roi_in ? *roi_in : vsk::Roi{0, 0, w, h};
     VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.x + roi.w <= w && roi.y + roi.h <= h);
     VS_ARG(src_stride >= w * channels && dst_stride >= roi.w * channels);
-    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR);
+    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST);
     VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
     VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(roi.w, roi.h, dst_stride, channels)));
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -338,8 +338,8 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
         e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
                              dst_fs, roi, s);
-    if (e == hipErrorNotSupported)
-        e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
+    if (e == hipErrorNotSupported)   // layouts without a tuned kernel: the fast mode is served by the exact arithmetic
+        e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode == VS_WARP_LANCZOS2_FAST ? VS_WARP_LANCZOS2 : mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);
     VS_HIP(e);
     VS_TRY(g_param_ring.fence(pdev, (size_t)n_frames, s));

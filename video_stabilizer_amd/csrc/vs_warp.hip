@@ -102,6 +102,24 @@ __device__ __forceinline__ f2 lanczos2_pk(f2 x) {
     return v;
 }
 
+// VS_WARP_LANCZOS2_FAST: the same polynomial with every multiply-add fused (v_pk_fma_f32): one rounding per Horner step
+// instead of two.  Not the reference's sequence of roundings any more -- results stay within the north star's 1 ULP /
+// 1 LSB gate of the exact kernel (tests/test_kernels_gpu.py), at ~0.6x the VALU work.
+template <bool EDGE_X, bool EDGE_Y>
+__device__ __forceinline__ f2 lanczos2_pk_fma(f2 x) {
+    const f2 x2 = x * x;
+    f2 v = 0.000858519f;
+    v = __builtin_elementwise_fma(v, x2, (f2)(-0.0158853f));
+    v = __builtin_elementwise_fma(v, x2, (f2)(0.128693f));
+    v = __builtin_elementwise_fma(v, x2, (f2)(-0.583468f));
+    v = __builtin_elementwise_fma(v, x2, (f2)(1.52229f));
+    v = __builtin_elementwise_fma(v, x2, (f2)(-2.05238f));
+    v = __builtin_elementwise_fma(v, x2, (f2)(0.999861f));
+    if (EDGE_X) v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
+    if (EDGE_Y) v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
+    return v;
+}
+
 // 4 adjacent lanes hold one BGR pixel each (p = B | G<<8 | R<<16); lanes 0..2 of the quad assemble the three
 // dwords of the 12-byte group from their own pixel and their right neighbour's: bytes m..m+3 of {own, next}.
 __device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, int m) {
@@ -120,7 +138,7 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
         if (BORDER == 1) return (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : (float)src[(size_t)sy * stride + (size_t)sx * 3 + c];
         return (float)src[(size_t)clampi(sy, 0, h - 1) * stride + (size_t)clampi(sx, 0, w - 1) * 3 + c];
     };
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {   // the rare tiles on this path keep the exact arithmetic in the fast mode too
         float wx[4], wy[4];
         lanczos_weights4(frx, wx);
         lanczos_weights4(fry, wy);
@@ -284,6 +302,32 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
                     o[0] = store_u(qb, maxv);
                     o[1] = store_u(qg, maxv);
                     o[2] = store_u(qr, maxv);
+                } else if (MODE == 2) {
+                    // VS_WARP_LANCZOS2_FAST: fused multiply-adds for the weights and the tap sums, one refined reciprocal
+                    const f2 frx = {fr.x, fr.x}, fry = {fr.y, fr.y};
+                    const f2 wx01 = lanczos2_pk_fma<true, false>(f2{-1.0f, 0.0f} - frx), wx23 = lanczos2_pk_fma<false, true>(f2{1.0f, 2.0f} - frx);
+                    const f2 wy01 = lanczos2_pk_fma<true, false>(f2{-1.0f, 0.0f} - fry), wy23 = lanczos2_pk_fma<false, true>(f2{1.0f, 2.0f} - fry);
+                    const float wy[4] = {wy01.x, wy01.y, wy23.x, wy23.y};
+                    const f4* t = tile + (iy - 1 - sy_lo) * WS_W + (ix - 1 - sx_lo);
+                    f2 nbg = {0.f, 0.f}, nrd = {0.f, 0.f};
+#pragma unroll
+                    for (int ry = 0; ry < 4; ry++) {
+                        const f2 wyy = {wy[ry], wy[ry]};
+                        const f2 p01 = wx01 * wyy, p23 = wx23 * wyy;
+                        const float w2d[4] = {p01.x, p01.y, p23.x, p23.y};
+#pragma unroll
+                        for (int rx = 0; rx < 4; rx++) {
+                            const f4 v = t[ry * WS_W + rx];
+                            const f2 ww = {w2d[rx], w2d[rx]};
+                            nbg = __builtin_elementwise_fma(ww, f2{v.x, v.y}, nbg);
+                            nrd = __builtin_elementwise_fma(ww, f2{v.z, v.w}, nrd);
+                        }
+                    }
+                    float r = __builtin_amdgcn_rcpf(nrd.y);
+                    r = __builtin_fmaf(__builtin_fmaf(-nrd.y, r, 1.0f), r, r);       // one Newton step: ~0.5 ULP reciprocal
+                    o[0] = store_u(nbg.x * r, maxv);
+                    o[1] = store_u(nbg.y * r, maxv);
+                    o[2] = store_u(nrd.x * r, maxv);
                 } else {
                     const f4* t = tile + (iy - sy_lo) * WS_W + (ix - sx_lo);
                     const f4 a0 = t[0], a1 = t[1], b0 = t[WS_W], b1 = t[WS_W + 1];
@@ -347,6 +391,8 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
                        tiles_x, tiles_x * tiles_y, (int)total, chunk, maxv, roi)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
+    else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
+    else if (mode == 2) VS_LAUNCH(2, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
     else VS_LAUNCH(1, 1);
 #undef VS_LAUNCH
