@@ -5,7 +5,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../libvs_amd.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 ${VS_RESOURCE_REPORT:+-Rpass-analysis=kernel-resource-usage} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 ${VS_EXTRA_FLAGS:-} -O3 ${VS_RESOURCE_REPORT:+-Rpass-analysis=kernel-resource-usage} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result"
 SRCS="vs_kernels.hip vs_warp.hip vs_phase.hip vs_capi.hip vs_engine.hip vs_host.cpp"
 mkdir -p "$HERE/build"
 objs=""
@@ -14,7 +14,7 @@ for f in $SRCS; do
   [ -f "$HERE/$f" ] || continue
   o="$HERE/build/${f%.*}.o"
   objs="$objs $o"
-  if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ -n "$(find "$HERE" -maxdepth 1 -name '*.hpp' -newer "$o" -print -quit)" ] \
+  if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ -n "$(find "$HERE" -maxdepth 1 \( -name '*.hpp' -o -name '*.inc' \) -newer "$o" -print -quit)" ] \
      || [ "$HERE/../../include/vs_amd.h" -nt "$o" ]; then
     case "$f" in
       *.hip) "$HIPCC" $FLAGS -c "$HERE/$f" -o "$o" & pids="$pids $!" ;;

@@ -35,7 +35,6 @@ using namespace vsd;
 namespace {
 
 constexpr int kMaxLevels = 16;
-constexpr int kGnThreads = 1024;
 // on-device selection keeps (abs_delta,index) u32 + a u16 rank table per tile in LDS: 6 B x tiles <= 160 KB less
 // the static part; index fits 16 bits; a thread's chunk fits a 32-bit mask
 constexpr int kSelectCap = 26000;
@@ -174,561 +173,6 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
     write_rec(pair_recs(recs, recs_pair, p, nt_cap), set * nsel + j, lm, jac, nt, t, tmpl, w, h);
 }
 
-// ---- Gauss-Newton level solver: alignment.cpp:548-688 -------------------------------------------
-// Runs inside a workgroup that owns one frame pair.  H = sum j j^T (fp64) -> cond / Tikhonov /
-// pseudo-inverse once, then up to max_iters iterations of { sparse_ica (generators.cpp:429-596) ->
-// dt = Hinv b -> delta.compose(T) -> corner test }, all without leaving the device.  Every thread
-// carries the (identical) fp64 transform in registers; the only exchange per iteration is the block
-// sum.  T is updated in place (including the x2 of TX,TY when moving to a finer level).
-// Returns 0 ok / 2 max iterations / 3 over displacement; *iters_out, *cond_out as the reference logs.
-struct GnShared {
-    double red[2][(kGnThreads / 64) * 10];
-    double hinv[17];
-    double c0[8];   // corners at level start
-    double c1[8];   // corners after the previous iteration (only wave 0 needs them: kept out of everybody's registers)
-    double T[4];    // the transform after the current iteration, published by wave 0
-    int flag;       // 0 iterate on / 1 converged / 2 out of iterations / 3 over max_displacement
-};
-
-__device__ __noinline__ int gn_level(GnShared& sh, const uint8_t* __restrict__ key, int w, int h, int nsel,
-                                        const PointRecs& rc, int level, const GnParams& gp, double T[4], int* iters_out,
-                                        double* cond_out
-#ifdef VS_PROFILE_STAMPS
-                                        , unsigned long long* gtk
-#endif
-                                        ) {
-#ifdef VS_PROFILE_STAMPS
-    gtk[0] = __builtin_amdgcn_s_memtime();
-#define VS_GSTAMP(k) gtk[k] = __builtin_amdgcn_s_memtime()
-#else
-#define VS_GSTAMP(k)
-#endif
-    // This function is not inlined, so its arguments arrive as per-lane values and generic pointers.  They are the same
-    // in every lane and all point to device memory: say so (readfirstlane -> SGPRs; address space 1 -> global_load with a
-    // scalar base instead of flat_load with a 64-bit address per lane).
-    const vs_gbytes gkey = (vs_gbytes)uniform_ptr(key);
-    w = __builtin_amdgcn_readfirstlane(w); h = __builtin_amdgcn_readfirstlane(h);
-    nsel = __builtin_amdgcn_readfirstlane(nsel); level = __builtin_amdgcn_readfirstlane(level);
-    const VS_GLOBAL_AS uint32_t* __restrict__ rxy = (const VS_GLOBAL_AS uint32_t*)uniform_ptr(rc.xy);
-    const VS_GLOBAL_AS float* __restrict__ rtv = (const VS_GLOBAL_AS float*)uniform_ptr(rc.tv);
-    typedef float f32x4 __attribute__((ext_vector_type(4)));     // float4 records, read as a plain vector (HIP's float4 is a class)
-    const VS_GLOBAL_AS f32x4* __restrict__ rj = (const VS_GLOBAL_AS f32x4*)uniform_ptr(rc.j);
-    // Hessian (alignment.cpp:278-332): upper triangle of sum j j^T over both sets, in fp64
-    {
-        double hacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = threadIdx.x; r < 2 * nsel; r += kGnThreads) {
-            const f32x4 jf = rj[r];
-            const double j[4] = {(double)jf.x, (double)jf.y, (double)jf.z, (double)jf.w};
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = a; b < 4; b++) hacc[k++] += j[a] * j[b];
-        }
-        wave_partials<10>(hacc, sh.red[0]);
-        __syncthreads();
-        VS_GSTAMP(1);
-        if (threadIdx.x < 64) {   // one wave adds the per-wave partials and does the 4x4 eigen work; the others wait
-#pragma unroll
-            for (int k = 0; k < 10; k++) {
-                double t = 0.0;
-                for (int wv = 0; wv < kGnThreads / 64; wv++) t += sh.red[0][wv * 10 + k];
-                hacc[k] = t;
-            }
-            double H[16], Hinv[16];
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = a; b < 4; b++) { H[a * 4 + b] = hacc[k]; H[b * 4 + a] = hacc[k]; k++; }
-            double cond = condition_and_invert(H, Hinv);
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) sh.hinv[i] = Hinv[i];
-                sh.hinv[16] = cond;
-            }
-        }
-        __syncthreads();
-    }
-    VS_GSTAMP(2);
-    // The scalar part of an iteration (dt = Hinv b, compose, corner test: ~300 dependent fp64 instructions) runs on
-    // wave 0 only and is published through LDS; the other 15 waves only sample.  Two barriers per iteration.
-    const bool w0 = threadIdx.x < 64;
-    if (w0) {
-        double c1[8];
-        warp_corners(T, w, h, c1);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) { sh.c0[i] = c1[i]; sh.c1[i] = c1[i]; }
-        }
-    }
-    const double scale = 1.0 / w;   // alignment.cpp:629
-    int iters = 0, flag = 0;
-    for (int iter = 0; iter < gp.max_iters; iter++) {
-        iters++;
-        float P[4];
-        ul_params_sparse(T, w, h, P);
-        const float A1 = 1.0f + P[0];
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int set = 0; set < 2; set++) {
-            double* a = acc + 4 * set;
-            // the point's coordinates are fetched one point ahead: the gathers need them for their addresses, so without
-            // the prefetch every point pays two dependent memory round trips (record, then pixels)
-            const int end = (set + 1) * nsel;
-            int r = set * nsel + threadIdx.x;
-            uint32_t xy_next = r < end ? rxy[r] : 0u;
-            while (r < end) {
-                const uint32_t xy = xy_next;
-                const int rn = r + kGnThreads;
-                if (rn < end) xy_next = rxy[rn];
-                const f32x4 jf = rj[r];
-                const float tv = rtv[r];
-                const float ox = (float)(xy & 0xffffu), oy = (float)(xy >> 16);
-                const float Wx = A1 * ox - P[1] * oy + P[2];
-                const float Wy = P[1] * ox + A1 * oy + P[3];
-                const float warped = lanczos_sample_u8_fast(gkey, w, h, w, Wx, Wy);
-                const float residual = tv - warped;
-                a[0] += (double)(jf.x * residual);
-                a[1] += (double)(jf.y * residual);
-                a[2] += (double)(jf.z * residual);
-                a[3] += (double)(jf.w * residual);
-                r = rn;
-            }
-        }
-        if (iter == 0) VS_GSTAMP(3);
-        wave_partials<8>(acc, sh.red[0]);
-        __syncthreads();
-        if (iter == 0) VS_GSTAMP(4);
-        if (w0) {
-            double b[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                double sx = 0.0, sy = 0.0;
-                for (int wv = 0; wv < kGnThreads / 64; wv++) { sx += sh.red[0][wv * 8 + c]; sy += sh.red[0][wv * 8 + 4 + c]; }
-                b[c] = (sx + sy) * 0.5f;   // generators.cpp:595
-            }
-            double dt[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) s += sh.hinv[r * 4 + k] * b[k];
-                dt[r] = s;
-            }
-            double delta[4] = {dt[0] * scale, dt[1] * scale, dt[2], dt[3]};
-            double Tn[4];
-            compose(delta, T, Tn);   // alignment.cpp:639
-            double c1[8], c2[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) c1[i] = sh.c1[i];      // wave 0 only: LDS accesses of one wave are in program order
-            warp_corners(Tn, w, h, c2);
-            const double disp12 = corner_move(c2, c1);
-#pragma unroll
-            for (int i = 0; i < 8; i++) c1[i] = c2[i];
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) sh.c1[i] = c2[i];
-            }
-            int f = 0;
-            if (disp12 < gp.threshold) f = 1;
-            else if (iter >= gp.max_iters - 1) f = 2;
-            if (f == 1) {   // alignment.cpp:670-677: total corner move of the level
-                double c0[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) c0[i] = sh.c0[i];
-                if (corner_move(c0, c1) > gp.max_displacement) f = 3;
-            }
-            if (threadIdx.x == 0) {
-                sh.T[0] = Tn[0]; sh.T[1] = Tn[1]; sh.T[2] = Tn[2]; sh.T[3] = Tn[3];
-                sh.flag = f;
-            }
-        }
-        __syncthreads();
-        if (iter == 0) VS_GSTAMP(5);
-        T[0] = sh.T[0]; T[1] = sh.T[1]; T[2] = sh.T[2]; T[3] = sh.T[3];
-        flag = sh.flag;
-        if (flag) break;
-    }
-    const int fail = flag == 1 ? 0 : flag;
-    if (!fail && level > 0) { T[2] *= 2.0; T[3] *= 2.0; }   // alignment.cpp:683-687
-    *iters_out = iters;
-    *cond_out = sh.hinv[16];
-    __syncthreads();   // sh.T / sh.flag / sh.red are rewritten by the next level
-    return fail;
-}
-
-// Per-level form (selection on the host between launches: VS_SELECT_STL_HOST)
-__global__ __launch_bounds__(kGnThreads) void vs_k_gn_level(PairState* __restrict__ states,
-                                                            const PairDesc* __restrict__ descs,
-                                                            const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                            size_t img_off, int w, int h, int nsel,
-                                                            uint8_t* __restrict__ recs, size_t recs_pair, int nt_cap,
-                                                            int level, GnParams gp) {
-    __shared__ GnShared sh;
-    const int p = blockIdx.x;
-    PairState& st = states[p];
-    if (st.status != 1) return;   // uniform for the block
-    const PairDesc d = descs[p];
-    const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + img_off;
-    const PointRecs rc = pair_recs(recs, recs_pair, p, nt_cap);
-    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
-    int iters;
-    double cond;
-#ifdef VS_PROFILE_STAMPS
-    unsigned long long gtk[6];
-    const int fail = gn_level(sh, key, w, h, nsel, rc, level, gp, T, &iters, &cond, gtk);
-#else
-    const int fail = gn_level(sh, key, w, h, nsel, rc, level, gp, T, &iters, &cond);
-#endif
-    __syncthreads();   // every thread has read st.T before thread 0 rewrites it
-    if (threadIdx.x == 0) {
-        st.iterations[level] = iters;
-        st.condition[level] = cond;
-        if (fail) { st.status = 0; st.fail_reason = fail; st.fail_level = level; }
-        st.T[0] = T[0]; st.T[1] = T[1]; st.T[2] = T[2]; st.T[3] = T[3];
-    }
-}
-
-// ---- on-device replica of libstdc++'s std::nth_element (bits/stl_algo.h, GCC 11) -----------------
-// alignment.cpp:466-486 calls std::nth_element(begin, begin+n, end, abs_delta <) and keeps the first
-// n elements.  Which tied elements survive, and in which order, is decided by libstdc++'s
-// __introselect: median-of-3 (first+1, mid, last-1) moved to `first`, an unguarded Hoare partition of
-// [first+1,last) around it, recurse into the side holding nth, insertion sort once <= 3 remain.
-// The Hoare sweep is sequential in the STL but depends only on the ORIGINAL values: its k-th swap
-// exchanges the k-th left stopper (a[i] >= pivot, scanning up) with the k-th right stopper
-// (a[j] <= pivot, scanning down) for as long as the former lies left of the latter, and it returns
-// the first left stopper that did not swap (or the last right stopper that did).  That is a pair of
-// prefix counts, so one partition is a few block-wide scans.  tests/test_select_gpu.py checks the
-// permutation against the host's std::nth_element on tie-heavy inputs.
-// Elements are packed (abs_delta << 16) | tile_index; only abs_delta takes part in comparisons.
-// selection tuning (tools/select_bench.py): ranges up to VS_SEL_WAVE_RANGE elements are finished by one wave; the
-// block-wide rounds give elements to VS_SEL_THREADS threads (more only when a 32-element chunk would not cover the range)
-#ifndef VS_SEL_WAVE_RANGE
-#define VS_SEL_WAVE_RANGE 256
-#endif
-#ifndef VS_SEL_THREADS
-#define VS_SEL_THREADS 256
-#endif
-struct SelShared {
-    int wl[kGnThreads / 64], wr[kGnThreads / 64];   // per-wave stopper counts
-    int red_k[kGnThreads / 64], red_c[kGnThreads / 64];
-};
-
-// One wave finishes the job once the active range fits 64 lanes x 32 elements: the same partition rounds,
-// but every exchange is a wave shuffle and LDS accesses of a single wave execute in program order, so a round
-// costs no block barrier (most rounds of an introselect run are on small ranges: the block-wide rounds take
-// ~1.7 us each, these ~0.3 us).  Called by wave 0 only, with all 64 lanes.
-// The selection arrays live in LDS.  The functions below are not inlined, so their pointer arguments arrive generic (every
-// access a flat_load / flat_store) and their scalars per lane; each function re-types them on entry: address space 3 for
-// the arrays (ds_read / ds_write), readfirstlane for the wave-uniform scalars.
-#define VS_LDS_AS __attribute__((address_space(3)))
-typedef VS_LDS_AS uint32_t lds_u32;
-typedef VS_LDS_AS uint16_t lds_u16;
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ void median_to_first(lds_u32* __restrict__ a, int first, int last) {
-    // __unguarded_partition_pivot: __move_median_to_first(first, first+1, mid, last-1)
-    const int mid = first + (last - first) / 2;
-    const int ia = first + 1, ib = mid, ic = last - 1;
-    const uint32_t A = a[ia] >> 16, B = a[ib] >> 16, C = a[ic] >> 16;
-    int m;
-    if (A < B) m = (B < C) ? ib : ((A < C) ? ic : ia);
-    else if (A < C) m = ia;
-    else if (B < C) m = ic;
-    else m = ib;
-    const uint32_t t = a[first]; a[first] = a[m]; a[m] = t;
-}
-
-__device__ __noinline__ int introselect_wave(uint32_t* __restrict__ a_g, uint16_t* __restrict__ posR_g, int first, int last,
-                                             int nth, int depth) {
-    lds_u32* __restrict__ a = (lds_u32*)a_g;
-    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
-    first = uni(first); last = uni(last); nth = uni(nth); depth = uni(depth);
-    const int lane = threadIdx.x & 63;
-    while (last - first > 3) {
-        if (depth == 0) return 1;
-        --depth;
-        if (lane == 0) median_to_first(a, first, last);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t pv = a[first] >> 16;
-        const int f0 = first + 1, m = last - f0;
-        const int chunk = (m + 63) >> 6;                  // <= 32
-        const int lo = min(f0 + lane * chunk, last), hi = min(lo + chunk, last);
-        uint32_t maskL = 0, maskR = 0;
-        for (int i = lo; i < hi; i++) {
-            const uint32_t k = a[i] >> 16;
-            maskL |= (uint32_t)(k >= pv) << (i - lo);
-            maskR |= (uint32_t)(k <= pv) << (i - lo);
-        }
-        const int cl = __popc(maskL), cr = __popc(maskR);
-        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
-        const int nR = wave_total(ir);
-        {
-            int rk = nR - ir;
-            uint32_t mr = maskR;
-            while (mr) {
-                const int e = 31 - __clz(mr);
-                mr &= ~(1u << e);
-                posR[rk++] = (uint16_t)(lo + e);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int swaps = 0, cand = 0x7fffffff;
-        {
-            int k = il - cl;
-            uint32_t ml = maskL;
-            while (ml) {
-                const int e = __ffs(ml) - 1;
-                ml &= ml - 1;
-                const int i = lo + e;
-                const int j = k < nR ? (int)posR[k] : -1;
-                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
-                else if (cand == 0x7fffffff) cand = i;
-                k++;
-            }
-        }
-        swaps = wave_total(wave_incl_scan(swaps));
-        cand = wave_min_nonneg(cand);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int RK = swaps > 0 ? (int)posR[swaps - 1] : last;
-        const int cut = (cand != 0x7fffffff && cand < RK) ? cand : RK;
-        if (cut <= nth) first = cut; else last = cut;
-    }
-    // __insertion_sort(first, last) on <= 3 elements
-    if (lane == 0) {
-        for (int i = first + 1; i < last; i++) {
-            const uint32_t v = a[i];
-            if ((v >> 16) < (a[first] >> 16)) {
-                for (int j = i; j > first; j--) a[j] = a[j - 1];
-                a[first] = v;
-            } else {
-                int j = i;
-                while ((v >> 16) < (a[j - 1] >> 16)) { a[j] = a[j - 1]; j--; }
-                a[j] = v;
-            }
-        }
-    }
-    return 0;
-}
-
-// returns 0 on success, 1 when libstdc++ would have fallen back to heap-select (depth limit): the
-// caller then re-runs the pair through the host path.
-__device__ __noinline__ int introselect_block(uint32_t* __restrict__ a_g, uint16_t* __restrict__ posR_g, SelShared& ss_g,
-                                              int n, int nth) {
-    lds_u32* __restrict__ a = (lds_u32*)a_g;
-    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
-    VS_LDS_AS SelShared& ss = *(VS_LDS_AS SelShared*)&ss_g;
-    n = uni(n); nth = uni(nth);
-    if (n == 0 || nth == n) return 0;                 // std::nth_element's early return
-    int first = 0, last = n;
-    int depth = 2 * (31 - __clz(n));                  // std::__lg(n) * 2
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int kWaveRange = VS_SEL_WAVE_RANGE;
-    constexpr int kSelThreadsSmall = VS_SEL_THREADS;   // threads that own elements in the block-wide rounds ...
-    bool fail = false;
-    // block-wide rounds while the range is large.  Round structure: [median swap by thread 0] barrier
-    // [classify + count] barrier [rank table] barrier [swaps + reduce] barrier; the next round's median swap
-    // rides in front of the following barrier.
-    bool median_done = false;
-    while (last - first > 3 && last - first - 1 > kWaveRange) {
-        if (depth == 0) { fail = true; break; }
-        --depth;
-        if (!median_done) {
-            if (tid == 0) median_to_first(a, first, last);
-            __syncthreads();
-        }
-        const uint32_t pv = a[first] >> 16;
-        const int f0 = first + 1, m = last - f0;
-        // ... unless a 32-element chunk per thread would not cover the range (a chunk must fit the 32-bit masks)
-        const int kSelThreads = m > 32 * kSelThreadsSmall ? kGnThreads : kSelThreadsSmall;
-        const int chunk = (m + kSelThreads - 1) / kSelThreads;   // <= 32: the caller caps n at 32*kGnThreads
-        const int lo = min(f0 + min(tid, kSelThreads) * chunk, last), hi = tid < kSelThreads ? min(lo + chunk, last) : lo;
-        // classify my chunk once, from the unmodified values: bit e of maskL / maskR = element lo+e stops the
-        // left / right scan.  Later passes use only the masks, so swaps by other threads cannot disturb them.
-        uint32_t maskL = 0, maskR = 0;
-        for (int i = lo; i < hi; i++) {
-            const uint32_t k = a[i] >> 16;
-            maskL |= (uint32_t)(k >= pv) << (i - lo);
-            maskR |= (uint32_t)(k <= pv) << (i - lo);
-        }
-        const int cl = __popc(maskL), cr = __popc(maskR);
-        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
-        if (lane == 63) { ss.wl[wave] = il; ss.wr[wave] = ir; }
-        __syncthreads();
-        int pre_l = il - cl, pre_r_incl = ir, nR = 0;
-        for (int wv = 0; wv < kSelThreads / 64; wv++) {
-            const int a_l = ss.wl[wv], a_r = ss.wr[wv];
-            if (wv < wave) { pre_l += a_l; pre_r_incl += a_r; }
-            nR += a_r;
-        }
-        // right-stopper ranks count from the right: rank of my topmost stopper = # stoppers after my chunk
-        {
-            int rk = nR - pre_r_incl;
-            uint32_t mr = maskR;
-            while (mr) {
-                const int e = 31 - __clz(mr);
-                mr &= ~(1u << e);
-                posR[rk++] = (uint16_t)(lo + e);
-            }
-        }
-        __syncthreads();
-        // left stoppers in increasing order: rank k swaps with posR[k] while it lies to the left of it.
-        // Swapped pairs are disjoint (every swapping left stopper is left of every swapping right stopper).
-        int swaps = 0, cand = 0x7fffffff;
-        {
-            int k = pre_l;
-            uint32_t ml = maskL;
-            while (ml) {
-                const int e = __ffs(ml) - 1;
-                ml &= ml - 1;
-                const int i = lo + e;
-                const int j = k < nR ? (int)posR[k] : -1;
-                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
-                else if (cand == 0x7fffffff) cand = i;
-                k++;
-            }
-        }
-        // K = total swaps; cand = position of the first left stopper that did not swap
-        swaps = wave_total(wave_incl_scan(swaps));
-        cand = wave_min_nonneg(cand);
-        if (lane == 0) { ss.red_k[wave] = swaps; ss.red_c[wave] = cand; }
-        __syncthreads();
-        int K = 0, c = 0x7fffffff;
-        for (int wv = 0; wv < kSelThreads / 64; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
-        const int RK = K > 0 ? (int)posR[K - 1] : last;
-        const int cut = (c != 0x7fffffff && c < RK) ? c : RK;
-        if (cut <= nth) first = cut; else last = cut;
-        // every swap of this round is complete (barrier above): thread 0 may already place the next round's
-        // pivot; the barrier that closes this round (posR / ss are rewritten next) then also publishes it
-        median_done = false;
-        if (last - first > 3 && last - first - 1 > kWaveRange && depth > 0) {
-            if (tid == 0) median_to_first(a, first, last);
-            median_done = true;
-        }
-        __syncthreads();
-    }
-    // the rest (including the final insertion sort) on one wave
-    if (!fail && wave == 0) {
-        if (introselect_wave(a_g, posR_g, first, last, nth, depth)) ss.red_k[0] = -1; else ss.red_k[0] = 0;
-    }
-    __syncthreads();
-    return fail || ss.red_k[0] < 0 ? 1 : 0;
-}
-
-// Both point sets of a level at once: threads 0..511 select the x-set, threads 512..1023 the y-set, each half
-// running the rounds of introselect_block on its own arrays.  The block barriers are shared, so the halves advance
-// in lock step and a half that has finished its block-wide rounds idles through the other's; the wave-level tails
-// then run side by side on wave 0 and wave 8.  Wall time = max instead of sum of the two selections.
-__device__ __noinline__ int introselect_dual(uint32_t* __restrict__ aX, uint16_t* __restrict__ pRX, uint32_t* __restrict__ aY,
-                                             uint16_t* __restrict__ pRY, SelShared* ss2, int n, int nth) {
-    if (n == 0 || nth == n) return 0;                 // std::nth_element's early return (same n, nth for both sets)
-    const int tid = threadIdx.x, half = tid >> 9, gt = tid & 511, lane = tid & 63, gw = gt >> 6;
-    n = uni(n); nth = uni(nth);
-    uint32_t* a_g = half ? aY : aX;                   // uniform per wave (a half is 8 whole waves)
-    uint16_t* posR_g = half ? pRY : pRX;
-    lds_u32* __restrict__ a = (lds_u32*)a_g;
-    lds_u16* __restrict__ posR = (lds_u16*)posR_g;
-    VS_LDS_AS SelShared& ss = *(VS_LDS_AS SelShared*)&ss2[half];
-    constexpr int kWaveRange = VS_SEL_WAVE_RANGE, kSmall = VS_SEL_THREADS, kHalf = kGnThreads / 2, kHalfWaves = kHalf / 64;
-    int first = 0, last = n;
-    int depth = 2 * (31 - __clz(n));
-    bool fail = false;
-    // does my half need another block-wide round?  if so take its depth token and place its pivot
-    auto begin_round = [&]() -> bool {
-        if (fail || !(last - first > 3 && last - first - 1 > kWaveRange)) return false;
-        if (depth == 0) { fail = true; return false; }
-        --depth;
-        if (gt == 0) median_to_first(a, first, last);
-        return true;
-    };
-    bool need = begin_round();
-    while (__syncthreads_or(need)) {                 // also publishes the pivot swaps
-        uint32_t maskL = 0, maskR = 0, pv = 0;
-        int lo = 0, f0 = first + 1;
-        if (need) {
-            pv = a[first] >> 16;
-            const int m = last - f0;
-            const int nthr = m > 32 * kSmall ? kHalf : kSmall;      // a chunk must fit the 32-bit masks
-            const int chunk = (m + nthr - 1) / nthr;
-            lo = min(f0 + min(gt, nthr) * chunk, last);
-            const int hi = gt < nthr ? min(lo + chunk, last) : lo;
-            for (int i = lo; i < hi; i++) {
-                const uint32_t k = a[i] >> 16;
-                maskL |= (uint32_t)(k >= pv) << (i - lo);
-                maskR |= (uint32_t)(k <= pv) << (i - lo);
-            }
-        }
-        const int cl = __popc(maskL), cr = __popc(maskR);
-        const int il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
-        if (lane == 63) { ss.wl[gw] = il; ss.wr[gw] = ir; }
-        __syncthreads();
-        int pre_l = il - cl, pre_r_incl = ir, nR = 0;
-        for (int wv = 0; wv < kHalfWaves; wv++) {
-            const int a_l = ss.wl[wv], a_r = ss.wr[wv];
-            if (wv < gw) { pre_l += a_l; pre_r_incl += a_r; }
-            nR += a_r;
-        }
-        {
-            int rk = nR - pre_r_incl;
-            uint32_t mr = maskR;
-            while (mr) {
-                const int e = 31 - __clz(mr);
-                mr &= ~(1u << e);
-                posR[rk++] = (uint16_t)(lo + e);
-            }
-        }
-        __syncthreads();
-        int swaps = 0, cand = 0x7fffffff;
-        {
-            int k = pre_l;
-            uint32_t ml = maskL;
-            while (ml) {
-                const int e = __ffs(ml) - 1;
-                ml &= ml - 1;
-                const int i = lo + e;
-                const int j = k < nR ? (int)posR[k] : -1;
-                if (i < j) { const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; swaps++; }
-                else if (cand == 0x7fffffff) cand = i;
-                k++;
-            }
-        }
-        swaps = wave_total(wave_incl_scan(swaps));
-        cand = wave_min_nonneg(cand);
-        if (lane == 0) { ss.red_k[gw] = swaps; ss.red_c[gw] = cand; }
-        __syncthreads();
-        if (need) {
-            int K = 0, c = 0x7fffffff;
-            for (int wv = 0; wv < kHalfWaves; wv++) { K += ss.red_k[wv]; c = min(c, ss.red_c[wv]); }
-            const int RK = K > 0 ? (int)posR[K - 1] : last;
-            const int cut = (c != 0x7fffffff && c < RK) ? c : RK;
-            if (cut <= nth) first = cut; else last = cut;
-        }
-        need = begin_round();     // all swaps of this round completed before the barrier above
-    }
-    int r = 0;
-    if (!fail && gw == 0) r = introselect_wave(a_g, posR_g, first, last, nth, depth);
-    if (gt == 0) ss.red_k[0] = (fail || r) ? -1 : 0;
-    __syncthreads();
-    return (ss2[0].red_k[0] < 0 || ss2[1].red_k[0] < 0) ? 1 : 0;
-}
-
-// Kernel-level selection op (one block per array): out_idx[0..nsel) = tile indices in the order
-// std::nth_element leaves them.  status[b] = 1 when the depth limit was hit.
-__global__ __launch_bounds__(kGnThreads) void vs_k_select(const uint16_t* __restrict__ wd, int nt, int nsel,
-                                                          int32_t* __restrict__ out_idx, int32_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    __shared__ SelShared ss;
-    uint32_t* a = (uint32_t*)dyn;
-    uint16_t* posR = (uint16_t*)(a + nt);
-    wd += (size_t)blockIdx.x * nt;
-    out_idx += (size_t)blockIdx.x * nt;
-    for (int i = threadIdx.x; i < nt; i += kGnThreads) a[i] = ((uint32_t)wd[i] << 16) | (uint32_t)i;
-    __syncthreads();
-    const int r = introselect_block(a, posR, ss, nt, nsel);
-    for (int i = threadIdx.x; i < nsel; i += kGnThreads) out_idx[i] = (int32_t)(a[i] & 0xffffu);
-    if (threadIdx.x == 0) status[blockIdx.x] = r;
-}
-
 // ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
 struct FusedLevels {
     int levels;
@@ -736,112 +180,20 @@ struct FusedLevels {
     unsigned long long img_off[kMaxLevels], lm_off[kMaxLevels], jac_off[kMaxLevels];
 };
 
-__global__ __launch_bounds__(kGnThreads) void vs_k_align_pairs(PairState* __restrict__ states,
-                                                               const PairDesc* __restrict__ descs,
-                                                               const uint8_t* __restrict__ pyr, size_t pyr_frame,
-                                                               const uint16_t* __restrict__ lm_tab, size_t lm_frame,
-                                                               const float* __restrict__ jac_tab, size_t jac_frame,
-                                                               uint8_t* __restrict__ recs, size_t recs_pair,
-                                                               int nt_cap, int dyn_bytes, FusedLevels fl, GnParams gp) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];
-    __shared__ SelShared ss2[2];
-    __shared__ GnShared sh;
-    uint32_t* a = (uint32_t*)dyn;
-    uint16_t* posR = (uint16_t*)(a + nt_cap);
-    const int p = blockIdx.x;
-    PairState& st = states[p];
-    const PairDesc d = descs[p];
-    // alignment.cpp:344 identity, or the phase-correlation start value the host side put into the state (:376-387)
-    double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
-    int fail = 0, fail_level = 0;
-    for (int l = fl.levels - 1; l >= 0 && !fail; l--) {
-        const int w = fl.w[l], h = fl.h[l], nt = fl.nt[l], nsel = fl.nsel[l];
-        const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + fl.img_off[l];
-        const uint8_t* key = pyr + (size_t)d.key_slot * pyr_frame + fl.img_off[l];
-        const PointRecs rc = pair_recs(recs, recs_pair, p, nt_cap);
-        float P[4];
-        ul_params_sparse(T, w, h, P);
-        const float A1 = 1.0f + P[0];
-#ifdef VS_PROFILE_STAMPS
-        unsigned long long tk[6];
-        tk[0] = __builtin_amdgcn_s_memtime();
-#define VS_STAMP(k) tk[k] = __builtin_amdgcn_s_memtime()
-#else
-#define VS_STAMP(k)
-#endif
-        const uint16_t* lm0 = lm_tab + (size_t)d.key_slot * lm_frame + fl.lm_off[l];
-        const float* jac0 = jac_tab + (size_t)d.key_slot * jac_frame + fl.jac_off[l];
-        // sparse_warpdiff (generators.cpp:646-700) of tile keypoint i of a set, packed for the selection
-        auto warpdiff_packed = [&](const uint16_t* __restrict__ lm, int i) -> uint32_t {
-            int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
-            float ox = (float)tile_x, oy = (float)tile_y;
-            float Wx = A1 * ox - P[1] * oy + P[2];
-            float Wy = P[1] * ox + A1 * oy + P[3];
-            float v = lanczos_sample_u8_fast(key, w, h, w, Wx, Wy);
-            float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
-            diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
-            return ((uint32_t)(uint16_t)diff << 16) | (uint32_t)i;
-        };
-        if (12 * nt <= dyn_bytes && nt <= 32 * (kGnThreads / 2)) {
-            // both sets side by side: aX | aY | posRX | posRY inside the same dynamic LDS block
-            uint32_t* aX = a;
-            uint32_t* aY = a + nt;
-            uint16_t* pRX = (uint16_t*)(a + 2 * nt);
-            uint16_t* pRY = pRX + nt;
-            for (int i = threadIdx.x; i < 2 * nt; i += kGnThreads) {
-                const int set = i >= nt, t = i - set * nt;
-                (set ? aY : aX)[t] = warpdiff_packed(lm0 + (size_t)set * 2 * nt, t);
-            }
-            __syncthreads();
-            VS_STAMP(1);
-            if (introselect_dual(aX, pRX, aY, pRY, ss2, nt, nsel)) { fail = 100; fail_level = l; }
-            VS_STAMP(2);
-            // gather (alignment.cpp:523-546) in the order nth_element left the survivors
-            for (int j = threadIdx.x; j < 2 * nsel; j += kGnThreads) {
-                const int set = j >= nsel, q = j - set * nsel;
-                write_rec(rc, j, lm0 + (size_t)set * 2 * nt, jac0 + (size_t)set * 4 * nt, nt, (int)((set ? aY : aX)[q] & 0xffffu), tmpl, w, h);
-            }
-            __syncthreads();
-        } else {
-            for (int set = 0; set < 2 && !fail; set++) {
-                const uint16_t* lm = lm0 + (size_t)set * 2 * nt;
-                const float* jac = jac0 + (size_t)set * 4 * nt;
-                for (int i = threadIdx.x; i < nt; i += kGnThreads) a[i] = warpdiff_packed(lm, i);
-                __syncthreads();
-                if (introselect_block(a, posR, ss2[0], nt, nsel)) { fail = 100; fail_level = l; }
-                for (int j = threadIdx.x; j < nsel; j += kGnThreads)
-                    write_rec(rc, set * nsel + j, lm, jac, nt, (int)(a[j] & 0xffffu), tmpl, w, h);
-                __syncthreads();   // a[] is refilled by the next set; the record stores are visible block-wide
-            }
-        }
-        if (fail) break;
-        VS_STAMP(3);
-        int iters;
-        double cond;
-#ifdef VS_PROFILE_STAMPS
-        unsigned long long gtk[6];
-        const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond, gtk);
-        if (threadIdx.x == 0)
-            printf("[gn stamps] level %d: hessian-sum %llu jacobi+barrier %llu sample0 %llu partials+barrier %llu update+barrier %llu\n", l,
-                   gtk[1] - gtk[0], gtk[2] - gtk[1], gtk[3] - gtk[2], gtk[4] - gtk[3], gtk[5] - gtk[4]);
-#else
-        const int f = gn_level(sh, key, w, h, nsel, rc, l, gp, T, &iters, &cond);
-#endif
-        VS_STAMP(4);
-#ifdef VS_PROFILE_STAMPS
-        if (threadIdx.x == 0) for (int k = 0; k < 5; k++) st.stamps[l][k] = tk[k];
-#endif
-        if (threadIdx.x == 0) { st.iterations[l] = iters; st.condition[l] = cond; }
-        if (f) { fail = f; fail_level = l; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        st.status = fail ? 0 : 1;
-        st.fail_reason = fail;
-        st.fail_level = fail_level;
-        st.T[0] = T[0]; st.T[1] = T[1]; st.T[2] = T[2]; st.T[3] = T[3];
-    }
-}
+// The per-pair kernels are compiled for two workgroup sizes (vs_align_kernels.inc).  512 threads is the faster shape
+// whenever it can be used (fewer waves behind every block barrier: 0.70 -> 0.62 ms for 239 1080p pairs, one pair alone
+// 0.445 -> 0.40 ms) and leaves room for a second workgroup on the CU; the side-by-side selection of both point sets gives
+// each set half the workgroup with 32 elements per thread, so levels of more than 8192 tiles (4K level 0) need the
+// 1024-thread build.
+namespace nt1024 {
+constexpr int kGnThreads = 1024;
+#include "vs_align_kernels.inc"
+}  // namespace nt1024
+namespace nt512 {
+constexpr int kGnThreads = 512;
+#include "vs_align_kernels.inc"
+}  // namespace nt512
+constexpr int kSmallWgTiles = 32 * (512 / 2);   // largest level the 512-thread kernels select side by side
 
 }  // namespace
 
@@ -1233,10 +585,12 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             // selection arrays in LDS: 6 B per tile for one point set; 12 B when both sets fit, so that they are selected
             // side by side (introselect_dual) -- always for 1080p, for every level but the finest at 4K
             const size_t dyn = (((size_t)nt_max * ((size_t)nt_max * 12 <= 150 * 1024 ? 12 : 6) + 15) & ~(size_t)15);
-            VS_HIP(hipFuncSetAttribute((const void*)vs_k_align_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            const bool small_wg = nt_max <= kSmallWgTiles;
+            const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
+            VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             t_begin(VS_STAGE_GN);
-            hipLaunchKernelGGL(vs_k_align_pairs, dim3(n_pairs), dim3(kGnThreads), dyn, s, states, descs, pyr, pyr_frame, lm,
-                               lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp);
+            hipLaunchKernelGGL(kernel, dim3(n_pairs), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, states, descs,
+                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp);
             VS_HIP(hipGetLastError());
             t_end(1);
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -1275,8 +629,12 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 t_end(1);
             }
             t_begin(VS_STAGE_GN);
-            hipLaunchKernelGGL(vs_k_gn_level, dim3(n_pairs), dim3(kGnThreads), 0, s, states, descs, pyr, pyr_frame, ld.img_off,
-                               ld.w, ld.h, ld.nsel, recs, recs_pair, nt_max, l, gp);
+            if (nt_max <= kSmallWgTiles)
+                hipLaunchKernelGGL(nt512::vs_k_gn_level, dim3(n_pairs), dim3(nt512::kGnThreads), 0, s, states, descs, pyr, pyr_frame,
+                                   ld.img_off, ld.w, ld.h, ld.nsel, recs, recs_pair, nt_max, l, gp);
+            else
+                hipLaunchKernelGGL(nt1024::vs_k_gn_level, dim3(n_pairs), dim3(nt1024::kGnThreads), 0, s, states, descs, pyr, pyr_frame,
+                                   ld.img_off, ld.w, ld.h, ld.nsel, recs, recs_pair, nt_max, l, gp);
             VS_HIP(hipGetLastError());
             t_end(1);
         }
@@ -1334,9 +692,11 @@ int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, f
     VS_TRY(o.out(out_idx, (size_t)n_arrays * nt * 4, mem));
     VS_TRY(st.out(status, (size_t)n_arrays * 4, mem));
     const size_t dyn = (((size_t)nt * 6 + 15) & ~(size_t)15);
-    VS_HIP(hipFuncSetAttribute((const void*)vs_k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    hipLaunchKernelGGL(vs_k_select, dim3(n_arrays), dim3(kGnThreads), dyn, s, a.as<uint16_t>(), nt, nsel, o.as<int32_t>(),
-                       st.as<int32_t>());
+    const bool small_wg = nt <= 32 * nt512::kGnThreads;      // a single selection gives every thread up to 32 elements
+    const auto kernel = small_wg ? nt512::vs_k_select : nt1024::vs_k_select;
+    VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(kernel, dim3(n_arrays), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, a.as<uint16_t>(), nt,
+                       nsel, o.as<int32_t>(), st.as<int32_t>());
     VS_HIP(hipGetLastError());
     VS_TRY(o.finish(s));
     VS_TRY(st.finish(s));
