@@ -180,11 +180,11 @@ struct FusedLevels {
     unsigned long long img_off[kMaxLevels], lm_off[kMaxLevels], jac_off[kMaxLevels];
 };
 
-// The per-pair kernels are compiled for two workgroup sizes (vs_align_kernels.inc).  512 threads is the faster shape
-// whenever it can be used (fewer waves behind every block barrier: 0.70 -> 0.62 ms for 239 1080p pairs, one pair alone
-// 0.445 -> 0.40 ms) and leaves room for a second workgroup on the CU; the side-by-side selection of both point sets gives
-// each set half the workgroup with 32 elements per thread, so levels of more than 8192 tiles (4K level 0) need the
-// 1024-thread build.
+// The per-pair kernels are compiled for two workgroup sizes (vs_align_kernels.inc).  512 threads is the faster shape in
+// every configuration measured (fewer waves behind every block barrier: 239 1080p pairs 0.70 -> 0.62 ms, one pair alone
+// 0.445 -> 0.40 ms, 952 pairs 2.50 -> 2.09 ms, 119 4K pairs 1.34 -> 1.29 ms although the 20736-tile selection itself is
+// slower with half the threads) and is the default for every level size; VS_SMALL_WG_TILES (build time) sends larger levels
+// to the 1024-thread build.
 namespace nt1024 {
 constexpr int kGnThreads = 1024;
 #include "vs_align_kernels.inc"
@@ -193,7 +193,10 @@ namespace nt512 {
 constexpr int kGnThreads = 512;
 #include "vs_align_kernels.inc"
 }  // namespace nt512
-constexpr int kSmallWgTiles = 32 * (512 / 2);   // largest level the 512-thread kernels select side by side
+#ifndef VS_SMALL_WG_TILES
+#define VS_SMALL_WG_TILES 26000
+#endif
+constexpr int kSmallWgTiles = VS_SMALL_WG_TILES;   // largest level handled by the 512-thread kernels (<= kSelectCap <= 64 * 512)
 
 }  // namespace
 
@@ -692,7 +695,7 @@ int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, f
     VS_TRY(o.out(out_idx, (size_t)n_arrays * nt * 4, mem));
     VS_TRY(st.out(status, (size_t)n_arrays * 4, mem));
     const size_t dyn = (((size_t)nt * 6 + 15) & ~(size_t)15);
-    const bool small_wg = nt <= 32 * nt512::kGnThreads;      // a single selection gives every thread up to 32 elements
+    const bool small_wg = nt <= kSmallWgTiles;
     const auto kernel = small_wg ? nt512::vs_k_select : nt1024::vs_k_select;
     VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(kernel, dim3(n_arrays), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, a.as<uint16_t>(), nt,
