@@ -189,8 +189,11 @@ namespace nt1024 {
 constexpr int kGnThreads = 1024;
 #include "vs_align_kernels.inc"
 }  // namespace nt1024
+#ifndef VS_NT_SMALL
+#define VS_NT_SMALL 512
+#endif
 namespace nt512 {
-constexpr int kGnThreads = 512;
+constexpr int kGnThreads = VS_NT_SMALL;
 #include "vs_align_kernels.inc"
 }  // namespace nt512
 #ifndef VS_SMALL_WG_TILES
