@@ -105,6 +105,15 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
 typedef const VS_GLOBAL_AS uint8_t* vs_gbytes;
 struct __attribute__((packed)) vs_packed_u32 { uint32_t v; };
 __device__ __forceinline__ uint32_t load_u32_unaligned(vs_gbytes p) { return ((const VS_GLOBAL_AS vs_packed_u32*)p)->v; }
+// ... and through a pointer into LDS (a level image staged there): the two aligned dwords around the address + v_alignbyte.
+// The staged image is padded so that the second dword always exists.
+#define VS_LDS_BYTES_AS __attribute__((address_space(3)))
+typedef const VS_LDS_BYTES_AS uint8_t* vs_lbytes;
+__device__ __forceinline__ uint32_t load_u32_unaligned(vs_lbytes p) {
+    const uint32_t addr = (uint32_t)(uintptr_t)p;
+    const VS_LDS_BYTES_AS uint32_t* q = (const VS_LDS_BYTES_AS uint32_t*)(uintptr_t)(addr & ~3u);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], addr & 3u);
+}
 
 // requires w >= 4.  P: const uint8_t* (generic) or vs_gbytes (global)
 template <typename P>

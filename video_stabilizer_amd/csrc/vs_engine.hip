@@ -590,7 +590,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             }
             // selection arrays in LDS: 6 B per tile for one point set; 12 B when both sets fit, so that they are selected
             // side by side (introselect_dual) -- always for 1080p, for every level but the finest at 4K
-            const size_t dyn = (((size_t)nt_max * ((size_t)nt_max * 12 <= 150 * 1024 ? 12 : 6) + 15) & ~(size_t)15);
+            size_t dyn = (((size_t)nt_max * ((size_t)nt_max * 12 <= 150 * 1024 ? 12 : 6) + 15) & ~(size_t)15);
+            // ... and room for the coarsest level's image if it fits next to the static LDS (the kernel stages it for the
+            // Gauss-Newton iterations): 480x270 at 1080p / 4K with pyramid_min_width 256
+            {
+                const size_t img_bytes = (size_t)L[levels - 1].w * L[levels - 1].h + 8;     // the coarsest level
+                if (img_bytes <= 150 * 1024) dyn = std::max(dyn, (img_bytes + 15) & ~(size_t)15);
+            }
             const bool small_wg = nt_max <= kSmallWgTiles;
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
             VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
