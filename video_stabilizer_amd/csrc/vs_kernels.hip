@@ -412,25 +412,28 @@ __device__ __forceinline__ unsigned sad_u32_imm(unsigned a, unsigned b) {
 
 // one row step of a lane: its own GW bytes in(x .. x+GW-1, y) by one aligned load; in(x-1) and in(x+GW) are the last /
 // first byte of the neighbouring lanes' words (wave_shr / wave_shl DPP moves), except at the two ends of the wave's strip,
-// where a single clamped byte is loaded
+// where the lane also fetches that single clamped byte.  Everything a row needs from memory is in RowFetch, so rows can
+// be requested several steps before they are used.
+struct RowFetch { uint32_t own, left, right; };
 template <int GW>
-__device__ __forceinline__ uint32_t load_own(const uint8_t* __restrict__ row, int x) {
-    uint32_t v = 0;
-    if (GW == 4) __builtin_memcpy(&v, row + x, 4);
-    else { uint16_t t; __builtin_memcpy(&t, row + x, 2); v = t; }
-    return v;
+__device__ __forceinline__ RowFetch fetch_row(const uint8_t* __restrict__ row, int x, int xl, int xr, bool first, bool last) {
+    RowFetch f{0, 0, 0};
+    if (GW == 4) __builtin_memcpy(&f.own, row + x, 4);
+    else { uint16_t t; __builtin_memcpy(&t, row + x, 2); f.own = t; }
+    if (first) f.left = row[xl];
+    if (last) f.right = row[xr];
+    return f;
 }
 // p[k] = in(x - 1 + k, y) << 16, k = 0 .. GW + 1
 template <int GW>
-__device__ __forceinline__ void position_row(uint32_t own, const uint8_t* __restrict__ row, int xl, int xr, bool first, bool last,
-                                             unsigned (&p)[GW + 2]) {
-    uint32_t left = (uint32_t)dpp_mov0<0x138>((int)own);     // wave_shr:1 -> lane - 1
-    uint32_t right = (uint32_t)dpp_mov0<0x130>((int)own);    // wave_shl:1 -> lane + 1
-    if (first) left = (uint32_t)row[xl] << (8 * (GW - 1));
-    if (last) right = row[xr];
+__device__ __forceinline__ void position_row(const RowFetch f, bool first, bool last, unsigned (&p)[GW + 2]) {
+    uint32_t left = (uint32_t)dpp_mov0<0x138>((int)f.own);     // wave_shr:1 -> lane - 1
+    uint32_t right = (uint32_t)dpp_mov0<0x130>((int)f.own);    // wave_shl:1 -> lane + 1
+    if (first) left = f.left << (8 * (GW - 1));
+    if (last) right = f.right;
     p[0] = __builtin_amdgcn_perm(0u, left, 0x0c000c0cu | ((unsigned)(GW - 1) << 16));
 #pragma unroll
-    for (int k = 0; k < GW; k++) p[k + 1] = __builtin_amdgcn_perm(0u, own, 0x0c000c0cu | ((unsigned)k << 16));
+    for (int k = 0; k < GW; k++) p[k + 1] = __builtin_amdgcn_perm(0u, f.own, 0x0c000c0cu | ((unsigned)k << 16));
     p[GW + 1] = __builtin_amdgcn_perm(0u, right, 0x0c000c0cu);
 }
 
@@ -463,37 +466,40 @@ __global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restr
         const bool first = lane == 0, last = lane == n_live - 1;
         const int xl = max(x - 1, 0), xr = min(x + GW, w - 1);
         unsigned prev[GW + 2], cur[GW + 2], nxt[GW + 2];
-        {
-            const uint8_t* r0 = img + (size_t)max(by - 1, 0) * stride;
-            const uint8_t* r1 = img + (size_t)by * stride;
-            position_row<GW>(load_own<GW>(r0, x), r0, xl, xr, first, last, prev);
-            position_row<GW>(load_own<GW>(r1, x), r1, xl, xr, first, last, cur);
-        }
-        uint32_t ahead = load_own<GW>(img + (size_t)min(by + 1, h - 1) * stride, x);
+        auto row_at = [&](int y) { return fetch_row<GW>(img + (size_t)clampi(y, 0, h - 1) * stride, x, xl, xr, first, last); };
+        position_row<GW>(row_at(by - 1), first, last, prev);
+        position_row<GW>(row_at(by), first, last, cur);
+        // D rows are in flight before the first one is needed and every step refills the slot it consumed (3 registers per
+        // row).  The loop stays rolled: fully unrolled, the compiler hoists all TS + 2 row loads and the kernel drops to
+        // 2 waves / SIMD.
+        constexpr int D = (TS % 4 == 0) ? 4 : 2;
+        RowFetch ring[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) ring[j] = row_at(by + 1 + j);
         unsigned mx = 0, my = 0;
         unsigned base = 0xffffu - (unsigned)(cx + GW - 1);       // row 0; + (GW-1-k) = 0xffff - (ry*TS + cx + k)
-        // rolled on purpose (fully unrolled, the compiler hoists all TS + 2 row loads and the kernel drops to
-        // 2 waves / SIMD); the next row is fetched one step ahead of its use
-#pragma unroll 2
-        for (int ry = 0; ry < TS; ry++) {
-            const uint32_t fetched = load_own<GW>(img + (size_t)min(by + ry + 2, h - 1) * stride, x);
-            position_row<GW>(ahead, img + (size_t)min(by + ry + 1, h - 1) * stride, xl, xr, first, last, nxt);
-            ahead = fetched;
-            unsigned gxm, gym;
-            if (GW == 4) {
-                gxm = max(max(sad_u32_imm<3>(cur[2], cur[0]), sad_u32_imm<2>(cur[3], cur[1])),
-                          max(sad_u32_imm<1>(cur[4], cur[2]), sad_u32_imm<0>(cur[5], cur[3])));
-                gym = max(max(sad_u32_imm<3>(nxt[1], prev[1]), sad_u32_imm<2>(nxt[2], prev[2])),
-                          max(sad_u32_imm<1>(nxt[3], prev[3]), sad_u32_imm<0>(nxt[4], prev[4])));
-            } else {
-                gxm = max(sad_u32_imm<1>(cur[2], cur[0]), sad_u32_imm<0>(cur[3], cur[1]));
-                gym = max(sad_u32_imm<1>(nxt[1], prev[1]), sad_u32_imm<0>(nxt[2], prev[2]));
-            }
-            mx = max(mx, gxm + base);
-            my = max(my, gym + base);
-            base -= (unsigned)TS;
+#pragma unroll 1
+        for (int ry0 = 0; ry0 < TS; ry0 += D) {
 #pragma unroll
-            for (int k = 0; k < GW + 2; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; }
+            for (int j = 0; j < D; j++) {
+                position_row<GW>(ring[j], first, last, nxt);
+                ring[j] = row_at(by + ry0 + j + 1 + D);
+                unsigned gxm, gym;
+                if (GW == 4) {
+                    gxm = max(max(sad_u32_imm<3>(cur[2], cur[0]), sad_u32_imm<2>(cur[3], cur[1])),
+                              max(sad_u32_imm<1>(cur[4], cur[2]), sad_u32_imm<0>(cur[5], cur[3])));
+                    gym = max(max(sad_u32_imm<3>(nxt[1], prev[1]), sad_u32_imm<2>(nxt[2], prev[2])),
+                              max(sad_u32_imm<1>(nxt[3], prev[3]), sad_u32_imm<0>(nxt[4], prev[4])));
+                } else {
+                    gxm = max(sad_u32_imm<1>(cur[2], cur[0]), sad_u32_imm<0>(cur[3], cur[1]));
+                    gym = max(sad_u32_imm<1>(nxt[1], prev[1]), sad_u32_imm<0>(nxt[2], prev[2]));
+                }
+                mx = max(mx, gxm + base);
+                my = max(my, gym + base);
+                base -= (unsigned)TS;
+#pragma unroll
+                for (int k = 0; k < GW + 2; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; }
+            }
         }
         atomicMax(&s_key[wave][tw][0], mx);
         atomicMax(&s_key[wave][tw][1], my);
