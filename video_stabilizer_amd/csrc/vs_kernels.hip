@@ -58,34 +58,6 @@ __device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint16
     }
 }
 
-__global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__ in, int w, int h, int in_stride,
-                                                     uint8_t* __restrict__ out, int ow, int oh, int out_stride,
-                                                     size_t in_frame_stride, size_t out_frame_stride) {
-    __shared__ uint8_t tile[PD_IH][PD_IWP];
-    __shared__ uint16_t vsum[PD_TH][PD_IWP];
-    in += blockIdx.z * in_frame_stride;
-    out += blockIdx.z * out_frame_stride;
-    const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
-    const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;
-    // stage 35 rows x 136 bytes
-    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
-        int r = i / (PD_IW / 4), c4 = (i % (PD_IW / 4)) * 4;
-        int gy = clampi(iy0 + r, 0, h - 1);
-        const uint8_t* row = in + (size_t)gy * in_stride;
-        int gx = ix0 + c4;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < w && (((uintptr_t)(row + gx)) & 3) == 0) {
-            v = *(const uint32_t*)(row + gx);
-        } else {
-            v = (uint32_t)row[clampi(gx, 0, w - 1)] | ((uint32_t)row[clampi(gx + 1, 0, w - 1)] << 8) |
-                ((uint32_t)row[clampi(gx + 2, 0, w - 1)] << 16) | ((uint32_t)row[clampi(gx + 3, 0, w - 1)] << 24);
-        }
-        *(uint32_t*)&tile[r][c4] = v;
-    }
-    __syncthreads();
-    pyr_passes(tile, vsum, x0, y0, out, ow, oh, out_stride);
-}
-
 // ------------------------------------------------------------------------------------------------
 // pyr_down, row-walking form (the layout of vs_k_keyframe_rows): a wave owns a strip of 256 input columns and a band of
 // PR_OUT output rows; a lane owns 4 input columns = 2 output columns and walks down the 2*PR_OUT + 3 input rows of the
@@ -94,7 +66,8 @@ __global__ __launch_bounds__(256) void vs_k_pyr_down(const uint8_t* __restrict__
 // ends of the strip and of the image), five v_perm_b32 that pair the bytes up as {even, odd}-output operands, and the
 // horizontal 1-4-6-4-1 for both outputs at once in packed u16 (<= 4080).  The vertical 1-4-6-4-1 runs on a five-row
 // register window, again packed (<= 65280), every second input row; >> 8 is a byte pick.  No LDS, every input row is
-// read once (+ 3 halo rows per band), D rows in flight.  Integer arithmetic: the same bytes as the LDS kernel below.
+// read once (+ 3 halo rows per band), D rows in flight.  Integer arithmetic: the same bytes as pyr_passes above (which the
+// fused ingest kernel still runs on its LDS tile).
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int PR_OUT = 16;           // output rows per wave
