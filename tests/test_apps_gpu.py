@@ -173,3 +173,45 @@ def test_grid_search_smoother_quick(gpu_vs, clip):
     assert float(re.search(r"jitter ratio    = ([0-9.eE+-]+)", out).group(1)) == min(ratios)
     for key in ("lag", "smoother_memory", "lambda", "min_disp", "max_disp", "min_decay", "max_decay"):
         assert re.search(r"^  %s\s+= " % key, out, re.M), key
+
+
+def test_video_test_10bit_y4m(gpu_vs, tmp_path):
+    """a 10-bit clip goes through the 16-bit frame path end to end: C444p10 in, C444p10 out, lag frames of latency, and the
+    output is what the library's stabilizer returns for the frames the reader decodes"""
+    from video_stabilizer_amd import synth
+    w, h, n = 256, 192, 14
+    frames, _ = synth.make_clip(w, h, n, seed=9, channels=3, bits=10)
+    b, g, r = (frames[..., c].astype(np.int64) for c in range(3))
+    y = np.clip(((66 * r + 129 * g + 25 * b + 128) >> 8) + 64, 0, 1023)
+    cb = np.clip(((-38 * r - 74 * g + 112 * b + 128) >> 8) + 512, 0, 1023)
+    cr = np.clip(((112 * r - 94 * g - 18 * b + 128) >> 8) + 512, 0, 1023)
+    d = tmp_path / "in"
+    d.mkdir()
+    with open(d / "deep.y4m", "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F25:1 Ip A1:1 C444p10\n" % (w, h))
+        for k in range(n):
+            f.write(b"FRAME\n")
+            for p in (y[k], cb[k], cr[k]):
+                f.write(p.astype("<u2").tobytes())
+    out = run("vs_video_test", d, tmp_path / "out")
+    assert "Finished processing 14 frames (4 written" in out
+    raw = open(tmp_path / "out" / "processed_deep.y4m", "rb").read()
+    header = raw[:raw.index(b"\n")].decode()
+    assert " W256 " in header and " H192 " in header and header.endswith("C444p10") and " F25:1 " in header
+    fsz = w * h * 3 * 2
+    assert len(raw) == len(header) + 1 + 4 * (6 + fsz)
+    # decode twin (10-bit, 4:4:4) of the input, stabilized by the library, encoded again == the file's planes
+    c_, d_, e_ = y - 64, cb - 512, cr - 512
+    dec = np.stack([np.clip((298 * c_ + 516 * d_ + 128) >> 8, 0, 1023), np.clip((298 * c_ - 100 * d_ - 208 * e_ + 128) >> 8, 0, 1023),
+                    np.clip((298 * c_ + 409 * e_ + 128) >> 8, 0, 1023)], -1).astype(np.uint16)
+    stab = gpu_vs.Stabilizer(device=0, crop_pixels=0)
+    want = np.stack([o for o in (stab.process(f) for f in dec) if o is not None]).astype(np.int64)
+    want = np.minimum(want, 1023)                            # the writer clamps to the clip's depth
+    wb, wg, wr = want[..., 0], want[..., 1], want[..., 2]
+    wy = np.clip(((66 * wr + 129 * wg + 25 * wb + 128) >> 8) + 64, 0, 1023)
+    pos = len(header) + 1
+    for k in range(4):
+        assert raw[pos:pos + 6] == b"FRAME\n"
+        got_y = np.frombuffer(raw, "<u2", w * h, pos + 6).reshape(h, w)
+        assert np.array_equal(got_y, wy[k]), k
+        pos += 6 + fsz
