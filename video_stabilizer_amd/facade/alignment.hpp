@@ -45,6 +45,13 @@ public:
                             const VideoAlignerParams& params = VideoAlignerParams()) {
         return align(gray, width, height, width, VS_FMT_GRAY8, transform, params);
     }
+#ifdef VS_FACADE_HAVE_OPENCV
+    // alignment.hpp:55-58: the reference's own signature
+    bool AlignNextFrame(const cv::Mat& frame, SimilarityTransform& transform, const VideoAlignerParams& params = VideoAlignerParams()) {
+        vs::require_bgr8(frame, "VideoAligner::AlignNextFrame");
+        return align(frame.data, frame.cols, frame.rows, vs::mat_stride_elems(frame), VS_FMT_BGR8, transform, params);
+    }
+#endif
     vs_aligner* handle() { return h_; }
 
 private:

@@ -142,3 +142,34 @@ inline bool warpBySimilarityTransform(const uint8_t* src_bgr, int w, int h, cons
     const SimilarityTransform sampling = transform.inverse();
     return vs_bgr_image_warp(src_bgr, w, h, w * 3, 3, 8, &sampling.c(), mode, border, 255, dst_bgr, w * 3, VS_MEM_HOST, nullptr) == 0;
 }
+
+// ---- optional cv::Mat overloads: compiled only where the caller's own OpenCV headers exist -----------------------
+// With them the reference's call sites compile unchanged: warpBySimilarityTransform(frame, correction)
+// (stabilizer.cpp:98), aligner.AlignNextFrame(inputFrame, currentMeas, params) (stabilizer.cpp:19),
+// stabilizer.processFrame(frame) (video_test.cpp:106).  Define VS_FACADE_NO_OPENCV to leave them out.
+#if !defined(VS_FACADE_NO_OPENCV) && defined(__has_include)
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define VS_FACADE_HAVE_OPENCV 1
+namespace vs {
+// the reference's adapters throw std::runtime_error on a wrong Mat type (imgproc.cpp:207-209,239-241)
+inline void require_bgr8(const cv::Mat& m, const char* who) {
+    if (m.empty() || m.type() != CV_8UC3) throw std::runtime_error(std::string(who) + ": expected a non-empty CV_8UC3 (BGR) cv::Mat");
+}
+inline int mat_stride_elems(const cv::Mat& m) { return (int)(m.step / m.elemSize1()); }
+}  // namespace vs
+
+// imgproc.hpp:97 / imgproc.cpp:446-484.  Same defaults as the reference's call: bilinear, black border.
+inline cv::Mat warpBySimilarityTransform(const cv::Mat& src, const SimilarityTransform& transform, int mode = VS_WARP_BILINEAR,
+                                         int border = VS_BORDER_CONSTANT) {
+    vs::require_bgr8(src, "warpBySimilarityTransform");
+    cv::Mat dst(src.rows, src.cols, CV_8UC3);
+    const SimilarityTransform sampling = transform.inverse();
+    if (vs_bgr_image_warp(src.data, src.cols, src.rows, vs::mat_stride_elems(src), 3, 8, &sampling.c(), mode, border, 255, dst.data,
+                          vs::mat_stride_elems(dst), VS_MEM_HOST, nullptr) != 0)
+        throw std::runtime_error(std::string("vs_bgr_image_warp: ") + vs_last_error());
+    return dst;
+}
+#endif
+#endif
+

@@ -45,6 +45,18 @@ public:
         if (r == 0) { out.clear(); out_width = out_height = 0; }
         return out;
     }
+#ifdef VS_FACADE_HAVE_OPENCV
+    // stabilizer.hpp:39: an empty cv::Mat until `lag` frames have arrived, then the stabilized, cropped frame
+    cv::Mat processFrame(const cv::Mat& inputFrame) {
+        vs::require_bgr8(inputFrame, "VideoStabilizer::processFrame");
+        cv::Mat out(inputFrame.rows - 2 * crop_, inputFrame.cols - 2 * crop_, CV_8UC3);
+        int ow = 0, oh = 0;
+        const int r = vs_stabilizer_process(h_, inputFrame.data, inputFrame.cols, inputFrame.rows, vs::mat_stride_elems(inputFrame), VS_FMT_BGR8,
+                                            VS_MEM_HOST, out.data, &ow, &oh);
+        if (r < 0) throw std::runtime_error(std::string("vs_stabilizer_process: ") + vs_last_error());
+        return r == 1 ? out : cv::Mat();
+    }
+#endif
 private:
     vs_stabilizer* h_ = nullptr;
     int crop_ = 0;
