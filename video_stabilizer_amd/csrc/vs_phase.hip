@@ -36,9 +36,11 @@ template <int R>
 __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2* __restrict__ dst, int n, int nb, int m, int s,
                                          int tstep, const float2* __restrict__ tw) {
     const int per = m * s;
+    // idx / per and bf / s by multiplication: n / d == umulhi(n, 2^32 / d + 1) for n, d < 2^16 (d > 1)
+    const uint32_t inv_per = 0xffffffffu / (uint32_t)per + 1u, inv_s = 0xffffffffu / (uint32_t)s + 1u;
     for (int idx = threadIdx.x; idx < nb * per; idx += kThreads) {
-        const int t = idx / per, bf = idx - t * per;
-        const int p = bf / s, q = bf - p * s;
+        const int t = per > 1 ? (int)__umulhi((uint32_t)idx, inv_per) : idx, bf = idx - t * per;
+        const int p = s > 1 ? (int)__umulhi((uint32_t)bf, inv_s) : bf, q = bf - p * s;
         const float2* in = src + t * n + q + s * p;
         float2* out = dst + t * n + q + s * (R * p);
         float2 a[R], b[R];
@@ -79,8 +81,12 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
 }
 
 // Forward transform of nb lines in LDS; returns the buffer holding the result.  Entry and exit are barrier-separated.
-__device__ float2* fft_lds(float2* src, float2* dst, const vsp::Plan& plan, int nb, const float2* __restrict__ tw) {
+// tw_lds: plan.n float2 of LDS that receive the twiddle table (every pass reads r - 1 twiddles per butterfly: from LDS
+// that is ~64 cycles instead of an L2 round trip).
+__device__ float2* fft_lds(float2* src, float2* dst, const vsp::Plan& plan, int nb, const float2* __restrict__ tw_global,
+                           float2* __restrict__ tw) {
     int n_cur = plan.n, s = 1;
+    for (int i = threadIdx.x; i < plan.n; i += kThreads) tw[i] = tw_global[i];
     __syncthreads();
     for (int pass = 0; pass < plan.passes; pass++) {
         const int r = plan.radix[pass], m = n_cur / r, tstep = plan.n / n_cur;
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_rows_fwd(const uint8_t* _
         const int t = idx / N, c = idx - t * N, r = r0 + t;
         a[idx] = make_float2((r < h && c < w) ? (float)im[(size_t)r * stride + c] : 0.0f, 0.0f);
     }
-    const float2* res = fft_lds(a, b, pn, lines, tw);
+    const float2* res = fft_lds(a, b, pn, lines, tw, lds_lines + (size_t)2 * nb * N);
     float2* out = spec + (size_t)blockIdx.y * spec_frame;
     for (int idx = threadIdx.x; idx < lines * NC; idx += kThreads) {
         const int t = idx / NC, c = idx - t * NC;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_cols_fwd(float2* __restri
         const int r = idx / lines, t = idx - r * lines;
         a[t * M + r] = sp[(size_t)r * NC + c0 + t];
     }
-    const float2* res = fft_lds(a, b, pm, lines, tw);
+    const float2* res = fft_lds(a, b, pm, lines, tw, lds_lines + (size_t)2 * nb * M);
     for (int idx = threadIdx.x; idx < lines * M; idx += kThreads) {
         const int r = idx / lines, t = idx - r * lines;
         sp[(size_t)r * NC + c0 + t] = res[t * M + r];
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_cross_cols_inv(const floa
         const float cim = (float)(((double)im * (double)mag) / denom);
         a[t * M + r] = make_float2(cre, -cim);
     }
-    const float2* res = fft_lds(a, b, pm, lines, tw);
+    const float2* res = fft_lds(a, b, pm, lines, tw, lds_lines + (size_t)2 * nb * M);
     float2* g = G + (size_t)blockIdx.y * g_pair;
     for (int idx = threadIdx.x; idx < lines * M; idx += kThreads) {
         const int r = idx / lines, t = idx - r * lines;
@@ -172,10 +178,34 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_cross_cols_inv(const floa
     }
 }
 
-// inverse row transform of the Hermitian extension, real part kept: the unshifted, unscaled surface.  grid (ceil(M/nb), pairs)
+// (value, shifted linear index) of a surface sample; minMaxLoc on the fftShift-ed image = largest value, first in row-major
+// order of the shifted image among equals
+struct PeakCand { float v; int si; };
+__device__ __forceinline__ bool cand_better(float v, int si, float bv, int bsi) { return v > bv || (v == bv && si < bsi); }
+
+// block-wide best candidate (all threads call; result valid in thread 0)
+__device__ __forceinline__ PeakCand block_best(float v, int si) {
+    __shared__ float s_v[kThreads];
+    __shared__ int s_i[kThreads];
+    s_v[threadIdx.x] = v;
+    s_i[threadIdx.x] = si;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float ov = s_v[threadIdx.x + off];
+            const int oi = s_i[threadIdx.x + off];
+            if (cand_better(ov, oi, s_v[threadIdx.x], s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    return PeakCand{s_v[0], s_i[0]};
+}
+
+// inverse row transform of the Hermitian extension, real part kept: the unshifted, unscaled surface; and the best sample of
+// the workgroup's rows as a candidate for the peak search.  grid (ceil(M/nb), pairs)
 __global__ __launch_bounds__(kThreads) void vs_k_phase_rows_inv(const float2* __restrict__ G, size_t g_pair, vsp::Plan pn, int M,
                                                                 int nb, const float2* __restrict__ tw, float* __restrict__ surf,
-                                                                size_t surf_pair) {
+                                                                size_t surf_pair, PeakCand* __restrict__ cands) {
     const int N = pn.n, NC = N / 2 + 1;
     const int r0 = blockIdx.x * nb, lines = min(nb, M - r0);
     const float2* g = G + (size_t)blockIdx.y * g_pair;
@@ -187,45 +217,39 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_rows_inv(const float2* __
         // X[c] for c <= N/2, conj(X[N-c]) above; stored conjugated for the inverse
         a[idx] = c < NC ? cconj(row[c]) : row[N - c];
     }
-    const float2* res = fft_lds(a, b, pn, lines, tw);
+    const float2* res = fft_lds(a, b, pn, lines, tw, lds_lines + (size_t)2 * nb * N);
     float* out = surf + (size_t)blockIdx.y * surf_pair;
+    const int hx = N / 2, hy = M / 2;
+    float best = -INFINITY;
+    int best_si = 0x7fffffff;
     for (int idx = threadIdx.x; idx < lines * N; idx += kThreads) {
         const int t = idx / N, c = idx - t * N;
-        out[(size_t)(r0 + t) * N + c] = res[idx].x;
+        const float v = res[idx].x;
+        out[(size_t)(r0 + t) * N + c] = v;
+        int sy = r0 + t + hy; if (sy >= M) sy -= M;             // fftShift moves element i to (i + n/2) mod n
+        int sx = c + hx; if (sx >= N) sx -= N;
+        const int si = sy * N + sx;
+        if (cand_better(v, si, best, best_si)) { best = v; best_si = si; }
     }
+    const PeakCand w = block_best(best, best_si);
+    if (threadIdx.x == 0) cands[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = w;
 }
 
-// fftShift + minMaxLoc (first maximum in row-major order of the shifted image) + weightedCentroid(5x5) + response.
-// one workgroup per pair
+// minMaxLoc over the row-block candidates + weightedCentroid(5x5) + response.  one workgroup per pair
 __global__ __launch_bounds__(kThreads) void vs_k_phase_peak(const float* __restrict__ surf, size_t surf_pair, int M, int N,
+                                                            const PeakCand* __restrict__ cands, int n_cands,
                                                             vsp::Result* __restrict__ results) {
     const float* sf = surf + (size_t)blockIdx.x * surf_pair;
     const int hx = N / 2, hy = M / 2;
-    __shared__ float s_v[kThreads];
-    __shared__ int s_i[kThreads];
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    // thread t walks shifted linear indices t, t + 256, ...: increasing, so strict '>' keeps its first maximum
-    for (int si = threadIdx.x; si < M * N; si += kThreads) {
-        const int sy = si / N, sx = si - sy * N;
-        int y = sy - hy; if (y < 0) y += M;
-        int x = sx - hx; if (x < 0) x += N;
-        const float v = sf[(size_t)y * N + x];
-        if (v > best) { best = v; best_i = si; }
+    for (int i = threadIdx.x; i < n_cands; i += kThreads) {
+        const PeakCand c = cands[(size_t)blockIdx.x * n_cands + i];
+        if (cand_better(c.v, c.si, best, best_i)) { best = c.v; best_i = c.si; }
     }
-    s_v[threadIdx.x] = best;
-    s_i[threadIdx.x] = best_i;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            const float ov = s_v[threadIdx.x + off];
-            const int oi = s_i[threadIdx.x + off];
-            if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
-        }
-        __syncthreads();
-    }
+    const PeakCand top = block_best(best, best_i);
     if (threadIdx.x == 0) {
-        int pi = s_i[0];
+        int pi = top.si;
         if (pi == 0x7fffffff) pi = 0;      // a surface without any comparable value (all NaN): minMaxLoc leaves (0, 0)
         const int py = pi / N, px = pi - py * N;
         int minr = py - 2, maxr = py + 2, minc = px - 2, maxc = px + 2;
@@ -297,6 +321,8 @@ static hipError_t upload_twiddles(int n, float2** out, hipStream_t s) {
 void Context::destroy() {
     if (twN) (void)hipFree(twN);
     if (twM) (void)hipFree(twM);
+    if (cands) (void)hipFree(cands);
+    cands = nullptr; cands_bytes = 0;
     twN = twM = nullptr;
     w = h = N = M = NC = 0;
 }
@@ -316,13 +342,23 @@ hipError_t Context::configure(int width, int height, hipStream_t s) {
 }
 
 static int lines_per_block(int n) { return std::max(1, std::min(8, kMaxLine / n)); }
+// dynamic LDS of a transform kernel: two line buffers of nb lines + the twiddle table
+static size_t lds_bytes(int nb, int n) { return sizeof(float2) * ((size_t)2 * nb + 1) * n; }
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 hipError_t Context::spectra(const uint8_t* img, size_t img_frame, int stride, int n_frames, float2* spec, hipStream_t s) const {
     if (n_frames <= 0) return hipSuccess;
     const int nbr = lines_per_block(N), nbc = lines_per_block(M);
-    vs_k_phase_rows_fwd<<<dim3((M + nbr - 1) / nbr, n_frames), kThreads, sizeof(float2) * 2 * (size_t)nbr * N, s>>>(
+    hipError_t e = allow_lds(vs_k_phase_rows_fwd, lds_bytes(nbr, N));
+    if (e != hipSuccess) return e;
+    e = allow_lds(vs_k_phase_cols_fwd, lds_bytes(nbc, M));
+    if (e != hipSuccess) return e;
+    vs_k_phase_rows_fwd<<<dim3((M + nbr - 1) / nbr, n_frames), kThreads, lds_bytes(nbr, N), s>>>(
         img, img_frame, w, h, stride, pn, M, nbr, twN, spec, spec_frame());
-    vs_k_phase_cols_fwd<<<dim3((NC + nbc - 1) / nbc, n_frames), kThreads, sizeof(float2) * 2 * (size_t)nbc * M, s>>>(
+    vs_k_phase_cols_fwd<<<dim3((NC + nbc - 1) / nbc, n_frames), kThreads, lds_bytes(nbc, M), s>>>(
         spec, spec_frame(), pm, NC, nbc, twM);
     return hipGetLastError();
 }
@@ -331,11 +367,24 @@ hipError_t Context::correlate(const float2* spec, const Pair* pairs_dev, int n_p
                               hipStream_t s) const {
     if (n_pairs <= 0) return hipSuccess;
     const int nbr = lines_per_block(N), nbc = lines_per_block(M);
-    vs_k_phase_cross_cols_inv<<<dim3((NC + nbc - 1) / nbc, n_pairs), kThreads, sizeof(float2) * 2 * (size_t)nbc * M, s>>>(
+    const int row_blocks = (M + nbr - 1) / nbr;
+    const size_t need = (size_t)n_pairs * row_blocks * sizeof(PeakCand);
+    if (need > cands_bytes) {                  // per-row-block peak candidates (grown on demand; the stream is in order)
+        if (cands) { hipError_t es = hipStreamSynchronize(s); if (es != hipSuccess) return es; (void)hipFree(cands); }
+        cands = nullptr; cands_bytes = 0;
+        hipError_t em = hipMalloc(&cands, need);
+        if (em != hipSuccess) return em;
+        cands_bytes = need;
+    }
+    hipError_t e = allow_lds(vs_k_phase_cross_cols_inv, lds_bytes(nbc, M));
+    if (e != hipSuccess) return e;
+    e = allow_lds(vs_k_phase_rows_inv, lds_bytes(nbr, N));
+    if (e != hipSuccess) return e;
+    vs_k_phase_cross_cols_inv<<<dim3((NC + nbc - 1) / nbc, n_pairs), kThreads, lds_bytes(nbc, M), s>>>(
         spec, spec_frame(), pairs_dev, pm, NC, nbc, twM, G, spec_frame());
-    vs_k_phase_rows_inv<<<dim3((M + nbr - 1) / nbr, n_pairs), kThreads, sizeof(float2) * 2 * (size_t)nbr * N, s>>>(
-        G, spec_frame(), pn, M, nbr, twN, surf, surface_elems());
-    vs_k_phase_peak<<<n_pairs, kThreads, 0, s>>>(surf, surface_elems(), M, N, results_dev);
+    vs_k_phase_rows_inv<<<dim3(row_blocks, n_pairs), kThreads, lds_bytes(nbr, N), s>>>(
+        G, spec_frame(), pn, M, nbr, twN, surf, surface_elems(), (PeakCand*)cands);
+    vs_k_phase_peak<<<n_pairs, kThreads, 0, s>>>(surf, surface_elems(), M, N, (const PeakCand*)cands, row_blocks, results_dev);
     return hipGetLastError();
 }
 

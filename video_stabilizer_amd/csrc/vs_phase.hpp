@@ -7,7 +7,7 @@
 
 namespace vsp {
 
-constexpr int kMaxLine = 4096;     // longest transform line held in LDS (two float2 buffers = 64 KB)
+constexpr int kMaxLine = 4096;     // longest transform line held in LDS (two float2 line buffers + the twiddle table = 96 KB)
 
 // radix plan: all factors 5, then 3, then 4, then at most one 2 (oracle/vs_phase.cpp "Transform specification")
 struct Plan {
@@ -27,6 +27,8 @@ struct Context {
     Plan pn{}, pm{};
     float2* twN = nullptr;
     float2* twM = nullptr;
+    mutable void* cands = nullptr;          // per-row-block peak candidates of the last correlate() (device)
+    mutable size_t cands_bytes = 0;
 
     hipError_t configure(int width, int height, hipStream_t s);   // hipErrorInvalidValue: a padded extent over kMaxLine
     void destroy();
