@@ -341,7 +341,11 @@ hipError_t Context::configure(int width, int height, hipStream_t s) {
     return hipSuccess;
 }
 
-static int lines_per_block(int n) { return std::max(1, std::min(8, kMaxLine / n)); }
+// lines per workgroup: small LDS footprints (several workgroups per CU) beat long ones, but the column transforms read
+// `lines` adjacent columns of every row and want whole sectors.  Measured per 240 1080p frames (N = 480, M = 270):
+// 8 / 8 lines 0.84 ms, 4 / 8 lines 0.69 ms, 2 / 3 lines 0.84 ms; per 120 4K frames (960, 540): 4 / 7 lines 2.00 ms,
+// 2 / 4 lines 1.62 ms, 2 / 8 lines 1.69 ms, 1 / 1 line 2.64 ms.
+static int lines_per_block(int n) { return std::max(1, std::min(n > 600 ? 2 : (n > 300 ? 4 : 8), kMaxLine / n)); }
 // dynamic LDS of a transform kernel: two line buffers of nb lines + the twiddle table
 static size_t lds_bytes(int nb, int n) { return sizeof(float2) * ((size_t)2 * nb + 1) * n; }
 template <typename K>
