@@ -14,10 +14,9 @@ using namespace vsd;
 // (2x,2y), truncating cast.  Every intermediate of the fp32 original is an exact multiple of
 // 1/256 below 2^24, so it equals the integer form (sum_j sum_i w_j w_i in) >> 8.
 //
-// Block = 256 threads, output tile 64 x 16.  The 136 x 35 input footprint is staged in LDS
-// (aligned dword loads in the interior, clamped byte loads at the borders), a vertical 5-tap pass
-// leaves u16 column sums in LDS for the 16 even rows, then each thread does the horizontal pass
-// for 4 adjacent outputs and stores them as one dword.
+// Two forms.  Tile form (pyr_passes, used by the fused ingest kernel): block = 256 threads, output tile 64 x 16, the
+// 136 x 35 gray footprint staged in LDS, a horizontal 5-tap pass on the dot-product unit, a vertical one in packed u16.
+// Row-walking form (vs_k_pyr_down_rows, the standalone kernel for levels >= 2): no LDS at all.
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int PD_TW = 64, PD_TH = 16;
@@ -27,28 +26,41 @@ constexpr int PD_IH = 2 * PD_TH + 3;     // 35 input rows:    2*y0-2 .. 2*y0+2*T
 constexpr int PD_IWP = PD_IW;            // LDS row pitch (136 B)
 }
 
-// The two LDS passes of pyr_down on a staged 35 x 136 tile (rows 2*y0-2.., columns 2*x0-4..): vertical 5 taps
-// at the 16 even rows into u16 column sums, then horizontal 5 taps, >> 8, 4 outputs per thread as one dword.
-__device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint16_t (*vsum)[PD_IWP], int x0, int y0,
+// The two LDS passes of pyr_down on a staged 35 x 136 gray tile (rows 2*y0-2.., columns 2*x0-4..) for a 64 x 16 output tile.
+// Horizontal first, on the dot-product unit: the five taps of an output are four bytes of one (byte-aligned) dword
+// against {1,4,6,4} plus one byte of the next dword, i.e. two v_dot4_u32_u8; an item = two adjacent outputs of one staged
+// row (35 x 32 items), stored as one dword {h, h'} (each <= 4080).  Then vertical in packed u16 (<= 65280): a thread owns four
+// adjacent outputs of one row, reads five 8-byte rows of sums, v = (a+e) + 4(b+d) + 6c on both halves, >> 8 is a byte pick,
+// one dword store.  All integer and exact, so the order of the two passes does not matter.
+__device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint32_t (*hsum)[PD_TW / 2], int x0, int y0,
                                            uint8_t* __restrict__ out, int ow, int oh, int out_stride) {
-    for (int i = threadIdx.x; i < PD_TH * PD_IW; i += 256) {
-        int r = i / PD_IW, c = i % PD_IW;
-        int rr = 2 * r;   // tile row of input row 2*(y0+r)-2
-        unsigned s = tile[rr][c] + 4u * tile[rr + 1][c] + 6u * tile[rr + 2][c] + 4u * tile[rr + 3][c] + tile[rr + 4][c];
-        vsum[r][c] = (uint16_t)s;
+    for (int i = threadIdx.x; i < PD_IH * (PD_TW / 2); i += 256) {
+        const int r = i >> 5, p = i & 31;                      // staged row, output pair (outputs 2p, 2p+1 of the tile)
+        const uint32_t* row = (const uint32_t*)&tile[r][0];
+        const uint32_t d0 = row[p], d1 = row[p + 1], d2 = row[p + 2];   // staged columns 4p .. 4p+11
+        // output 2p: input columns 2*(2p)-2 .. +2 = staged columns 4p+2 .. 4p+6; output 2p+1: staged columns 4p+4 .. 4p+8
+        uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), 0x04060401u, 0u, false);
+        h0 = __builtin_amdgcn_udot4(d1, 0x00010000u, h0, false);
+        uint32_t h1 = __builtin_amdgcn_udot4(d1, 0x04060401u, 0u, false);
+        h1 = __builtin_amdgcn_udot4(d2, 0x00000001u, h1, false);
+        hsum[r][p] = h0 | (h1 << 16);
     }
     __syncthreads();
-    // horizontal pass: thread -> 4 adjacent outputs of one row
-    const int r = threadIdx.x / (PD_TW / 4), q = threadIdx.x % (PD_TW / 4);
+    typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+    const int r = threadIdx.x >> 4, q = threadIdx.x & 15;      // output row, group of four outputs
     const int oy = y0 + r, ox = x0 + 4 * q;
     if (oy < oh && ox < ow) {
-        uint32_t packed = 0;
+        us2v lo[5], hi[5];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int c = 2 * (4 * q + k) + 2;   // staged column of input column 2*(ox+k)-2
-            unsigned s = vsum[r][c] + 4u * vsum[r][c + 1] + 6u * vsum[r][c + 2] + 4u * vsum[r][c + 3] + vsum[r][c + 4];
-            packed |= (s >> 8) << (8 * k);
+        for (int j = 0; j < 5; j++) {
+            const uint2 v = *(const uint2*)&hsum[2 * r + j][2 * q];
+            lo[j] = __builtin_bit_cast(us2v, v.x);
+            hi[j] = __builtin_bit_cast(us2v, v.y);
         }
+        const us2v va = (lo[0] + lo[4]) + (lo[1] + lo[3]) * (unsigned short)4 + lo[2] * (unsigned short)6;
+        const us2v vb = (hi[0] + hi[4]) + (hi[1] + hi[3]) * (unsigned short)4 + hi[2] * (unsigned short)6;
+        // bytes 1 and 3 of each packed pair are the four outputs >> 8
+        const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, vb), __builtin_bit_cast(uint32_t, va), 0x07050301u);
         uint8_t* dst = out + (size_t)oy * out_stride + ox;
         if (ox + 3 < ow && (((uintptr_t)dst) & 3) == 0) {
             *(uint32_t*)dst = packed;
@@ -204,8 +216,8 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
                                                        int shift_to_8, uint8_t* __restrict__ g0, uint8_t* __restrict__ g1,
                                                        int ow, int oh, size_t src_frame_stride, size_t pyr_frame_stride,
                                                        int tiles_x, int tiles_per_frame, int total_tiles, int chunk) {
-    __shared__ uint8_t tile[PD_IH][PD_IWP];
-    __shared__ uint16_t vsum[PD_TH][PD_IWP];
+    __shared__ __attribute__((aligned(8))) uint8_t tile[PD_IH][PD_IWP];
+    __shared__ __attribute__((aligned(8))) uint32_t hsum[PD_IH][PD_TW / 2];
     // XCD-aware order (see vs_warp.hip): each XCD walks a contiguous raster run of tiles
     const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (logical >= total_tiles) return;
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
         }
     }
     __syncthreads();
-    pyr_passes(tile, vsum, x0, y0, g1, ow, oh, ow);
+    pyr_passes(tile, hsum, x0, y0, g1, ow, oh, ow);
 }
 
 // ------------------------------------------------------------------------------------------------
