@@ -28,6 +28,15 @@ def test_pyr_down_bit_exact(gpu_vs, oracle, w, h):
     assert np.array_equal(gpu_vs.pyr_down(img), oracle.pyr_down(img))
 
 
+@pytest.mark.parametrize("w,h", [(2, 2), (3, 2), (4, 4), (5, 7), (7, 5), (8, 3), (9, 9), (254, 17), (255, 18), (256, 19), (257, 33), (258, 34), (259, 35),
+                                 (511, 64), (513, 66), (1027, 5), (130, 257)])
+def test_pyr_down_strip_and_band_boundaries(gpu_vs, oracle, w, h):
+    """the row-walking kernel's seams: strips of 256 input columns, bands of 16 output rows, widths that are not a multiple
+    of 4 (byte-assembled last group), 1- and 2-lane strips, images smaller than the 5x5 window"""
+    img = _noise(w, h, w * 131 + h)
+    assert np.array_equal(gpu_vs.pyr_down(img), oracle.pyr_down(img))
+
+
 def test_pyr_down_known_answers(gpu_vs):
     # SURVEY 8c-1: impulse responses of the integer form (sum w_i w_j in) >> 8
     img = np.zeros((32, 32), np.uint8)
@@ -95,6 +104,23 @@ def test_keyframe_fused_equals_three_stage_oracle(gpu_vs, oracle, w, h):
     ots, olx, oly = oracle.grad_argmax(gx, gy)
     ojx, ojy = oracle.sparse_jac(gx, gy, olx, oly)
     assert ts == ots
+    assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
+    assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+
+
+@pytest.mark.parametrize("ts", [2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 3, 7, 21, 24, 64])
+@pytest.mark.parametrize("w,h", [(324, 250), (257, 131), (1283, 97)])
+def test_keyframe_fused_every_tile_size(gpu_vs, oracle, ts, w, h):
+    """the ten strip kernels (the reference's tile sizes, CMakeLists.txt:212-253) and the generic kernel (any other size),
+    on widths that leave partial strips, unaligned rows and remainder columns; tie-heavy content (values 0..7)"""
+    if ts > min(w, h):
+        pytest.skip("tile larger than the image")
+    rng = np.random.default_rng(ts * 1000 + w)
+    img = (rng.integers(0, 8, (h, w)) * 36).astype(np.uint8)
+    _, lmx, lmy, jx, jy = gpu_vs.keyframe_fused(img, ts=ts)
+    gx, gy = oracle.grad_xy(img)
+    _, olx, oly = oracle.grad_argmax(gx, gy, ts=ts)
+    ojx, ojy = oracle.sparse_jac(gx, gy, olx, oly)
     assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
     assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
 
