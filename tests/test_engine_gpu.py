@@ -373,3 +373,22 @@ def test_stabilizer_process_clips_equals_fresh_stabilizers(gpu_vs):
     assert s.process(clips[1][0]) is None and s.state()[2] is False
     out2, has2 = s.process_clips(np.concatenate(clips), n_clips)
     assert has2 == want_has and np.array_equal(out2, out)
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("w,h", [(323, 247), (258, 130), (1283, 99), (256, 96), (131, 129)])
+def test_ingest_pyramid_bit_exact_on_awkward_sizes(gpu_vs, oracle, w, h, bits):
+    """the fused BGR -> gray level 0 + level 1 kernel and the row-walking pyr_down behind it: every pyramid level of a frame
+    equals the oracle's, for widths that are not multiples of 4 / 128 / 256, odd heights, and both frame depths (the 16-bit
+    path has its own vector loads and dot-product form)"""
+    rng = np.random.default_rng(w * 7 + h + bits)
+    hi = 255 if bits == 8 else 1023
+    frame = rng.integers(0, hi + 1, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+    gpu = gpu_vs.Aligner(device=0)
+    cpu = oracle.Aligner()
+    gpu.align_next(frame)
+    cpu.align_next(frame)
+    levels = cpu.debug().levels
+    assert gpu.info(0).levels == levels >= 3
+    for l in range(levels):
+        assert np.array_equal(gpu.level(0, l)["img"], cpu.level(l)["img"][0]), l
