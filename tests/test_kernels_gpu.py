@@ -333,26 +333,3 @@ def test_bgr_image_warp_window_equals_cropped_full_warp(gpu_vs, dtype, c, mode, 
         with pytest.raises(gpu_vs.VsError):
             gpu_vs.bgr_image_warp_roi_batch(src, ts, bad)
 
-
-@pytest.mark.parametrize("dtype,hi", [(np.uint8, 255), (np.uint16, 1023), (np.uint16, 65535)])
-@pytest.mark.parametrize("border", [0, 1])
-def test_lanczos2_fast_mode_stays_within_one_lsb_of_the_exact_warp(gpu_vs, oracle, dtype, hi, border):
-    """VS_WARP_LANCZOS2_FAST (opt-in: fused multiply-adds, refined reciprocal) against the exact sampler = the oracle.
-    Gate (SURVEY 8d / north star "warped pixels within 1 ULP of the Lanczos path"): integer outputs differ by at most
-    1 LSB, and only where the exact value sits on a rounding boundary: >= 99.9 % identical."""
-    from video_stabilizer_amd import synth
-    frames, _ = synth.make_clip(640, 360, 2, seed=5, channels=3, bits=8 if hi == 255 else 10)
-    src = frames if hi != 65535 else (frames.astype(np.uint32) * 64).astype(np.uint16)     # full 16-bit range
-    ts = [gpu_vs.Transform.of(0.004, -0.003, 2.25, -1.5), gpu_vs.Transform.of(-0.01, 0.02, -7.75, 3.125)]
-    exact = gpu_vs.bgr_image_warp_batch(src, ts, mode=gpu_vs.WARP_LANCZOS2, border=border, max_value=hi)
-    for i in range(2):
-        assert np.array_equal(exact[i], oracle.bgr_image_warp(src[i], oracle.Transform.of(*ts[i].tup()), border=border, max_value=hi))
-    fast = gpu_vs.bgr_image_warp_batch(src, ts, mode=gpu_vs.WARP_LANCZOS2_FAST, border=border, max_value=hi)
-    d = np.abs(fast.astype(np.int64) - exact.astype(np.int64))
-    assert d.max() <= 1
-    same = float((d == 0).mean())
-    assert same >= (0.999 if hi != 65535 else 0.97), same    # 16-bit full range: an LSB is 1.5e-5 of the value, ~1 float ULP x 100
-    # layouts without a tuned kernel are served by the exact arithmetic
-    gray = np.ascontiguousarray(src[..., :1])
-    assert np.array_equal(gpu_vs.bgr_image_warp_batch(gray, ts, mode=gpu_vs.WARP_LANCZOS2_FAST, border=border, max_value=hi),
-                          gpu_vs.bgr_image_warp_batch(gray, ts, mode=gpu_vs.WARP_LANCZOS2, border=border, max_value=hi))

@@ -16,8 +16,10 @@ for f in $SRCS; do
   objs="$objs $o"
   if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ -n "$(find "$HERE" -maxdepth 1 \( -name '*.hpp' -o -name '*.inc' \) -newer "$o" -print -quit)" ] \
      || [ "$HERE/../../include/vs_amd.h" -nt "$o" ]; then
+    # vs_warp.hip: the SLP vectorizer would re-pack its scalar fp32 chains into v_pk_* (slower on gfx950, see the file header)
+    extra=""; [ "$f" = "vs_warp.hip" ] && extra="-fno-slp-vectorize"
     case "$f" in
-      *.hip) "$HIPCC" $FLAGS -c "$HERE/$f" -o "$o" & pids="$pids $!" ;;
+      *.hip) "$HIPCC" $FLAGS $extra -c "$HERE/$f" -o "$o" & pids="$pids $!" ;;
       *.cpp) "$HIPCC" -x hip $FLAGS -c "$HERE/$f" -o "$o" & pids="$pids $!" ;;
     esac
   fi

@@ -338,8 +338,8 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
         e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
                              dst_fs, roi, s);
-    if (e == hipErrorNotSupported)   // layouts without a tuned kernel: the fast mode is served by the exact arithmetic
-        e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode == VS_WARP_LANCZOS2_FAST ? VS_WARP_LANCZOS2 : mode, border, max_value,
+    if (e == hipErrorNotSupported)   // layouts without a tuned kernel (other channel counts, float output): one thread per pixel, same arithmetic
+        e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);
     VS_HIP(e);
     VS_TRY(g_param_ring.fence(pdev, (size_t)n_frames, s));

@@ -39,6 +39,57 @@ __device__ __forceinline__ void lanczos_weights4(float frac, float w[4]) {
     w[3] = lanczos2(2.0f - frac);
 }
 
+// ---- VS_WARP_LANCZOS2_FAST: the tolerance-gated arithmetic of bgr_image_warp -------------------------------------
+// Same sampler (generators.cpp:31-47 polynomial, :672-697 window and normalisation), evaluated with fused
+// multiply-adds and in separable order -- NOT the reference's sequence of roundings:
+//   w(t)   = Horner in t*t with one fma per step (6 roundings instead of 12), same |t| >= 2 select
+//   h[ry]  = fma(wx3,v3, fma(wx2,v2, fma(wx1,v1, wx0*v0)))          horizontal pass, per source row and channel
+//   num    = fma(wy3,h3, fma(wy2,h2, fma(wy1,h1, wy0*h0)))          vertical pass
+//   den    = ((wx0+wx1)+(wx2+wx3)) * ((wy0+wy1)+(wy2+wy3))          == sum of wx*wy up to rounding
+//   out    = num * r,  r = rcp(den) refined by one Newton step
+// 20 multiply-adds per channel instead of 16 products + 32 separately rounded multiply / add steps.  Every kernel that
+// offers the fast mode calls these functions, so the f32-output gate (tests/test_warp_fast_gpu.py) checks the very
+// arithmetic the tuned u8 / u16 kernels run.
+__device__ __forceinline__ float lanczos2_fma(float x) {
+    const float x2 = x * x;
+    float v = 0.000858519f;
+    v = __builtin_fmaf(v, x2, -0.0158853f);
+    v = __builtin_fmaf(v, x2, 0.128693f);
+    v = __builtin_fmaf(v, x2, -0.583468f);
+    v = __builtin_fmaf(v, x2, 1.52229f);
+    v = __builtin_fmaf(v, x2, -2.05238f);
+    v = __builtin_fmaf(v, x2, 0.999861f);
+    return fabsf(x) >= 2.0f ? 0.0f : v;
+}
+__device__ __forceinline__ void lanczos_weights4_fma(float frac, float w[4]) {
+    w[0] = lanczos2_fma(-1.0f - frac);
+    w[1] = lanczos2_fma(0.0f - frac);
+    w[2] = lanczos2_fma(1.0f - frac);
+    w[3] = lanczos2_fma(2.0f - frac);
+}
+// reciprocal of the weight sum: den is within a few percent of 1, so one Newton step on v_rcp_f32 (1 ulp) is enough
+__device__ __forceinline__ float lanczos_fast_rden(const float wx[4], const float wy[4]) {
+    const float den = ((wx[0] + wx[1]) + (wx[2] + wx[3])) * ((wy[0] + wy[1]) + (wy[2] + wy[3]));
+    float r = __builtin_amdgcn_rcpf(den);
+    return __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+}
+// one channel: v[ry][rx] = the 4x4 window as floats
+__device__ __forceinline__ float lanczos_fast_combine(const float v[4][4], const float wx[4], const float wy[4], float rden) {
+    float h[4];
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+        float a = wx[0] * v[ry][0];
+        a = __builtin_fmaf(wx[1], v[ry][1], a);
+        a = __builtin_fmaf(wx[2], v[ry][2], a);
+        h[ry] = __builtin_fmaf(wx[3], v[ry][3], a);
+    }
+    float n = wy[0] * h[0];
+    n = __builtin_fmaf(wy[1], h[1], n);
+    n = __builtin_fmaf(wy[2], h[2], n);
+    n = __builtin_fmaf(wy[3], h[3], n);
+    return n * rden;
+}
+
 // Lanczos2 sample of a single-channel u8 image with clamp-to-edge addressing:
 // generators.cpp:672-697 (sparse_warpdiff) == :469-498 (sparse_ica).  rx inner, ry outer,
 // separate num / den accumulators from 0, one IEEE divide.

@@ -705,11 +705,30 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
     float flx = floorf(Wx), fly = floorf(Wy);
     int ix = (int)flx, iy = (int)fly;
     float frx = Wx - flx, fry = Wy - fly;
-    float wx[4], wy[4];
+    float wx[4], wy[4], rden = 0.0f;
     if (MODE == 0) { lanczos_weights4(frx, wx); lanczos_weights4(fry, wy); }
+    if (MODE == 2) { lanczos_weights4_fma(frx, wx); lanczos_weights4_fma(fry, wy); rden = lanczos_fast_rden(wx, wy); }
     for (int c = 0; c < channels; c++) {
         float v;
-        if (MODE == 0) {
+        if (MODE == 2) {
+            // VS_WARP_LANCZOS2_FAST (vs_device.hpp): the arithmetic of the tuned kernels, here with float output too
+            float t[4][4];
+#pragma unroll
+            for (int ry = 0; ry < 4; ry++) {
+                int sy = iy + ry - 1;
+#pragma unroll
+                for (int rx = 0; rx < 4; rx++) {
+                    int sx = ix + rx - 1;
+                    if (BORDER == 1) {
+                        t[ry][rx] = (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f
+                                    : (float)src[(size_t)sy * src_stride + (size_t)sx * channels + c];
+                    } else {
+                        t[ry][rx] = (float)src[(size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(sx, 0, w - 1) * channels + c];
+                    }
+                }
+            }
+            v = lanczos_fast_combine(t, wx, wy, rden);
+        } else if (MODE == 0) {
             float num = 0.0f, den = 0.0f;
 #pragma unroll
             for (int ry = 0; ry < 4; ry++) {
@@ -891,6 +910,8 @@ static void launch_generic(const T* src, int w, int h, int src_stride, int chann
                        params, max_value, dst, dst_stride, src_fs, dst_fs, roi)
     if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
     else if (mode == 0) VS_LAUNCH(0, 1);
+    else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
+    else if (mode == 2) VS_LAUNCH(2, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
     else VS_LAUNCH(1, 1);
 #undef VS_LAUNCH

@@ -3,8 +3,9 @@
 // Sampler semantics = vs_k_bgr_warp_generic (vs_kernels.hip), i.e. the reference's Lanczos2 sampler
 // (generators.cpp:672-697: 5x5 window, polynomial weights, rx inner / ry outer, num and den summed
 // separately, one divide) or image_warp's bilinear (generators.cpp:148-163), evaluated per channel at
-// image_warp's coordinates (generators.cpp:141-142).  Results are bit-identical to the generic kernel
-// and to the CPU oracle: same fp32 operations in the same order, no FMA contraction.
+// image_warp's coordinates (generators.cpp:141-142).  VS_WARP_LANCZOS2 / VS_WARP_BILINEAR results are
+// bit-identical to the generic kernel and to the CPU oracle: same fp32 operations in the same order, no
+// FMA contraction.  VS_WARP_LANCZOS2_FAST runs the tolerance-gated arithmetic of vs_device.hpp.
 //
 // Structure (one 256-thread workgroup = one 64x16 output tile of one frame):
 //   1. The similarity is affine, so the tile's source footprint is the bounding box of its four
@@ -13,22 +14,21 @@
 //   2. The footprint (+ the Lanczos halo) is read from HBM once with aligned 12-byte loads (4 pixels),
 //      converted to float ONCE, and parked in LDS as one float4 {B,G,R,1} per source pixel.  Clamp /
 //      constant-0 borders are resolved here, so the inner loop has no clamps and no global loads.
-//   3. Lane = output column, each wave owns 4 output rows.  One tap = one ds_read_b128 at an immediate
-//      offset from a single address register; neighbouring lanes read neighbouring 16-byte slots, so
-//      the reads are conflict-free.  The arithmetic is packed fp32 (v_pk_mul_f32 / v_pk_add_f32 on
-//      {B,G} and {R,den} pairs -- the trailing 1.0 makes den += w fall out of the same instruction,
-//      and w*1.0 is exact) and the eight polynomial weights run as four {x,y} packed Horner chains.
-//      Packed instructions issue at the scalar-VALU rate on gfx950, so this halves the VALU time;
-//      each component still sees exactly the reference's sequence of roundings.
-//   4. Results are transposed through a 3 KB LDS tile so that the stores leave as aligned dwords,
-//      192 contiguous bytes per output row.
+//   3. Lane = output column, each wave owns 4 output rows and computes them in ONE straight-line block
+//      (no branch between rows: lanes / rows outside the window sample a clamped coordinate and are masked
+//      at the store), so the scheduler interleaves the four rows' dependency chains.  One tap = one
+//      ds_read_b128 at an immediate offset from a single address register; neighbouring lanes read
+//      neighbouring 16-byte slots, so the reads are conflict-free.
+//   4. A quad of lanes assembles its 12 output bytes with one DPP move + one v_perm_b32 per row and stores
+//      3 aligned dwords (192 contiguous bytes per wave-row).
 // Tiles whose footprint does not fit the LDS window (large rotation / zoom) take the generic
 // global-memory path inside the same kernel, so every transform is supported.
 //
-// Cost model (DESIGN.md "bgr_image_warp roofline"): measured with rocprofv3 PMC the exact-order
-// Lanczos2 form needs a few hundred VALU instructions per output pixel against 6 bytes of HBM
-// traffic, and a wave64 VALU instruction occupies its SIMD for 4 cycles: the kernel is VALU-bound,
-// not HBM-bound, on gfx950 (bilinear is ~4x lighter).
+// Cost model (DESIGN.md "bgr_image_warp roofline", tools/ubench_valu.hip): the kernel is VALU-bound, not
+// HBM-bound.  Measured issue cost on gfx950 with >= 2 waves per SIMD (kernel time x 2.4 GHz / instructions):
+// v_fma/mul/add_f32 2.7 cycles, v_pk_{fma,mul,add}_f32 4.9, conversions / v_perm / v_med3 4.3-4.5, v_rcp 8.2.
+// The exact mode needs 248 separately rounded fp32 operations per pixel (112 Horner, 16 weight products, 96 tap
+// multiply / adds, 16 den adds, 8 selects) = 128 packed instructions = 632 cycles per 64 pixels before any overhead.
 #include "vs_kernels.hpp"
 #include "vs_device.hpp"
 
@@ -36,13 +36,33 @@ using namespace vsd;
 
 namespace {
 
-constexpr int WT_W = 64, WT_H = 16;      // output tile
+// tuning knobs (tools/build_variant.sh builds the library with other values to compare them on the GPU)
+#ifndef VS_WARP_FAST_MINWAVES
+#define VS_WARP_FAST_MINWAVES 4          // __launch_bounds__ waves per SIMD of the fast Lanczos2 kernels
+#endif
+#ifndef VS_WARP_FAST_SCHED
+#define VS_WARP_FAST_SCHED 1             // scheduling fences in the fast kernels: 0 none, 1 per row pair, 2 per source row
+#endif
+#ifndef VS_WARP_EXACT_MINWAVES
+#define VS_WARP_EXACT_MINWAVES 4
+#endif
+#ifndef VS_WARP_TILE_H
+#define VS_WARP_TILE_H 16                // output rows per workgroup (4 waves: VS_WARP_TILE_H / 4 rows per wave)
+#endif
+
+constexpr int WT_W = 64, WT_H = VS_WARP_TILE_H;      // output tile
+constexpr int RPW = WT_H / 4;            // output rows per wave (even)
 constexpr int WS_W = 80;                 // staged source pixels per row (multiple of 4)
-constexpr int WS_H = 24;                 // staged source rows
+constexpr int WS_H = WT_H + 8;           // staged source rows (multiple of 4)
+constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;   // fill items per thread: (row quads x column groups) / 16 per wave / 4 waves
+// A staged row holds WS_W pixels but is WS_RS slots long: 81 slots = 1296 bytes = 16 (mod 128), so the fill's ds_write_b128
+// (8-lane groups = 4 rows x 2 column groups, 64-byte column-group stride) touch every bank once.
+constexpr int WS_RS = WS_W + 1;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef const __attribute__((address_space(3))) f4* lds_f4;
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
@@ -54,78 +74,169 @@ __device__ __forceinline__ uint32_t store_u(float v, float maxv) {
     return (uint32_t)__builtin_amdgcn_fmed3f(v + 0.5f, 0.0f, maxv);
 }
 
-// generators.cpp:31-47 on an {x,y} pair: identical roundings per component, packed instructions.
-// EDGE = the argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]); for taps 2
-// and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
 // Three correctly rounded quotients over one denominator.  This is hipcc's own fp32 division expansion
 // (v_div_scale, v_rcp, two Newton steps on the reciprocal-quotient pair, v_div_fmas, v_div_fixup) with the
 // parts that are no-ops here removed: den is a sum of Lanczos weights (0.99..1.05) and the numerators are
 // bounded byte sums, so no operand scaling and no special-case fix-up ever applies; what is left is the
 // same fma sequence, and the reciprocal refinement is shared by the three channels (18 instructions
-// instead of 33).  Outside the safe range it falls back to operator/.
-__device__ __forceinline__ void div3_exact(float n0, float n1, float n2, float den, float& q0, float& q1, float& q2) {
-    if (den > 0.5f && den < 2.0f) {
-        float r = __builtin_amdgcn_rcpf(den);
-        const float e = __builtin_fmaf(-den, r, 1.0f);
-        r = __builtin_fmaf(e, r, r);
-        float q, t;
-        q = n0 * r; t = __builtin_fmaf(-den, q, n0); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n0); q0 = __builtin_fmaf(t, r, q);
-        q = n1 * r; t = __builtin_fmaf(-den, q, n1); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n1); q1 = __builtin_fmaf(t, r, q);
-        q = n2 * r; t = __builtin_fmaf(-den, q, n2); q = __builtin_fmaf(t, r, q); t = __builtin_fmaf(-den, q, n2); q2 = __builtin_fmaf(t, r, q);
-    } else {
-        q0 = n0 / den; q1 = n1 / den; q2 = n2 / den;
+// instead of 33).  Outside the safe range the caller falls back to operator/ (wave-uniform branch).
+__device__ __forceinline__ void div3_core(float n0, float n1, float n2, float den, float q[3]) {
+    float r = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float a, t;
+    a = n0 * r; t = __builtin_fmaf(-den, a, n0); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n0); q[0] = __builtin_fmaf(t, r, a);
+    a = n1 * r; t = __builtin_fmaf(-den, a, n1); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n1); q[1] = __builtin_fmaf(t, r, a);
+    a = n2 * r; t = __builtin_fmaf(-den, a, n2); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n2); q[2] = __builtin_fmaf(t, r, a);
+}
+
+// Exact Lanczos2 of two output pixels (rows k, k+1 of one lane) from the LDS tile; t[j] = staged pixel (iy-1, ix-1) of
+// pixel j.  Per pixel: the four live taps of the 5-tap window per axis (tap 0 has weight exactly 0) as four packed Horner
+// chains, each holding two adjacent taps of one axis, so the tap products are packed too; {B,G} and {R,den} accumulate as
+// pairs (the tile's trailing 1.0 makes den += w2d part of the same instruction; w2d*1.0 is exact).  Every component sees
+// exactly the reference's sequence of roundings (generators.cpp:31-47, 684-697).  num[j] = {numB, numG, numR, den}.
+__device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], float num[2][4]) {
+    // chain c of pixel j: 0 = x taps {1,2}, 1 = x taps {3,4}, 2 = y taps {1,2}, 3 = y taps {3,4}
+    f2 x[2][4], x2[2][4], v[2][4], mm[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const f2 frx = {fr[j].x, fr[j].x}, fry = {fr[j].y, fr[j].y};
+        x[j][0] = f2{-1.0f, 0.0f} - frx; x[j][1] = f2{1.0f, 2.0f} - frx;
+        x[j][2] = f2{-1.0f, 0.0f} - fry; x[j][3] = f2{1.0f, 2.0f} - fry;
     }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { x2[j][c] = x[j][c] * x[j][c]; v[j][c] = f2{0.000858519f, 0.000858519f}; }
+    const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) mm[j][c] = v[j][c] * x2[j][c];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) v[j][c] = C[s] + mm[j][c];
+    }
+    // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        v[j][0].x = fabsf(x[j][0].x) >= 2.0f ? 0.0f : v[j][0].x;
+        v[j][1].y = fabsf(x[j][1].y) >= 2.0f ? 0.0f : v[j][1].y;
+        v[j][2].x = fabsf(x[j][2].x) >= 2.0f ? 0.0f : v[j][2].x;
+        v[j][3].y = fabsf(x[j][3].y) >= 2.0f ? 0.0f : v[j][3].y;
+    }
+    f2 nbg[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, nrd[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+        f2 p01[2], p23[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float wy = (ry & 1) ? v[j][2 + (ry >> 1)].y : v[j][2 + (ry >> 1)].x;
+            const f2 wyy = {wy, wy};
+            p01[j] = v[j][0] * wyy; p23[j] = v[j][1] * wyy;               // w2d = wx[rx] * wy[ry]
+        }
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+            f2 mbg[2], mrd[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const f4 val = t[j][ry * WS_RS + rx];
+                const f2 pp = rx < 2 ? p01[j] : p23[j];
+                const float w2d = (rx & 1) ? pp.y : pp.x;
+                const f2 ww = {w2d, w2d};
+                mbg[j] = ww * f2{val.x, val.y};
+                mrd[j] = ww * f2{val.z, val.w};
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                nbg[j] = nbg[j] + mbg[j];                  // num_B, num_G
+                nrd[j] = nrd[j] + mrd[j];                  // num_R, den (val.w == 1: den + w2d*1 == den + w2d)
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { num[j][0] = nbg[j].x; num[j][1] = nbg[j].y; num[j][2] = nrd[j].x; num[j][3] = nrd[j].y; }
 }
 
-// u16 pixels: a pair of lanes owns 2 pixels = 12 bytes = 3 dwords {B0|G0, R0|B1, G1|R1}
-__device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, uint32_t& d0, uint32_t& d1) {
-    const uint32_t bg = o[0] | (o[1] << 16);
-    const uint32_t nbg = (uint32_t)dpp_mov0<0x101>((int)bg);   // row_shl:1 (only even lanes use it)
-    d0 = odd ? (o[1] | (o[2] << 16)) : bg;            // odd lane: G1|R1 ; even lane: B0|G0
-    d1 = o[2] | (nbg << 16);                           // even lane only: R0|B1
+// VS_WARP_LANCZOS2_FAST of two output pixels: vs_device.hpp's lanczos2_fma / lanczos_fast_rden / lanczos_fast_combine,
+// written out for the LDS tile.  Everything is scalar fp32: on gfx950 a packed fp32 instruction costs the issue time of
+// two scalar ones AND slows the scalar instructions around it (tools/ubench_mix.hip: fma alone 3.2 cycles, pk_fma 5.6,
+// a 3:1 mix 4.9 per instruction), so a stream without packed instructions is the fastest form of the same arithmetic.
+__device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], float q[2][3]) {
+    // weight chain c of pixel j: 0..3 = x taps 1..4, 4..7 = y taps 1..4
+    float x[2][8], x2[2][8], v[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        x[j][0] = -1.0f - fr[j].x; x[j][1] = 0.0f - fr[j].x; x[j][2] = 1.0f - fr[j].x; x[j][3] = 2.0f - fr[j].x;
+        x[j][4] = -1.0f - fr[j].y; x[j][5] = 0.0f - fr[j].y; x[j][6] = 1.0f - fr[j].y; x[j][7] = 2.0f - fr[j].y;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { x2[j][c] = x[j][c] * x[j][c]; v[j][c] = 0.000858519f; }
+    const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
+#pragma unroll
+    for (int s = 0; s < 6; s++)
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) v[j][c] = __builtin_fmaf(v[j][c], x2[j][c], C[s]);
+    float rden[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
+        v[j][0] = fabsf(x[j][0]) >= 2.0f ? 0.0f : v[j][0];
+        v[j][3] = fabsf(x[j][3]) >= 2.0f ? 0.0f : v[j][3];
+        v[j][4] = fabsf(x[j][4]) >= 2.0f ? 0.0f : v[j][4];
+        v[j][7] = fabsf(x[j][7]) >= 2.0f ? 0.0f : v[j][7];
+        rden[j] = lanczos_fast_rden(&v[j][0], &v[j][4]);
+    }
+    float n[2][3];
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+        float hh[2][3];
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const f4 val = t[j][ry * WS_RS + rx];
+                const float w = v[j][rx];
+                if (rx == 0) { hh[j][0] = w * val.x; hh[j][1] = w * val.y; hh[j][2] = w * val.z; }
+                else {
+                    hh[j][0] = __builtin_fmaf(w, val.x, hh[j][0]);
+                    hh[j][1] = __builtin_fmaf(w, val.y, hh[j][1]);
+                    hh[j][2] = __builtin_fmaf(w, val.z, hh[j][2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float wy = v[j][4 + ry];
+#pragma unroll
+            for (int c = 0; c < 3; c++) n[j][c] = ry == 0 ? wy * hh[j][c] : __builtin_fmaf(wy, hh[j][c], n[j][c]);
+        }
+        if (VS_WARP_FAST_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { q[j][0] = n[j][0] * rden[j]; q[j][1] = n[j][1] * rden[j]; q[j][2] = n[j][2] * rden[j]; }
 }
 
-// EDGE_X / EDGE_Y: that component's argument can reach |x| >= 2 (taps 1 and 4: -1-frac, 2-frac with frac in [0,1]);
-// for taps 2 and 3 (|x| <= 1) the select of generators.cpp:46 can never fire and is dropped.
-template <bool EDGE_X, bool EDGE_Y>
-__device__ __forceinline__ f2 lanczos2_pk(f2 x) {
-    f2 x2 = x * x;
-    f2 v = 0.000858519f;
-    v = -0.0158853f + v * x2;
-    v = 0.128693f + v * x2;
-    v = -0.583468f + v * x2;
-    v = 1.52229f + v * x2;
-    v = -2.05238f + v * x2;
-    v = 0.999861f + v * x2;
-    if (EDGE_X) v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
-    if (EDGE_Y) v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
-    return v;
-}
-
-// VS_WARP_LANCZOS2_FAST: the same polynomial with every multiply-add fused (v_pk_fma_f32): one rounding per Horner step
-// instead of two.  Not the reference's sequence of roundings any more -- results stay within the north star's 1 ULP /
-// 1 LSB gate of the exact kernel (tests/test_kernels_gpu.py), at ~0.6x the VALU work.
-template <bool EDGE_X, bool EDGE_Y>
-__device__ __forceinline__ f2 lanczos2_pk_fma(f2 x) {
-    const f2 x2 = x * x;
-    f2 v = 0.000858519f;
-    v = __builtin_elementwise_fma(v, x2, (f2)(-0.0158853f));
-    v = __builtin_elementwise_fma(v, x2, (f2)(0.128693f));
-    v = __builtin_elementwise_fma(v, x2, (f2)(-0.583468f));
-    v = __builtin_elementwise_fma(v, x2, (f2)(1.52229f));
-    v = __builtin_elementwise_fma(v, x2, (f2)(-2.05238f));
-    v = __builtin_elementwise_fma(v, x2, (f2)(0.999861f));
-    if (EDGE_X) v.x = fabsf(x.x) >= 2.0f ? 0.0f : v.x;
-    if (EDGE_Y) v.y = fabsf(x.y) >= 2.0f ? 0.0f : v.y;
-    return v;
-}
-
-// 4 adjacent lanes hold one BGR pixel each (p = B | G<<8 | R<<16); lanes 0..2 of the quad assemble the three
-// dwords of the 12-byte group from their own pixel and their right neighbour's: bytes m..m+3 of {own, next}.
-__device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, int m) {
-    const uint32_t q = (uint32_t)dpp_mov0<0x101>((int)p);   // row_shl:1 = the right neighbour's pixel (lane 3 of a quad ignores it)
-    const uint32_t lo = p | (q << 24), hi = q >> 8;
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)m);
+// image_warp's bilinear (generators.cpp:148-163) per channel; t = staged pixel (iy, ix)
+__device__ __forceinline__ void sample_bilinear(lds_f4 t, f2 fr, float q[3]) {
+    const f4 a0 = t[0], a1 = t[1], b0 = t[WS_RS], b1 = t[WS_RS + 1];
+    const f2 tx = {fr.x, fr.x}, ty = {fr.y, fr.y};
+    const f2 otx = 1.0f - tx, oty = 1.0f - ty;
+    // lerp(a,b,t) = a*(1-t) + b*t (generators.cpp:161-163), {B,G} and {R,-} pairs
+    const f2 top_bg = f2{a0.x, a0.y} * otx + f2{a1.x, a1.y} * tx;
+    const f2 bot_bg = f2{b0.x, b0.y} * otx + f2{b1.x, b1.y} * tx;
+    const f2 top_r = f2{a0.z, a0.z} * otx + f2{a1.z, a1.z} * tx;
+    const f2 bot_r = f2{b0.z, b0.z} * otx + f2{b1.z, b1.z} * tx;
+    const f2 bg = top_bg * oty + bot_bg * ty;
+    const f2 rr = top_r * oty + bot_r * ty;
+    q[0] = bg.x; q[1] = bg.y; q[2] = rr.x;
 }
 
 template <typename T, int MODE, int BORDER>
@@ -138,7 +249,7 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
         if (BORDER == 1) return (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : (float)src[(size_t)sy * stride + (size_t)sx * 3 + c];
         return (float)src[(size_t)clampi(sy, 0, h - 1) * stride + (size_t)clampi(sx, 0, w - 1) * 3 + c];
     };
-    if (MODE == 0 || MODE == 2) {   // the rare tiles on this path keep the exact arithmetic in the fast mode too
+    if (MODE == 0) {
         float wx[4], wy[4];
         lanczos_weights4(frx, wx);
         lanczos_weights4(fry, wy);
@@ -154,6 +265,19 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
             }
 #pragma unroll
         for (int c = 0; c < 3; c++) out[c] = store_u(num[c] / den, maxv);
+    } else if (MODE == 2) {
+        float wx[4], wy[4];
+        lanczos_weights4_fma(frx, wx);
+        lanczos_weights4_fma(fry, wy);
+        const float rden = lanczos_fast_rden(wx, wy);
+        for (int c = 0; c < 3; c++) {
+            float v[4][4];
+#pragma unroll
+            for (int ry = 0; ry < 4; ry++)
+#pragma unroll
+                for (int rx = 0; rx < 4; rx++) v[ry][rx] = fetch(ix + rx - 1, iy + ry - 1, c);
+            out[c] = store_u(lanczos_fast_combine(v, wx, wy, rden), maxv);
+        }
     } else {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -164,20 +288,47 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
     }
 }
 
+// 4 adjacent lanes hold one BGR pixel each (p = B | G<<8 | R<<16); lanes 0..2 of the quad assemble the three
+// dwords of the 12-byte group from their own pixel and their right neighbour's: bytes m..m+3 of {own 3 bytes, next 3 bytes}
+// = one v_perm_b32 with a per-lane selector (v_perm byte indices: 0-3 = second operand, 4-7 = first operand).
+__device__ __forceinline__ uint32_t quad_sel(int m) {
+    return m == 0 ? 0x04020100u : (m == 1 ? 0x05040201u : 0x06050402u);
+}
+__device__ __forceinline__ uint32_t quad_pack_bgr(uint32_t p, uint32_t sel) {
+    const uint32_t q = (uint32_t)dpp_mov0<0x101>((int)p);   // row_shl:1 = the right neighbour's pixel (lane 3 of a quad ignores it)
+    return __builtin_amdgcn_perm(q, p, sel);
+}
+
+// u16 pixels: a pair of lanes owns 2 pixels = 12 bytes = 3 dwords {B0|G0, R0|B1, G1|R1}
+__device__ __forceinline__ void pair_pack_bgr16(const uint32_t o[3], int odd, uint32_t& d0, uint32_t& d1) {
+    const uint32_t bg = o[0] | (o[1] << 16);
+    const uint32_t nbg = (uint32_t)dpp_mov0<0x101>((int)bg);   // row_shl:1 (only even lanes use it)
+    d0 = odd ? (o[1] | (o[2] << 16)) : bg;            // odd lane: G1|R1 ; even lane: B0|G0
+    d1 = o[2] | (nbg << 16);                           // even lane only: R0|B1
+}
+
+// fill item of lane (rr = lane & 3, pair index p): rows 4 * (p / 20) + rr, column group p % 20 (4 source pixels)
+struct FillItem { int row, g; };
+__device__ __forceinline__ FillItem fill_item(int lane, int slot) {
+    const int p = (lane >> 2) + 16 * slot;                   // < 256
+    const int rq = (p * 205) >> 12;                          // p / 20
+    return FillItem{4 * rq + (lane & 3), p - 20 * rq};
+}
+
 template <typename T, int MODE, int BORDER>
-__global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ src, int w, int h, int src_stride,
-                                                        const float4* __restrict__ params, T* __restrict__ dst,
-                                                        int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x,
-                                                        int tiles_per_frame, int total_tiles, int chunk, float maxv,
-                                                        vsk::Roi roi) {
-    __shared__ f4 tile[WS_H * WS_W];                       // {B,G,R,1} per staged source pixel
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
-    // workgroup b works on logical tile (b % 8) * chunk + b / 8: every XCD walks one contiguous run of
-    // tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
-    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (logical >= total_tiles) return;
-    const int frame = logical / tiles_per_frame, tl = logical - frame * tiles_per_frame;
-    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EXACT_MINWAVES) void vs_k_bgr_warp_c3(
+    const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
+    int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
+    float maxv, vsk::Roi roi) {
+    __shared__ f4 tile[WS_H * WS_RS];                      // {B,G,R,1} per staged source pixel
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id order and
+    // gridDim.x is a multiple of 8, so workgroup b of a frame works on its tile (b % 8) * chunk + b / 8: every XCD walks
+    // one contiguous run of tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
+    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tl >= tiles_per_frame) return;
+    const int frame = blockIdx.y;
+    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);         // tl / tiles_x (scalar unit)
+    const int txi = tl - tyi * tiles_x;
     const float4 P = params[frame];
     src += (size_t)frame * src_fs;
     dst += (size_t)frame * dst_fs;
@@ -197,54 +348,68 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
     const float yc = A1 >= 0.f ? fy0 : fy1, yd = A1 >= 0.f ? fy1 : fy0;
     const float mny = B * xc + A1 * yc + TY, mxy = B * xd + A1 * yd + TY;
     bool fits = fabsf(mnx) < 1.0e6f && fabsf(mxx) < 1.0e6f && fabsf(mny) < 1.0e6f && fabsf(mxy) < 1.0e6f;
-    int sx_lo = 0, sy_lo = 0;
+    int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
     if (fits) {
         sx_lo = ((int)floorf(mnx) - 1) & ~3;               // first staged column: a multiple of 4 pixels (12 bytes)
         const int sx_hi = (int)floorf(mxx) + 2;
         sy_lo = (int)floorf(mny) - 1;
         const int sy_hi = (int)floorf(mxy) + 2;
-        fits = (sx_hi - sx_lo + 1) <= WS_W && (sy_hi - sy_lo + 1) <= WS_H;
-        if (fits) {
-            // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4
-            const int rows = sy_hi - sy_lo + 1;
-            const int groups = (sx_hi - sx_lo + 4) >> 2;              // <= 20
-            const uint32_t inv_groups = 65536u / (uint32_t)groups + 1u;  // i / groups == (i * inv) >> 16 for i < 24*20
-            for (int i = threadIdx.x; i < rows * groups; i += 256) {
-                const int r = (int)(((uint32_t)i * inv_groups) >> 16), g = i - r * groups;
-                const int sy = sy_lo + r, sx = sx_lo + 4 * g;
-                f4* t = tile + r * WS_W + 4 * g;
-                const bool row_in = sy >= 0 && sy < h;
-                if (BORDER == 1 && !row_in) {
-                    const f4 z = {0.f, 0.f, 0.f, 1.f};
-                    t[0] = z; t[1] = z; t[2] = z; t[3] = z;
-                    continue;
-                }
-                const T* row = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
-                if (sx >= 0 && sx + 3 < w && ((((uintptr_t)(row + sx * 3)) & 3) == 0)) {
-                    if (sizeof(T) == 1) {
-                        const u32x3 q = *(const u32x3*)(row + sx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                        t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
-                        t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
-                        t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
-                        t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
-                    } else {
-                        const u32x3 q0 = *(const u32x3*)(row + sx * 3), q1 = *(const u32x3*)(row + sx * 3 + 6);
-                        // q0 = B0G0 R0B1 G1R1 ; q1 = B2G2 R2B3 G3R3 (16 bits each)
-                        t[0] = f4{(float)(q0.x & 0xffffu), (float)(q0.x >> 16), (float)(q0.y & 0xffffu), 1.f};
-                        t[1] = f4{(float)(q0.y >> 16), (float)(q0.z & 0xffffu), (float)(q0.z >> 16), 1.f};
-                        t[2] = f4{(float)(q1.x & 0xffffu), (float)(q1.x >> 16), (float)(q1.y & 0xffffu), 1.f};
-                        t[3] = f4{(float)(q1.y >> 16), (float)(q1.z & 0xffffu), (float)(q1.z >> 16), 1.f};
-                    }
-                } else {
+        rows = sy_hi - sy_lo + 1;
+        groups = (sx_hi - sx_lo + 4) >> 2;                 // column groups of 4 pixels
+        fits = groups <= WS_W / 4 && rows <= WS_H;
+    }
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (fits) {
+        // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
+        // (16 + 8) rows x 20 groups = 480 items = 2 per thread; all loads are issued before the first conversion.
+        const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)((size_t)src_stride * sizeof(T))) & 3) == 0;   // uniform
+        FillItem it[FILL_SLOTS];
+        bool live[FILL_SLOTS], direct[FILL_SLOTS];
+        const T* rowp[FILL_SLOTS];
+        u32x3 q0[FILL_SLOTS], q1[FILL_SLOTS];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int px = sx + k;
-                        if (BORDER == 1 && (px < 0 || px >= w)) {
-                            t[k] = f4{0.f, 0.f, 0.f, 1.f};
-                        } else {
-                            const T* q = row + clampi(px, 0, w - 1) * 3;
-                            t[k] = f4{(float)q[0], (float)q[1], (float)q[2], 1.f};
-                        }
+        for (int s = 0; s < FILL_SLOTS; s++) {
+            it[s] = fill_item(lane, wv + 4 * s);
+            live[s] = it[s].row < rows && it[s].g < groups;
+            const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+            rowp[s] = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
+            const bool row_in = sy >= 0 && sy < h;
+            direct[s] = live[s] && src_aligned && sx >= 0 && sx + 3 < w && (BORDER == 0 || row_in);
+            if (direct[s]) {
+                q0[s] = *(const u32x3*)(rowp[s] + sx * 3);
+                if (sizeof(T) == 2) q1[s] = *(const u32x3*)(rowp[s] + sx * 3 + 6);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            f4* t = tile + it[s].row * WS_RS + 4 * it[s].g;
+            if (direct[s]) {
+                if (sizeof(T) == 1) {
+                    const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+                    t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
+                    t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
+                    t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
+                    t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
+                } else {
+                    const u32x3 a = q0[s], b = q1[s];        // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3 (16 bits each)
+                    t[0] = f4{(float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), 1.f};
+                    t[1] = f4{(float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), 1.f};
+                    t[2] = f4{(float)(b.x & 0xffffu), (float)(b.x >> 16), (float)(b.y & 0xffffu), 1.f};
+                    t[3] = f4{(float)(b.y >> 16), (float)(b.z & 0xffffu), (float)(b.z >> 16), 1.f};
+                }
+            } else {
+                // frame border, an unaligned frame, or (constant border) a row outside the frame: pixel by pixel
+                const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+                const bool row_in = sy >= 0 && sy < h;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int px = sx + k;
+                    if (BORDER == 1 && (!row_in || px < 0 || px >= w)) {
+                        t[k] = f4{0.f, 0.f, 0.f, 1.f};
+                    } else {
+                        const T* q = rowp[s] + clampi(px, 0, w - 1) * 3;
+                        t[k] = f4{(float)q[0], (float)q[1], (float)q[2], 1.f};
                     }
                 }
             }
@@ -252,123 +417,133 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_c3(const T* __restrict__ sr
     }
     __syncthreads();
 
-    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = x0 + lx;
-    const float fx = (float)(x + roi.x);
-    const float A1x = A1 * fx, Bx = B * fx;
+    const int x = x0 + lane;
+    const int yw = y0 + wv * RPW;                            // first row of this wave
+    if (yw >= roi.h) return;                                 // wave-uniform
     // a quad of lanes owns 4 pixels = 12 output bytes; it stores them as 3 aligned dwords when the whole
-    // quad is inside the row and the row is dword aligned, else byte by byte
-    const int m = lx & 3;
-    const bool quad_in = (x | 3) < roi.w;
+    // quad is inside the row and every row is dword aligned, else byte by byte
+    const int m = lane & 3;
+    const bool rows_aligned = ((((uintptr_t)dst) | (uintptr_t)((size_t)dst_stride * sizeof(T))) & 3) == 0;   // uniform
+
+    if (!fits) {
+        // footprint too large for the LDS window: per-pixel taps through L1 / L2
+        for (int k = 0; k < RPW; k++) {
+            const int y = yw + k;
+            if (y >= roi.h || x >= roi.w) continue;
+            const float fx = (float)(x + roi.x), fy = (float)(y + roi.y);
+            const float Wx = A1 * fx - B * fy + TX, Wy = B * fx + A1 * fy + TY;
+            uint32_t o[3];
+            warp_pixel_global<T, MODE, BORDER>(src, w, h, src_stride, Wx, Wy, maxv, o);
+            T* q = dst + (size_t)y * dst_stride + (size_t)x * 3;
+            q[0] = (T)o[0]; q[1] = (T)o[1]; q[2] = (T)o[2];
+        }
+        return;
+    }
+
+    // ---- the four rows of this wave, one straight-line block ----
+    const int xq = min(x, roi.w - 1);                        // lanes right of the window sample its last column (masked below)
+    const float fx = (float)(xq + roi.x);
+    const float A1x = A1 * fx, Bx = B * fx;
+    // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
+    constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
+    const float c0 = -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
+    uint32_t o[RPW][3];
+    float num[RPW][4];                                         // exact mode: {numB, numG, numR, den} kept for the operator/ fallback
+    bool all_ok = true;
+    // rows are processed two at a time, the two rows' instructions alternating in source order: a packed-fp32 result
+    // cannot feed the very next VALU instruction without a wait state on gfx950, and the other row's operation fills it
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int y = y0 + wv * 4 + k;
-        if (y >= roi.h) break;                           // wave-uniform
-        uint32_t o[3] = {0, 0, 0};
-        if (x < roi.w) {
-            const float fy = (float)(y + roi.y);
-            const float Wx = A1x - B * fy + TX;          // generators.cpp:141
-            const float Wy = Bx + A1 * fy + TY;          // generators.cpp:142
-            if (!fits) {
-                warp_pixel_global<T, MODE, BORDER>(src, w, h, src_stride, Wx, Wy, maxv, o);
-            } else {
-                const float flx = floorf(Wx), fly = floorf(Wy);
-                const int ix = (int)flx, iy = (int)fly;
-                const f2 fr = {Wx - flx, Wy - fly};
-                if (MODE == 0) {
-                    // the four live taps of the 5-tap window (tap 0 has weight exactly 0): four packed Horner chains,
-                    // each holding two adjacent taps of one axis, so the tap products below are packed too
-                    const f2 frx = {fr.x, fr.x}, fry = {fr.y, fr.y};
-                    const f2 wx01 = lanczos2_pk<true, false>(f2{-1.0f, 0.0f} - frx), wx23 = lanczos2_pk<false, true>(f2{1.0f, 2.0f} - frx);
-                    const f2 wy01 = lanczos2_pk<true, false>(f2{-1.0f, 0.0f} - fry), wy23 = lanczos2_pk<false, true>(f2{1.0f, 2.0f} - fry);
-                    const float wy[4] = {wy01.x, wy01.y, wy23.x, wy23.y};
-                    const f4* t = tile + (iy - 1 - sy_lo) * WS_W + (ix - 1 - sx_lo);
-                    f2 nbg = {0.f, 0.f}, nrd = {0.f, 0.f};
+    for (int kp = 0; kp < RPW; kp += 2) {
+        f2 fr[2];
+        lds_f4 t[2];
 #pragma unroll
-                    for (int ry = 0; ry < 4; ry++) {
-                        const f2 wyy = {wy[ry], wy[ry]};
-                        const f2 p01 = wx01 * wyy, p23 = wx23 * wyy;              // w2d = wx[rx] * wy[ry]
-                        const float w2d[4] = {p01.x, p01.y, p23.x, p23.y};
+        for (int j = 0; j < 2; j++) {
+            const int yq = min(yw + kp + j, roi.h - 1);      // rows below the window repeat its last row (masked below)
+            const float fy = (float)(yq + roi.y);
+            const float Wx = A1x - B * fy + TX;              // generators.cpp:141
+            const float Wy = Bx + A1 * fy + TY;              // generators.cpp:142
+            const float flx = floorf(Wx), fly = floorf(Wy);
+            fr[j] = f2{Wx - flx, Wy - fly};
+            const int boff = (int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0));
+            t[j] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
+        }
+        float q[2][3];
+        if (MODE == 0) {
+            exact_pair(t, fr, &num[kp]);
 #pragma unroll
-                        for (int rx = 0; rx < 4; rx++) {
-                            const f4 v = t[ry * WS_W + rx];
-                            const f2 ww = {w2d[rx], w2d[rx]};
-                            nbg = nbg + ww * f2{v.x, v.y};       // num_B, num_G
-                            nrd = nrd + ww * f2{v.z, v.w};       // num_R, den (v.w == 1: den + w2d*1 == den + w2d)
-                        }
-                    }
-                    float qb, qg, qr;
-                    div3_exact(nbg.x, nbg.y, nrd.x, nrd.y, qb, qg, qr);
-                    o[0] = store_u(qb, maxv);
-                    o[1] = store_u(qg, maxv);
-                    o[2] = store_u(qr, maxv);
-                } else if (MODE == 2) {
-                    // VS_WARP_LANCZOS2_FAST: fused multiply-adds for the weights and the tap sums, one refined reciprocal
-                    const f2 frx = {fr.x, fr.x}, fry = {fr.y, fr.y};
-                    const f2 wx01 = lanczos2_pk_fma<true, false>(f2{-1.0f, 0.0f} - frx), wx23 = lanczos2_pk_fma<false, true>(f2{1.0f, 2.0f} - frx);
-                    const f2 wy01 = lanczos2_pk_fma<true, false>(f2{-1.0f, 0.0f} - fry), wy23 = lanczos2_pk_fma<false, true>(f2{1.0f, 2.0f} - fry);
-                    const float wy[4] = {wy01.x, wy01.y, wy23.x, wy23.y};
-                    const f4* t = tile + (iy - 1 - sy_lo) * WS_W + (ix - 1 - sx_lo);
-                    f2 nbg = {0.f, 0.f}, nrd = {0.f, 0.f};
+            for (int j = 0; j < 2; j++) {
+                all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
+                div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
+            }
+        } else if (MODE == 2) {
+            fast_pair(t, fr, q);
+        } else {
+            sample_bilinear(t[0], fr[0], q[0]);
+            sample_bilinear(t[1], fr[1], q[1]);
+        }
 #pragma unroll
-                    for (int ry = 0; ry < 4; ry++) {
-                        const f2 wyy = {wy[ry], wy[ry]};
-                        const f2 p01 = wx01 * wyy, p23 = wx23 * wyy;
-                        const float w2d[4] = {p01.x, p01.y, p23.x, p23.y};
+        for (int j = 0; j < 2; j++) {
+            o[kp + j][0] = store_u(q[j][0], maxv);
+            o[kp + j][1] = store_u(q[j][1], maxv);
+            o[kp + j][2] = store_u(q[j][2], maxv);
+        }
+        if (MODE == 2 && VS_WARP_FAST_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // keeps the second pair's 32 LDS reads (128 VGPRs) behind the first pair
+    }
+    if (MODE == 0 && __any(!all_ok)) {
+        // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
-                        for (int rx = 0; rx < 4; rx++) {
-                            const f4 v = t[ry * WS_W + rx];
-                            const f2 ww = {w2d[rx], w2d[rx]};
-                            nbg = __builtin_elementwise_fma(ww, f2{v.x, v.y}, nbg);
-                            nrd = __builtin_elementwise_fma(ww, f2{v.z, v.w}, nrd);
-                        }
-                    }
-                    float r = __builtin_amdgcn_rcpf(nrd.y);
-                    r = __builtin_fmaf(__builtin_fmaf(-nrd.y, r, 1.0f), r, r);       // one Newton step: ~0.5 ULP reciprocal
-                    o[0] = store_u(nbg.x * r, maxv);
-                    o[1] = store_u(nbg.y * r, maxv);
-                    o[2] = store_u(nrd.x * r, maxv);
-                } else {
-                    const f4* t = tile + (iy - sy_lo) * WS_W + (ix - sx_lo);
-                    const f4 a0 = t[0], a1 = t[1], b0 = t[WS_W], b1 = t[WS_W + 1];
-                    const f2 tx = {fr.x, fr.x}, ty = {fr.y, fr.y};
-                    const f2 otx = 1.0f - tx, oty = 1.0f - ty;
-                    // lerp(a,b,t) = a*(1-t) + b*t (generators.cpp:161-163), {B,G} and {R,-} pairs
-                    const f2 top_bg = f2{a0.x, a0.y} * otx + f2{a1.x, a1.y} * tx;
-                    const f2 bot_bg = f2{b0.x, b0.y} * otx + f2{b1.x, b1.y} * tx;
-                    const f2 top_r = f2{a0.z, a0.z} * otx + f2{a1.z, a1.z} * tx;
-                    const f2 bot_r = f2{b0.z, b0.z} * otx + f2{b1.z, b1.z} * tx;
-                    const f2 bg = top_bg * oty + bot_bg * ty;
-                    const f2 rr = top_r * oty + bot_r * ty;
-                    o[0] = store_u(bg.x, maxv);
-                    o[1] = store_u(bg.y, maxv);
-                    o[2] = store_u(rr.x, maxv);
+        for (int k = 0; k < RPW; k++) {
+            float den = num[k][3];
+            asm volatile("" : "+v"(den));                    // keeps the three divisions inside this branch (no speculation)
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[k][c] = store_u(num[k][c] / den, maxv);
+        }
+    }
+
+    // ---- stores ----
+    // all four rows are final here: without this pin the compiler sinks each row's arithmetic into the conditional store
+    // blocks below while its LDS reads stay hoisted at the top, and the tile values spill to scratch in between
+#pragma unroll
+    for (int k = 0; k < RPW; k++) asm volatile("" :: "v"(o[k][0]), "v"(o[k][1]), "v"(o[k][2]));
+    const bool lane_in = x < roi.w;
+    if (sizeof(T) == 1) {
+        const bool quad_in = (x | 3) < roi.w;
+        const uint32_t sel = quad_sel(m);
+        const uint32_t loff = (uint32_t)(x & ~3) * 3u + 4u * (uint32_t)m;
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const int y = yw + k;
+            const uint32_t p = o[k][0] | (o[k][1] << 8) | (o[k][2] << 16);
+            const uint32_t d = quad_pack_bgr(p, sel);        // every lane of the wave takes part in the shuffle
+            if (y < roi.h) {                                 // wave-uniform
+                uint8_t* orow = (uint8_t*)dst + (size_t)y * dst_stride;
+                if (rows_aligned && quad_in) {
+                    if (m < 3) *(uint32_t*)(orow + loff) = d;
+                } else if (lane_in) {
+                    orow[(size_t)x * 3] = (uint8_t)o[k][0];
+                    orow[(size_t)x * 3 + 1] = (uint8_t)o[k][1];
+                    orow[(size_t)x * 3 + 2] = (uint8_t)o[k][2];
                 }
             }
         }
-        T* orow = dst + (size_t)y * dst_stride;
-        if (sizeof(T) == 1) {
-            const uint32_t p = o[0] | (o[1] << 8) | (o[2] << 16);
-            const uint32_t d = quad_pack_bgr(p, m);          // every lane of the wave takes part in the shuffle
-            if (quad_in && ((((uintptr_t)orow) & 3) == 0)) {
-                if (m < 3) *(uint32_t*)((uint8_t*)orow + (size_t)(x & ~3) * 3 + 4 * m) = d;
-            } else if (x < roi.w) {
-                orow[(size_t)x * 3] = (T)o[0];
-                orow[(size_t)x * 3 + 1] = (T)o[1];
-                orow[(size_t)x * 3 + 2] = (T)o[2];
-            }
-        } else {
+    } else {
+        const bool pair_in = (x | 1) < roi.w;
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const int y = yw + k;
             uint32_t d0, d1;
-            pair_pack_bgr16(o, x & 1, d0, d1);
-            const bool pair_in = (x | 1) < roi.w;
-            if (pair_in && ((((uintptr_t)orow) & 3) == 0)) {
-                uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
-                if (x & 1) q[2] = d0;
-                else { q[0] = d0; q[1] = d1; }
-            } else if (x < roi.w) {
-                orow[(size_t)x * 3] = (T)o[0];
-                orow[(size_t)x * 3 + 1] = (T)o[1];
-                orow[(size_t)x * 3 + 2] = (T)o[2];
+            pair_pack_bgr16(o[k], x & 1, d0, d1);
+            if (y < roi.h) {
+                T* orow = dst + (size_t)y * dst_stride;
+                if (rows_aligned && pair_in) {
+                    uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
+                    if (x & 1) q[2] = d0;
+                    else { q[0] = d0; q[1] = d1; }
+                } else if (lane_in) {
+                    orow[(size_t)x * 3] = (T)o[k][0];
+                    orow[(size_t)x * 3 + 1] = (T)o[k][1];
+                    orow[(size_t)x * 3 + 2] = (T)o[k][2];
+                }
             }
         }
     }
@@ -382,19 +557,27 @@ template <typename T>
 static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border, T* dst,
                             int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + WT_H - 1) / WT_H;
-    const long long total = (long long)tiles_x * tiles_y * n_frames;
-    if (total > 0x3fffffffLL) return hipErrorNotSupported;
-    const int chunk = (int)((total + 7) / 8);
-    dim3 grid((unsigned)(chunk * 8)), block(256);
+    const long long tpf = (long long)tiles_x * tiles_y;
+    if (tpf > 0x3fffffLL) return hipErrorNotSupported;
+    const int chunk = (int)((tpf + 7) / 8);
+    // tl / tiles_x == (tl * magic) >> 32 for every tl with tl * tiles_x < 2^32 (tiles_x >= 2; the kernel special-cases 1)
+    const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {         // gridDim.y limit
+        const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+        const T* sp = src + (size_t)f0 * src_fs;
+        T* dp = dst + (size_t)f0 * dst_fs;
+        const float4* pp = params_dev + f0;
+        dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
 #define VS_LAUNCH(M, Bd) \
-    hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, src, w, h, src_stride, params_dev, dst, dst_stride, src_fs, dst_fs, \
-                       tiles_x, tiles_x * tiles_y, (int)total, chunk, maxv, roi)
-    if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
-    else if (mode == 0) VS_LAUNCH(0, 1);
-    else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
-    else if (mode == 2) VS_LAUNCH(2, 1);
-    else if (border == 0) VS_LAUNCH(1, 0);
-    else VS_LAUNCH(1, 1);
+        hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
+                           tiles_x, magic, (int)tpf, chunk, maxv, roi)
+        if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
+        else if (mode == 0) VS_LAUNCH(0, 1);
+        else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
+        else if (mode == 2) VS_LAUNCH(2, 1);
+        else if (border == 0) VS_LAUNCH(1, 0);
+        else VS_LAUNCH(1, 1);
+    }
 #undef VS_LAUNCH
     return hipGetLastError();
 }
