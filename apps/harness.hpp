@@ -19,7 +19,17 @@ inline void hip_check(hipError_t e, const char* what) {
 inline void vs_check(int r, const char* what) {
     if (r < 0) throw std::runtime_error(std::string(what) + ": " + vs_last_error());
 }
-inline int vs_format_of(const vsio::Format& f) { return f.bits > 8 ? VS_FMT_BGR16 : VS_FMT_BGR8; }
+// sample depth -> frame format; depths the library has no format for are refused (the aligner's luma shift and the warp's
+// saturation value follow the format)
+inline int vs_format_of(const vsio::Format& f) {
+    switch (f.bits) {
+        case 8: return VS_FMT_BGR8;
+        case 10: return VS_FMT_BGR10;
+        case 12: return VS_FMT_BGR12;
+        case 16: return VS_FMT_BGR16_FULL;
+        default: throw std::runtime_error("unsupported sample depth " + std::to_string(f.bits) + " (8, 10, 12 or 16 bits)");
+    }
+}
 
 struct DeviceBuffer {
     void* ptr = nullptr;

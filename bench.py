@@ -16,14 +16,23 @@ but the barriers that bracket the timed region and one max/sum all-reduce for th
 
 The JSON line also carries
   roofline      the dominant kernel of the timed region (bgr_image_warp): algorithmic bytes / mean launch time, HIP
-                events on the launch stream, against the 8 TB/s HBM peak; `traffic` from the committed PMC passes
+                events on the launch stream, against the 8 TB/s HBM peak; `traffic` scaled from the committed PMC passes
+  roofline_4k   the same kernel where the north star quotes it: 32 x 4K frames per launch, isolated, after the timed
+                region (exact and fast arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
+                the kernel is VALU-issue-bound, the HBM fraction is what that leaves
   align_only    the same clip through the alignment stages alone (configs[1] read literally), with per-stage times
   cpu_baseline  the CPU restatement of the reference path (oracle/, kind "port") on the host cores, bounded sample
 torch is used for device memory, streams, events and torch.distributed only.
+
+--gpus N without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself: N child processes of this
+script, one per GPU, spawned BEFORE this process touches the GPU (the pattern of the reference's only many-clip
+precedent, the worker pool of grid_search_align.cpp:159-210); rank 0's JSON line is the output.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -85,6 +94,80 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
                       "path (not Halide)" % (sample, what, threads)}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def spawn_ranks(n, argv, n_devices_hint=None):
+    """Start ranks 0..n-1 of this script as child processes (fresh interpreters: nothing in this process has touched
+    the GPU, and nothing is exec'ed from a process that has).  LOCAL_RANK i -> device i unless --device overrides it."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
+    """bgr_image_warp where the north star quotes it: `frames` 4K u8 frames per launch, nothing else running."""
+    W, H = 3840, 2160
+    src = torch.randint(0, 256, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint8)
+    dst = torch.empty_like(src)
+    ts = [capi.Transform.of(0.002, -0.0015, 3.3 + 0.37 * i, -2.7 - 0.21 * i) for i in range(frames)]
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
+    except Exception:
+        pass
+    out = {}
+    for name, mode in (("exact", capi.WARP_LANCZOS2), ("fast", capi.WARP_LANCZOS2_FAST)):
+        def run():
+            capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
+                                             max_value=255, stream=stream.cuda_stream)
+        run()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            run()
+            b.record(stream)
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        ms.sort()
+        med = ms[len(ms) // 2]
+        nbytes = W * H * 3 * 2 * frames
+        ach = nbytes / (med * 1e-3) / 1e9
+        p = pmc.get(name, {})
+        out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,%s,clamp>" % ("lanczos2" if name == "exact" else "lanczos2 fast"),
+                     "bound": "hbm", "binding": "valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": int(p["traffic_bytes_per_frame"] * frames) if "traffic_bytes_per_frame" in p else None,
+                     "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
+                     "valu_instr_per_px": p.get("valu_instr_per_px"), "valu_frac": p.get("valu_frac"), "lds_frac": p.get("lds_frac"),
+                     "counters": "valu_instr_per_px / valu_frac / lds_frac / traffic: rocprofv3 PMC passes of this kernel committed in "
+                                 "profiles/r02_warp_pmc.json (not measured in this run); achieved: HIP events in this run"}
+    del src, dst
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +189,12 @@ def main():
                          "fast = VS_WARP_LANCZOS2_FAST (opt-in fused-multiply-add variant, within 1 LSB)")
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
+    ap.add_argument("--no-roofline-4k", action="store_true", help="skip the isolated 32 x 4K bgr_image_warp measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be the launcher.  Nothing above has imported torch or made a HIP call.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     from video_stabilizer_amd import capi, synth
@@ -214,7 +302,8 @@ def main():
                     for k, v in t.items() if isinstance(v, dict) and v["launches"]}
         out = {
             "metric": "aligned frames/sec", "value": round(total_frames / dt, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "dist_backend": (args.dist_backend if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if bits == 8 else "u16", "data": "synthetic",
             "config": {"workload": wl["name"] if not args.default_levels else
@@ -249,18 +338,23 @@ def main():
                 traffic = int(tj[key]["traffic_bytes"] / per * n * n_clips)
             except Exception:
                 pass
-            out["roofline"] = {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm",
+            out["roofline"] = {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm", "binding": "valu",
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                               "traffic_source": "scaled from the committed PMC passes (profiles/r01_traffic.json), not measured in this run",
                                "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
-                               "note": "VALU-issue-bound, not HBM-bound: ~240 VALU instructions per output pixel in the "
-                                       "reference's exact fp32 order (DESIGN.md, profiles/r01_bgr_image_warp_pmc.md); launches "
+                               "note": "VALU-issue-bound, not HBM-bound: ~230 VALU instructions per output pixel in the "
+                                       "reference's exact fp32 order (DESIGN.md, profiles/r02_bgr_image_warp.md); launches "
                                        "overlap the next clip's aligner kernels"}
+        if not args.no_roofline_4k:
+            out["roofline_4k"] = roofline_4k(torch, capi, dev, stream)
         if not args.no_cpu_baseline and world == 1:
             fh = clips[0][: min(n, 64)].cpu().numpy()
             if bits != 8:
                 fh = fh.view("uint16")
             out["cpu_baseline"] = cpu_baseline(fh, params_kw, wl["stabilizer"])
+            out["cpu_baseline"]["cpu_model"] = cpu_model()
+            out["cpu_baseline"]["hardware_threads"] = os.cpu_count()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -34,7 +34,12 @@ extern "C" {
 #define VS_ERR_STATE (-4)
 
 enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
-enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR16 = 2 };
+/* Frame formats.  16-bit containers say how many bits the samples really use: the aligner derives its 8-bit luma with
+ * gray >> (bits - 8) and the stabilizer's warp saturates at (1 << bits) - 1.  VS_FMT_BGR16 is the historical name of the
+ * 10-bit format (BASELINE config 5, "4K 10-bit BGR"); the reference itself is 8-bit only (imgproc.cpp:207-209). */
+enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR10 = 2, VS_FMT_BGR16 = 2, VS_FMT_BGR12 = 3, VS_FMT_BGR16_FULL = 4 };
+/* bits per sample of a format: 8, 10, 12 or 16; 0 for an unknown format */
+int vs_format_bits(int format);
 /* VS_WARP_LANCZOS2: the reference sampler's exact sequence of fp32 roundings (bit-identical to the CPU restatement).
  * VS_WARP_LANCZOS2_FAST: opt-in, same sampler with fused multiply-adds and one refined reciprocal; integer outputs stay
  * within 1 LSB of the exact mode (> 99.9 % identical), ~1.4x faster.  Tuned for 3-channel integer frames; other
@@ -215,6 +220,14 @@ void vs_aligner_destroy(vs_aligner* a);
 int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
 /* forget the sequence: the next frame is treated as the first frame of a new clip (device memory is kept) */
 int  vs_aligner_reset(vs_aligner* a);
+/* Stream ordering of the engine-level calls.  A handle works on its own non-blocking stream (vs_aligner_stream), which
+ * is NOT ordered against the caller's streams, the NULL stream included.  With VS_MEM_DEVICE the frames must therefore be
+ * complete before an align / process call -- either the producer stream has been synchronised, or
+ * vs_aligner_wait_stream(a, producer_stream) was called after the last producer enqueue: everything enqueued on
+ * producer_stream up to that point then happens before whatever the handle enqueues afterwards.  In the other direction
+ * nothing is needed: align / process calls return after their device work has finished (they hand results to the host). */
+void* vs_aligner_stream(const vs_aligner* a);
+int   vs_aligner_wait_stream(vs_aligner* a, void* producer_stream);
 /* VideoAligner::AlignNextFrame (alignment.hpp:55-58, alignment.cpp:334-704).
  * returns 1 aligned / 0 not aligned (first frame, no convergence, over displacement) / <0 error.  When not aligned,
  * *out holds what the reference leaves in `transform`: identity for the first frame, else the estimate reached when the
@@ -289,6 +302,9 @@ int  vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t fr
                                  int w, int h, int stride, int format, int mem, void* out, size_t out_frame_stride,
                                  int32_t* has_output, int* out_w, int* out_h);
 int  vs_stabilizer_reset(vs_stabilizer* s);   /* start a new clip; device buffers are kept */
+/* stream ordering for VS_MEM_DEVICE frames: see vs_aligner_wait_stream */
+void* vs_stabilizer_stream(const vs_stabilizer* s);
+int   vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream);
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 
 #ifdef __cplusplus

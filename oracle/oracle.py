@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libvs_oracle.so")
+_LIB_PATH = os.environ.get("VS_ORACLE_LIB", os.path.join(_HERE, "libvs_oracle.so"))   # VS_ORACLE_LIB: the sanitizer build (make -C oracle asan-test)
 
 
 class Transform(C.Structure):
@@ -54,6 +54,7 @@ class AlignDebug(C.Structure):
 WARP_LANCZOS2, WARP_BILINEAR = 0, 1
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
+FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4
 
 _lib = None
 
@@ -88,6 +89,7 @@ def lib():
         "vso_bgr_image_warp": (None, [vp, i32, i32, i32, i32, i32, TP, i32, i32, i32, vp, i32]),
         "vso_bgr_image_warp_f32": (None, [vp, i32, i32, i32, i32, i32, TP, i32, i32, vp, i32]),
         "vso_bgr_to_gray": (None, [vp, i32, i32, i32, i32, i32, vp, i32]),
+        "vso_format_bits": (i32, [i32]),
         "vso_transform_inverse": (Transform, [TP]),
         "vso_transform_compose": (Transform, [TP, TP]),
         "vso_transform_warp": (Point, [TP, Point]),
@@ -435,9 +437,9 @@ class Aligner:
         self.h = lib().vso_aligner_create()
         self.params = aligner_params(**params)
 
-    def align_next(self, frame):
+    def align_next(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)
-        fmt = _fmt_of(frame)
+        fmt = _fmt_of(frame) if fmt is None else fmt
         hh, ww = frame.shape[:2]
         stride = ww * (1 if fmt == FMT_GRAY8 else 3)
         t = Transform()
@@ -481,9 +483,9 @@ class Stabilizer:
         self.params = stabilizer_params(**params)
         self.h = lib().vso_stabilizer_create(C.byref(self.params))
 
-    def process(self, frame):
+    def process(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)
-        fmt = _fmt_of(frame)
+        fmt = _fmt_of(frame) if fmt is None else fmt
         hh, ww = frame.shape[:2]
         c = max(self.params.crop_pixels, 0)
         out = np.empty((hh - 2 * c, ww - 2 * c, 3), frame.dtype)

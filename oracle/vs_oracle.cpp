@@ -356,6 +356,16 @@ void vso_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int c
 }
 
 /* stands in for cv::cvtColor(BGR2GRAY) (alignment.cpp:212): OpenCV 4.x 15-bit fixed point */
+int vso_format_bits(int format) {
+    switch (format) {
+        case VSO_FMT_GRAY8: case VSO_FMT_BGR8: return 8;
+        case VSO_FMT_BGR10: return 10;
+        case VSO_FMT_BGR12: return 12;
+        case VSO_FMT_BGR16_FULL: return 16;
+        default: return 0;
+    }
+}
+
 void vso_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,
                      int dst_stride) {
     for (int y = 0; y < h; y++)
@@ -599,7 +609,7 @@ bool vso_aligner::ComputePyramid(const void* frame, int width0, int height0, int
     } else if (format == VSO_FMT_BGR8) {
         vso_bgr_to_gray(frame, width0, height0, stride, 8, 0, g0, width0);
     } else {
-        vso_bgr_to_gray(frame, width0, height0, stride, 16, 2, g0, width0);
+        vso_bgr_to_gray(frame, width0, height0, stride, 16, vso_format_bits(format) - 8, g0, width0);
     }
     for (int i = 1; i < PyramidLevels; i++)
         vso_pyr_down(L[i - 1].img[CurrFrameIndex].data(), L[i - 1].w, L[i - 1].h, L[i - 1].w,
@@ -780,8 +790,9 @@ void vso_stabilizer_destroy(vso_stabilizer* s) { delete s; }
 
 int vso_stabilizer_process(vso_stabilizer* s, const void* frame, int w, int h, int stride, int format, void* out,
                            int* out_w, int* out_h) {
-    if (!s || !frame || (format != VSO_FMT_BGR8 && format != VSO_FMT_BGR16)) return -1;
-    const int bits = format == VSO_FMT_BGR8 ? 8 : 16;
+    if (!s || !frame || format == VSO_FMT_GRAY8 || vso_format_bits(format) == 0) return -1;
+    const int depth = vso_format_bits(format);              /* bits the samples use */
+    const int bits = depth > 8 ? 16 : 8;                    /* container */
     const size_t esz = bits / 8;
     ++s->frameIndex;
     /* :15 clone */
@@ -834,7 +845,7 @@ int vso_stabilizer_process(vso_stabilizer* s, const void* frame, int w, int h, i
             vso_transform sampling = vso_transform_inverse(&correction);
             std::vector<uint8_t> warped((size_t)w * h * 3 * esz);
             vso_bgr_image_warp(frameToStabilize.data(), w, h, w * 3, 3, bits, &sampling, s->params.warp_mode,
-                               s->params.warp_border, bits == 8 ? 255 : 65535, warped.data(), w * 3);
+                               s->params.warp_border, (1 << depth) - 1, warped.data(), w * 3);
             int c = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
             int ow = w - 2 * c, oh = h - 2 * c;
             for (int y = 0; y < oh; y++)

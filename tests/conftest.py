@@ -23,6 +23,15 @@ def oracle():
 @pytest.fixture(scope="session")
 def vs():
     """the product's C ABI via ctypes; a missing library is an error, never a skip"""
+    # torch first, where it is installed: torch ships its own copy of the HIP runtime, and the copy that is loaded first is
+    # the one the whole process uses (same SONAME) -- the other way round torch finds "no HIP GPUs" in tests that also use
+    # torch for device memory / streams.  bench.py imports in this order too (INTEGRATION.md, "one HIP runtime per process").
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from video_stabilizer_amd import capi
     capi.lib()
     return capi

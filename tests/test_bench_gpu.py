@@ -29,9 +29,32 @@ def test_bench_line_contract(gpu_vs):
     assert j["value"] > 0 and j["aligned_per_step"] == 7
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["binding"] == "valu" and "traffic_source" in r
     c = j["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]
     assert j["align_only"]["value"] > j["value"]
+    assert j["rccl_ranks"] == 1
+    # the north star's own operating point: 32 x 4K frames, isolated, exact and fast arithmetic
+    for name in ("exact", "fast"):
+        q = j["roofline_4k"][name]
+        assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
+        assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
+    assert j["roofline_4k"]["fast"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
+
+
+def test_bench_spawns_its_own_ranks(gpu_vs):
+    """`bench.py --gpus 2` with no launcher in the environment starts both ranks itself (gloo here: two ranks share the one
+    GPU of the box; the real run is nccl = RCCL with one GPU per rank) and rank 0 reports n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-roofline-4k", "--dist-backend", "gloo", "--device", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                          # one line for the whole job
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "gloo"
+    assert j["aligned_per_step"] == 2 * 5                           # both ranks' clips are counted
 
 
 def test_bench_two_ranks_gloo_rehearsal(gpu_vs):
@@ -40,7 +63,7 @@ def test_bench_two_ranks_gloo_rehearsal(gpu_vs):
     for r in range(2):
         env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2",
-                                       "--warmup", "1", "--no-cpu-baseline", "--dist-backend", "gloo", "--device", "0"],
+                                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline-4k", "--dist-backend", "gloo", "--device", "0"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (o, e) in zip(procs, outs):

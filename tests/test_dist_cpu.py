@@ -57,3 +57,37 @@ def test_shard_covers_every_clip_once():
         got = sorted(i for r in range(world) for i in D.shard_clips(64, r, world))
         assert got == list(range(64))
         assert max(len(D.shard_clips(64, r, world)) for r in range(world)) == 64 // world
+
+
+def test_bench_launcher_starts_ranks_and_fails_loudly_without_a_gpu():
+    """`bench.py --gpus 2` with no launcher environment spawns its two ranks (each gets RANK / LOCAL_RANK / WORLD_SIZE and a
+    shared rendezvous port).  In this container there is no GPU, so the ranks must fail loudly -- and the launcher must hand
+    that failure back as its own exit code instead of printing a result line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: the launcher is exercised by tests/test_bench_gpu.py::test_bench_spawns_its_own_ranks")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "4", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-roofline-4k", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert "{" not in out.stdout
+
+
+def test_spawn_ranks_environment(tmp_path, monkeypatch):
+    """the launcher's contract: N children of the same script, RANK = LOCAL_RANK = 0..N-1, WORLD_SIZE = N, one port for all"""
+    import bench
+    import sys
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys\n"
+                     "open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in "
+                     "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+                     "print('{\"rank\": %s}' % os.environ['RANK'])\n")
+    monkeypatch.setattr(bench, "__file__", str(probe))
+    rc = bench.spawn_ranks(3, [str(tmp_path)])
+    assert rc == 0
+    seen = [open(tmp_path / ("r%d" % r)).read().split() for r in range(3)]
+    assert [s[0] for s in seen] == ["0", "1", "2"] and [s[1] for s in seen] == ["0", "1", "2"]
+    assert {s[2] for s in seen} == {"3"} and {s[3] for s in seen} == {"127.0.0.1"} and len({s[4] for s in seen}) == 1

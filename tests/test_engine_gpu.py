@@ -172,6 +172,40 @@ def test_10bit_bgr_alignment(gpu_vs, oracle):
     _check_seq(res)
 
 
+@pytest.mark.parametrize("bits,fmt_name", [(12, "FMT_BGR12"), (16, "FMT_BGR16_FULL")])
+def test_deep_formats_carry_their_bit_depth(gpu_vs, oracle, bits, fmt_name):
+    """12- and 16-bit content in u16 containers: the luma is gray >> (bits - 8) and the stabilizer's warp saturates at
+    2^bits - 1 -- declared through the frame format, checked against the oracle run with the same format."""
+    from video_stabilizer_amd import synth
+    f10, _ = synth.make_clip(480, 270, 14, seed=72, channels=3, bits=10)
+    frames = (f10.astype(np.uint32) << (bits - 10)).astype(np.uint16)       # the same picture at the deeper scale
+    fmt_g, fmt_c = getattr(gpu_vs, fmt_name), getattr(oracle, fmt_name)
+    gpu, cpu = gpu_vs.Aligner(device=0), oracle.Aligner()
+    res = []
+    for f in frames[:4]:
+        ok_g, t_g = gpu.align_next(f, fmt=fmt_g)
+        ok_c, t_c = cpu.align_next(f, fmt=fmt_c)
+        res.append((ok_g, t_g, gpu.info(0), ok_c, t_c, cpu.debug()))
+    assert sum(r[3] for r in res) == 3
+    _check_seq(res)
+    # declared as 10-bit, the same frames saturate the luma and the alignment is different (the old behaviour)
+    wrong = gpu_vs.Aligner(device=0)
+    wrong.align_next(frames[0])
+    assert wrong.align_next(frames[1])[1].tup() != res[1][1].tup()
+    kw = dict(lag=3, crop_pixels=8)
+    g, c = gpu_vs.Stabilizer(device=0, **kw), oracle.Stabilizer(**kw)
+    outs = 0
+    for f in frames:
+        og, oc = g.process(f, fmt=fmt_g), c.process(f, fmt=fmt_c)
+        assert (og is None) == (oc is None)
+        if oc is not None:
+            outs += 1
+            assert int(og.max()) <= (1 << bits) - 1
+            d = np.abs(og.astype(np.int64) - oc.astype(np.int64))
+            assert d.max() <= 1 << (bits - 10)                  # 1 LSB of the 10-bit picture the frames were scaled from
+    assert outs == 11
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_stabilizer_matches_oracle(gpu_vs, oracle, mode):
     from video_stabilizer_amd import synth
@@ -392,3 +426,26 @@ def test_ingest_pyramid_bit_exact_on_awkward_sizes(gpu_vs, oracle, w, h, bits):
     assert gpu.info(0).levels == levels >= 3
     for l in range(levels):
         assert np.array_equal(gpu.level(0, l)["img"], cpu.level(l)["img"][0]), l
+
+
+def test_wait_stream_orders_device_frames_behind_their_producer(gpu_vs):
+    """VS_MEM_DEVICE frames written by work that is still queued on the caller's stream: vs_aligner_wait_stream puts the
+    handle's (non-blocking) stream behind that producer, so the call sees the finished frames without a host sync."""
+    import torch
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(640, 360, 6, seed=41, channels=3)
+    want_s, want_t = gpu_vs.Aligner(device=0).align_batch(frames)
+    dev = torch.device("cuda", 0)
+    src = torch.from_numpy(frames).to(dev)
+    buf = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    al = gpu_vs.Aligner(device=0)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(200_000_000)            # ~0.1 s of device time in front of the copy
+        buf.copy_(src, non_blocking=True)
+    al.wait_stream(side.cuda_stream)              # no host synchronisation between the producer and the call
+    st, ts = al.align_batch_device(buf.data_ptr(), 6, 640, 360, gpu_vs.FMT_BGR8)
+    assert list(st) == list(want_s)
+    assert [t.tup() for t in ts] == [t.tup() for t in want_t]
+    torch.cuda.synchronize()

@@ -69,3 +69,11 @@ def test_tvl1_and_smoother_identical_to_oracle(vs, oracle):
         okg, tg = g.update(vs.Transform.of(*m))
         okc, tc = c.update(oracle.Transform.of(*m))
         assert okg == okc and tg.tup() == tc.tup()
+
+
+def test_format_bits(vs, oracle):
+    """16-bit containers carry their sample depth in the format (luma shift = bits - 8, warp saturation = 2^bits - 1)"""
+    want = {vs.FMT_GRAY8: 8, vs.FMT_BGR8: 8, vs.FMT_BGR10: 10, vs.FMT_BGR16: 10, vs.FMT_BGR12: 12, vs.FMT_BGR16_FULL: 16, 5: 0, -1: 0}
+    for f, b in want.items():
+        assert vs.lib().vs_format_bits(f) == b
+        assert oracle.lib().vso_format_bits(f) == b

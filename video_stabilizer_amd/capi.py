@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("VS_AMD_LIB", os.path.join(_HERE, "libvs_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
+FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use (FMT_BGR16 == FMT_BGR10)
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE = 0, 1
@@ -77,6 +78,11 @@ SIGNATURES = {
     "vs_last_error": (C.c_char_p, []),
     "vs_version": (C.c_char_p, []),
     "vs_device_count": (_i32, []),
+    "vs_format_bits": (_i32, [_i32]),
+    "vs_aligner_stream": (_vp, [_vp]),
+    "vs_aligner_wait_stream": (_i32, [_vp, _vp]),
+    "vs_stabilizer_stream": (_vp, [_vp]),
+    "vs_stabilizer_wait_stream": (_i32, [_vp, _vp]),
     "vs_aligner_params_default": (None, [C.POINTER(AlignerParams)]),
     "vs_stabilizer_params_default": (None, [C.POINTER(StabilizerParams)]),
     "vs_transform_inverse": (Transform, [_TP]),
@@ -474,10 +480,11 @@ class Aligner:
             raise VsError("vs_aligner_create failed: %s" % lib().vs_last_error().decode())
         _check(lib().vs_aligner_set_select_mode(self.h, select_mode))
 
-    def align_next(self, frame):
-        """frame: numpy (h,w) u8 gray, (h,w,3) u8/u16 BGR.  returns (ok, Transform)"""
+    def align_next(self, frame, fmt=None):
+        """frame: numpy (h,w) u8 gray, (h,w,3) u8/u16 BGR (u16 = 10-bit unless fmt says FMT_BGR12 / FMT_BGR16_FULL).
+        returns (ok, Transform)"""
         frame = np.ascontiguousarray(frame)
-        fmt = _fmt_of(frame.dtype, frame.ndim)
+        fmt = _fmt_of(frame.dtype, frame.ndim) if fmt is None else fmt
         hh, ww = frame.shape[:2]
         stride = ww * (1 if fmt == FMT_GRAY8 else 3)
         t = Transform()
@@ -542,6 +549,10 @@ class Aligner:
         d["gn_iterations"] = t.gn_iterations
         return d
 
+    def wait_stream(self, stream_handle):
+        """order the handle's stream behind everything enqueued so far on the caller's stream (raw hipStream_t value)"""
+        _check(lib().vs_aligner_wait_stream(self.h, C.c_void_p(stream_handle)))
+
     def info(self, i=0):
         inf = AlignInfo()
         _check(lib().vs_aligner_get_info(self.h, i, C.byref(inf)))
@@ -586,9 +597,9 @@ class Stabilizer:
         if not self.h:
             raise VsError("vs_stabilizer_create failed: %s" % lib().vs_last_error().decode())
 
-    def process(self, frame):
+    def process(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)
-        fmt = _fmt_of(frame.dtype, frame.ndim)
+        fmt = _fmt_of(frame.dtype, frame.ndim) if fmt is None else fmt
         hh, ww = frame.shape[:2]
         c = max(self.params.crop_pixels, 0)
         out = np.empty((hh - 2 * c, ww - 2 * c, 3), frame.dtype)
@@ -598,6 +609,9 @@ class Stabilizer:
 
     def reset(self):
         _check(lib().vs_stabilizer_reset(self.h))
+
+    def wait_stream(self, stream_handle):
+        _check(lib().vs_stabilizer_wait_stream(self.h, C.c_void_p(stream_handle)))
 
     def process_batch(self, frames):
         """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list)"""

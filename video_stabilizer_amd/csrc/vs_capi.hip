@@ -53,67 +53,76 @@ using vsi::set_error;
 
 #define VS_TRY(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
 #define VS_ARG(cond) do { if (!(cond)) return set_error(VS_ERR_ARG, "bad argument: %s (%s)", #cond, __func__); } while (0)
+#define VS_TRY_RING(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
 
 
-// Pinned host ring + device mirror for small parameter blocks.  upload() copies `n` float4 into the next
-// free span of the pinned ring, enqueues H2D into the same span of the device mirror on `s`, and returns
-// the device pointer.  A span is reused only after the event recorded behind its last consumer-side copy
-// has completed, so the call never blocks in steady state and the source of an in-flight copy is never
-// overwritten.  (The kernel that consumes the span runs on the same stream, after the copy.)
+// Pinned host ring + device mirror for small parameter blocks.  upload() copies `n` float4 into the next free span of
+// the pinned ring, enqueues H2D into the same span of the device mirror on `s`, and returns the device pointer.  A span
+// is tracked as busy from the moment its copy is enqueued (an event is recorded right behind the copy) and fence() moves
+// that event behind the consuming kernel; it is reused only after its event has completed, so the source of an in-flight
+// copy is never overwritten -- also when the call fails between upload() and fence().
+// One ring per (thread, device): calls from different threads or for different devices never wait on each other and need
+// no lock (the header promises that distinct handles are independent).  Events are pooled, not created per call.
 namespace {
 struct ParamRing {
     static constexpr size_t kSlots = 1 << 15;    // 32768 float4 = 512 KiB
-    std::mutex mu;
     float4* host = nullptr;
-    float4* dev[16] = {};
-    int dev_of = -1;
+    float4* dev = nullptr;
     size_t head = 0;
-    struct Busy { size_t begin, end; hipEvent_t ev; int device; };
+    struct Busy { size_t begin, end; hipEvent_t ev; };
     std::deque<Busy> busy;
+    std::vector<hipEvent_t> pool;
+    int take_event(hipEvent_t* ev) {
+        if (!pool.empty()) { *ev = pool.back(); pool.pop_back(); return VS_OK; }
+        VS_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        return VS_OK;
+    }
+    int retire(std::deque<Busy>::iterator it) {
+        VS_HIP(hipEventSynchronize(it->ev));
+        pool.push_back(it->ev);
+        busy.erase(it);
+        return VS_OK;
+    }
     int upload(const float* src, size_t n, hipStream_t s, float4** out) {
         if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
-        std::lock_guard<std::mutex> lock(mu);
-        int device = 0;
-        VS_HIP(hipGetDevice(&device));
-        if (device < 0 || device >= 16) return vsi::set_error(VS_ERR_UNSUPPORTED, "device index %d", device);
         if (!host) VS_HIP(hipHostMalloc((void**)&host, kSlots * sizeof(float4)));
-        if (!dev[device]) VS_HIP(hipMalloc((void**)&dev[device], kSlots * sizeof(float4)));
+        if (!dev) VS_HIP(hipMalloc((void**)&dev, kSlots * sizeof(float4)));
         if (head + n > kSlots) head = 0;
         const size_t b = head, e = head + n;
         // wait for (and retire) every in-flight span that overlaps [b, e)
-        for (auto it = busy.begin(); it != busy.end();) {
-            if (it->begin < e && b < it->end) {
-                VS_HIP(hipEventSynchronize(it->ev));
-                (void)hipEventDestroy(it->ev);
-                it = busy.erase(it);
-            } else {
-                ++it;
-            }
+        for (bool again = true; again;) {
+            again = false;
+            for (auto it = busy.begin(); it != busy.end(); ++it)
+                if (it->begin < e && b < it->end) { VS_TRY_RING(retire(it)); again = true; break; }
         }
+        while (busy.size() > 64) VS_TRY_RING(retire(busy.begin()));   // keep the list short: retire the oldest
         memcpy(host + b, src, n * sizeof(float4));
-        VS_HIP(hipMemcpyAsync(dev[device] + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s));
-        *out = dev[device] + b;
+        Busy bz{b, e, nullptr};
+        VS_TRY_RING(take_event(&bz.ev));
+        hipError_t err = hipMemcpyAsync(dev + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s);
+        if (err == hipSuccess) err = hipEventRecord(bz.ev, s);
+        if (err != hipSuccess) { pool.push_back(bz.ev); VS_HIP(err); }
+        busy.push_back(bz);
+        *out = dev + b;
         head = e;
         return VS_OK;
     }
-    // called after the consuming kernel has been enqueued on `s`
-    int fence(float4* p, size_t n, hipStream_t s) {
-        std::lock_guard<std::mutex> lock(mu);
-        int device = 0;
-        VS_HIP(hipGetDevice(&device));
-        Busy bz{(size_t)(p - dev[device]), (size_t)(p - dev[device]) + n, nullptr, device};
-        VS_HIP(hipEventCreateWithFlags(&bz.ev, hipEventDisableTiming));
-        VS_HIP(hipEventRecord(bz.ev, s));
-        busy.push_back(bz);
-        while (busy.size() > 64) {   // keep the list short: retire the oldest
-            VS_HIP(hipEventSynchronize(busy.front().ev));
-            (void)hipEventDestroy(busy.front().ev);
-            busy.pop_front();
-        }
+    // called after the consuming kernel has been enqueued on `s`: the span stays busy until that kernel is done
+    int fence(float4* p, hipStream_t s) {
+        const size_t b = (size_t)(p - dev);
+        for (auto& z : busy)
+            if (z.begin == b) { VS_HIP(hipEventRecord(z.ev, s)); return VS_OK; }
         return VS_OK;
     }
 };
-ParamRing g_param_ring;
+// rings live for the life of the process (no teardown at thread exit: the HIP runtime may already be gone by then)
+ParamRing* param_ring() {
+    thread_local ParamRing* rings[16] = {};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return nullptr;
+    if (!rings[device]) rings[device] = new ParamRing();
+    return rings[device];
+}
 }  // namespace
 
 static inline size_t img_span(int w, int h, int stride, int channels) {
@@ -328,7 +337,9 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     // Per-frame kernel parameters travel host -> device through a pinned ring (ParamRing below), so a
     // VS_MEM_DEVICE call stays asynchronous and never reads a host buffer that has gone out of scope.
     float4* pdev = nullptr;
-    VS_TRY(g_param_ring.upload(P.data(), (size_t)n_frames, s, &pdev));
+    ParamRing* ring = param_ring();
+    if (!ring) return set_error(VS_ERR_UNSUPPORTED, "no current HIP device with index < 16");
+    VS_TRY(ring->upload(P.data(), (size_t)n_frames, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
     const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(roi.w, roi.h, dst_stride, channels)) * osz;
@@ -342,7 +353,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);
     VS_HIP(e);
-    VS_TRY(g_param_ring.fence(pdev, (size_t)n_frames, s));
+    VS_TRY(ring->fence(pdev, s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
 }

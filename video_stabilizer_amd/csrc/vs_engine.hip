@@ -24,6 +24,7 @@
 #include <cstring>
 #include <deque>
 #include <thread>
+#include <string>
 #include <vector>
 
 using vsi::set_error;
@@ -341,6 +342,15 @@ int vs_aligner::configure(int w, int h, int format, const vs_aligner_params& p) 
         return set_error(VS_ERR_UNSUPPORTED, "%dx%d with pyramid_min %dx%d gives %d pyramid levels; 3..%d supported", w, h,
                          p.pyramid_min_width, p.pyramid_min_height, lv, kMaxLevels);
     if (w > 65535 || h > 65535) return set_error(VS_ERR_UNSUPPORTED, "frame larger than 65535 (u16 keypoints)");
+    // every level is validated BEFORE anything of the old configuration is released or overwritten: a refused size
+    // leaves the handle exactly as it was (the reference marks a failed setup with LastWidth = -1, alignment.cpp:360)
+    ww = w; hh = h;
+    for (int i = 0; i < lv; i++) {
+        if (i > 0) { ww /= 2; hh /= 2; }
+        const int ts = vs_tile_size(ww, hh);
+        if (ww < 4 || hh < 4 || (ww / ts) * (hh / ts) < 1)
+            return set_error(VS_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: levels below 4x4 are not supported", i, ww, hh);
+    }
     release();
     W = w; H = h; fmt = format; levels = lv; seq = 0;
     size_t img = 0, lmo = 0, jo = 0;
@@ -357,8 +367,6 @@ int vs_aligner::configure(int w, int h, int format, const vs_aligner_params& p) 
         l.lm_off = lmo; lmo += (size_t)l.nt * 4;     // x-set (2*nt) + y-set (2*nt)
         l.jac_off = jo; jo += (size_t)l.nt * 8;      // x-set (4*nt) + y-set (4*nt)
         nt_max = std::max(nt_max, l.nt);
-        if (l.nt < 1 || ww < 4 || hh < 4)
-            return set_error(VS_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: levels below 4x4 are not supported", i, ww, hh);
     }
     pyr_frame = img; lm_frame = (lmo + 63) & ~(size_t)63; jac_frame = (jo + 63) & ~(size_t)63;
     return VS_OK;
@@ -445,7 +453,8 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                           const vs_aligner_params& p, vs_transform* out, int32_t* status, vs_align_info* infos) {
     hipStream_t s = stream;
     const int ch = fmt == VS_FMT_GRAY8 ? 1 : 3;
-    const size_t esz = fmt == VS_FMT_BGR16 ? 2 : 1;
+    const int fbits = vs_format_bits(fmt);
+    const size_t esz = fbits > 8 ? 2 : 1;
 
     // carry-over: the previous call's last frame (pyramid + keyframe tables) moves to slot 0
     if (seq > 0 && last_n != 0) {
@@ -475,7 +484,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                                     stride, W, H, hipMemcpyDeviceToDevice, s));
     } else {
         // BGR -> gray level 0 and level 1 in one pass (levels >= 3 always, so level 1 exists)
-        VS_HIP(vsk::ingest_pyr(dframes, W, H, stride, fmt == VS_FMT_BGR8 ? 8 : 16, fmt == VS_FMT_BGR8 ? 0 : 2, slot1,
+        VS_HIP(vsk::ingest_pyr(dframes, W, H, stride, fbits > 8 ? 16 : 8, fbits - 8, slot1,
                                slot1 + L[1].img_off, n, frame_stride, pyr_frame, s));
     }
     t_end(1);
@@ -753,10 +762,25 @@ int vs_aligner_reset(vs_aligner* a) {
     return VS_OK;
 }
 
+void* vs_aligner_stream(const vs_aligner* a) { return a ? (void*)a->stream : nullptr; }
+
+// Everything enqueued on `producer_stream` so far happens before anything the handle enqueues from now on.
+int vs_aligner_wait_stream(vs_aligner* a, void* producer_stream) {
+    VS_ARG(a);
+    VS_HIP(hipSetDevice(a->device));
+    hipEvent_t ev = nullptr;
+    VS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)producer_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(a->stream, ev, 0);
+    (void)hipEventDestroy(ev);        // the wait already holds what it needs; destruction is deferred by the runtime
+    VS_HIP(e);
+    return VS_OK;
+}
+
 int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
                            int format, int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status) {
     VS_ARG(a && frames && out && status && n >= 1 && w >= 8 && h >= 8);
-    VS_ARG(format == VS_FMT_GRAY8 || format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
+    VS_ARG(vs_format_bits(format) != 0);
     const int ch = format == VS_FMT_GRAY8 ? 1 : 3;
     VS_ARG(stride >= w * ch);
     VS_ARG(n == 1 || frame_stride >= (size_t)(h - 1) * stride + (size_t)w * ch);
@@ -768,7 +792,7 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
     for (int l = 0; l < a->levels; l++)
         a->L[l].nsel = (int)static_cast<size_t>((size_t)a->L[l].nt * p.smallest_fraction);
     a->info.assign(n, vs_align_info{});
-    const size_t esz = format == VS_FMT_BGR16 ? 2 : 1;
+    const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
     // chunking bounds device memory: at most ~6 GiB of pyramids per handle
     int max_chunk = (int)std::max<size_t>(2, std::min<size_t>(1024, ((size_t)6 << 30) / std::max<size_t>(1, a->pyr_frame)));
     if (a->clip_len > 0) {   // whole clips per chunk
@@ -924,10 +948,31 @@ int vs_stabilizer_reset(vs_stabilizer* s);
 
 // n successive processFrame calls; clip_len > 0: the n frames are n / clip_len independent clips, each run through a
 // fresh stabilizer (reset before every clip and after the last), all of them aligned and warped together.
+static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
+                         int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h);
+
+// While a batch is in flight the frame queue holds non-owned pointers into the caller's buffer (or into batch_in); they
+// become copies of our own only at the end of a successful run.  Whatever stops a run early -- a HIP error, a refused
+// warp -- must not leave such an entry behind for the next call to warp from: the stabilizer is reset to a clean
+// "new clip" state (and the stream drained, so nothing still reads the caller's frames), and the error is passed on.
 static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
                     int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h) {
+    const int r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, out, out_frame_stride, has_output,
+                                out_w, out_h);
+    if (r < 0 && s && s->aligner) {
+        const std::string why = vs_last_error();             // the reset below must not hide the cause
+        (void)hipStreamSynchronize(s->aligner->stream);
+        for (auto it = s->frames.begin(); it != s->frames.end();) it = it->owned ? it + 1 : s->frames.erase(it);
+        (void)vs_stabilizer_reset(s);
+        set_error(r, "%s", why.c_str());
+    }
+    return r;
+}
+
+static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
+                         int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h) {
     VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
-    VS_ARG(format == VS_FMT_BGR8 || format == VS_FMT_BGR16);
+    VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0);
     VS_ARG(stride >= 3 * w);
     const int crop = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
     VS_ARG(w > 2 * crop && h > 2 * crop);
@@ -936,12 +981,15 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     vs_aligner* a = s->aligner;
     VS_HIP(hipSetDevice(a->device));
     hipStream_t st = a->stream;
-    const size_t esz = format == VS_FMT_BGR8 ? 1 : 2;
+    const int fbits = vs_format_bits(format);
+    const size_t esz = fbits > 8 ? 2 : 1;
     const size_t fbytes = (size_t)w * h * 3 * esz;
     if (s->w != w || s->h != h || s->fmt != format) {
-        // a size change restarts the aligner (alignment.cpp:155); buffered frames of the old size are dropped
+        // a size change restarts the aligner (alignment.cpp:155).  The reference would go on warping queued frames of the
+        // old size with measurements of the new one; here the change starts a new clip, cleanly: queued frames of the
+        // old size are dropped and the smoother, the accumulated correction and the frame counter start over.
         stab_drop_frames(s);
-        s->measurements.clear();
+        VS_TRY(vs_stabilizer_reset(s));
         s->w = w; s->h = h; s->fmt = format; s->frame_bytes = fbytes;
     }
     *out_w = ow; *out_h = oh;
@@ -1049,7 +1097,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
                                            : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
             const size_t dst_fs = mem == VS_MEM_HOST ? (size_t)ow * oh * 3 : out_frame_stride;
             int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
-                                                 s->params.warp_mode, s->params.warp_border, esz == 1 ? 255 : 65535, crop, crop, ow, oh,
+                                                 s->params.warp_mode, s->params.warp_border, (1 << fbits) - 1, crop, crop, ow, oh,
                                                  dst, dst_fs, ow * 3, VS_MEM_DEVICE, st);
             if (wr < 0) return wr;
             j = e;
@@ -1092,6 +1140,12 @@ int vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t fra
 }
 
 // forget the clip: the next frame starts a new sequence (device buffers are kept)
+void* vs_stabilizer_stream(const vs_stabilizer* s) { return s && s->aligner ? (void*)s->aligner->stream : nullptr; }
+int vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream) {
+    VS_ARG(s && s->aligner);
+    return vs_aligner_wait_stream(s->aligner, producer_stream);
+}
+
 int vs_stabilizer_reset(vs_stabilizer* s) {
     VS_ARG(s);
     VS_HIP(hipSetDevice(s->aligner->device));

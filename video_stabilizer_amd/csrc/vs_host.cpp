@@ -25,6 +25,16 @@ const char* vs_last_error(void) { return vsi::g_err; }
 const char* vs_version(void) { return "video_stabilizer_amd 0.1 (gfx950)"; }
 
 // alignment.hpp:5-41
+int vs_format_bits(int format) {
+    switch (format) {
+        case VS_FMT_GRAY8: case VS_FMT_BGR8: return 8;
+        case VS_FMT_BGR10: return 10;
+        case VS_FMT_BGR12: return 12;
+        case VS_FMT_BGR16_FULL: return 16;
+        default: return 0;
+    }
+}
+
 void vs_aligner_params_default(vs_aligner_params* p) {
     p->phase_correlate = 0;
     p->phase_correlate_threshold = 0.5;
