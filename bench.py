@@ -168,6 +168,45 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     return out
 
 
+def host_fed(torch, capi, dev, frames_dev, W, H, fmt, params_kw, reps=3):
+    """Frames that start in (pageable) host memory: vs_aligner_align_batch(VS_MEM_HOST) cuts the batch into chunks and
+    uploads chunk c+1 (own thread + stream) under the pipeline of chunk c.  Reported beside the link rate measured here."""
+    import numpy as np
+    host = frames_dev.cpu().numpy()
+    if host.dtype == np.int16:
+        host = host.view(np.uint16)
+    n, nbytes = host.shape[0], host.nbytes
+    pinned = torch.from_numpy(host.view(np.uint8).reshape(-1)).pin_memory()
+    dbuf = torch.empty_like(pinned, device=dev)
+
+    def best(fn):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    t_link = best(lambda: dbuf.copy_(pinned, non_blocking=True))
+    del dbuf, pinned
+    al = capi.Aligner(device=dev.index, **params_kw)
+    res = {}
+
+    def run():
+        al.reset()
+        res["r"] = al.align_batch(host)
+    t = best(run)
+    ref = capi.Aligner(device=dev.index, **params_kw)
+    st_d, ts_d = ref.align_batch_device(frames_dev.data_ptr(), n, W, H, fmt)
+    same = list(res["r"][0]) == list(st_d) and [x.tup() for x in res["r"][1]] == [x.tup() for x in ts_d]
+    return {"value": round(n / t, 1), "unit": "frames/s", "input_GBps": round(nbytes / t / 1e9, 2),
+            "pinned_h2d_GBps": round(nbytes / t_link / 1e9, 2), "of_pinned_h2d": round(t_link / t, 3), "frames": n,
+            "identical_to_device_resident": same,
+            "note": "alignment of a host-resident clip, PCIe-inclusive (never `value`); pipelined ingest, pageable host memory"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +229,7 @@ def main():
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     ap.add_argument("--no-roofline-4k", action="store_true", help="skip the isolated 32 x 4K bgr_image_warp measurement")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-resident (PCIe-inclusive) alignment measurement")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -348,6 +388,8 @@ def main():
                                        "overlap the next clip's aligner kernels"}
         if not args.no_roofline_4k:
             out["roofline_4k"] = roofline_4k(torch, capi, dev, stream)
+        if not args.no_host_fed and aligner is not None:
+            out["host_fed"] = host_fed(torch, capi, dev, clips[0], W, H, fmt, params_kw)
         if not args.no_cpu_baseline and world == 1:
             fh = clips[0][: min(n, 64)].cpu().numpy()
             if bits != 8:

@@ -40,6 +40,8 @@ def test_bench_line_contract(gpu_vs):
         assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
         assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
     assert j["roofline_4k"]["fast"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
+    hf = j["host_fed"]
+    assert hf["identical_to_device_resident"] is True and hf["value"] > 0 and 0 < hf["of_pinned_h2d"] <= 1.05
 
 
 def test_bench_spawns_its_own_ranks(gpu_vs):
@@ -47,7 +49,7 @@ def test_bench_spawns_its_own_ranks(gpu_vs):
     GPU of the box; the real run is nccl = RCCL with one GPU per rank) and rank 0 reports n_gpus == 2."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-roofline-4k", "--dist-backend", "gloo", "--device", "0"],
+                          "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -63,7 +65,7 @@ def test_bench_two_ranks_gloo_rehearsal(gpu_vs):
     for r in range(2):
         env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2",
-                                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline-4k", "--dist-backend", "gloo", "--device", "0"],
+                                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (o, e) in zip(procs, outs):

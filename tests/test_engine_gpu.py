@@ -449,3 +449,38 @@ def test_wait_stream_orders_device_frames_behind_their_producer(gpu_vs):
     assert list(st) == list(want_s)
     assert [t.tup() for t in ts] == [t.tup() for t in want_t]
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("clips", [0, 3])
+def test_pipelined_host_ingest_is_identical_to_one_upload(gpu_vs, monkeypatch, clips):
+    """Host-resident batches longer than one upload chunk are cut into chunks whose upload (own thread + stream) overlaps
+    the pipeline of the chunk before: same transforms, bit for bit, as the single-upload path -- sequences and clips,
+    dense and strided frames."""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 24, seed=77, channels=3)
+    al = gpu_vs.Aligner(device=0)
+    want = al.align_clips(frames, clips) if clips else al.align_batch(frames)
+    monkeypatch.setenv("VS_INGEST_CHUNK_BYTES", str(320 * 240 * 3 * 5))      # 5-frame chunks (8 in clip mode: whole clips)
+    al2 = gpu_vs.Aligner(device=0)
+    got = al2.align_clips(frames, clips) if clips else al2.align_batch(frames)
+    assert list(got[0]) == list(want[0]) and [t.tup() for t in got[1]] == [t.tup() for t in want[1]]
+    assert sum(got[0]) >= (24 - max(clips, 1)) - 1
+
+
+@pytest.mark.parametrize("bits,clips", [(8, 0), (10, 0), (8, 2)])
+def test_pipelined_host_stabilizer_is_identical_to_one_batch(gpu_vs, monkeypatch, bits, clips):
+    """vs_stabilizer_process_batch / _clips with host frames: upload, compute and download of successive chunks overlap;
+    outputs equal the unchunked run bit for bit (the batched form is defined as n successive process calls)."""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 26, seed=78, channels=3, bits=bits)
+    kw = dict(lag=4, smoother_memory=2, crop_pixels=16)
+    s1 = gpu_vs.Stabilizer(device=0, **kw)
+    want = s1.process_clips(frames, clips) if clips else s1.process_batch(frames)
+    esz = 1 if bits == 8 else 2
+    monkeypatch.setenv("VS_INGEST_CHUNK_BYTES", str(320 * 240 * 3 * esz * 6))
+    s2 = gpu_vs.Stabilizer(device=0, **kw)
+    got = s2.process_clips(frames, clips) if clips else s2.process_batch(frames)
+    assert got[1] == want[1] and sum(got[1]) == (26 - 4 if not clips else 2 * (13 - 4))
+    assert np.array_equal(got[0], want[0])
+    if not clips:
+        assert s1.state()[1].tup() == s2.state()[1].tup()

@@ -613,13 +613,16 @@ class Stabilizer:
     def wait_stream(self, stream_handle):
         _check(lib().vs_stabilizer_wait_stream(self.h, C.c_void_p(stream_handle)))
 
-    def process_batch(self, frames):
-        """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list)"""
+    def process_batch(self, frames, out=None):
+        """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list).  out: a buffer of that shape to reuse
+        (frames without an output are left untouched in it)"""
         frames = np.ascontiguousarray(frames)
         n, hh, ww = frames.shape[:3]
         fmt = _fmt_of(frames.dtype, 3)
         c = max(self.params.crop_pixels, 0)
-        out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
+        if out is None:
+            out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
+        assert out.shape == (n, hh - 2 * c, ww - 2 * c, 3) and out.dtype == frames.dtype and out.flags.c_contiguous
         has = (C.c_int32 * n)()
         ow, oh = C.c_int(), C.c_int()
         _check(lib().vs_stabilizer_process_batch(self.h, _p(frames), hh * ww * 3, n, ww, hh, ww * 3, fmt, MEM_HOST, _p(out),

@@ -24,6 +24,8 @@
 #include <cstring>
 #include <deque>
 #include <thread>
+#include <cstdlib>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -207,6 +209,17 @@ constexpr int kSmallWgTiles = VS_SMALL_WG_TILES;   // largest level handled by t
 // =================================================================================================
 // VideoAligner
 // =================================================================================================
+// host-resident video is uploaded in chunks of about this many bytes (192 MB = ~3.4 ms on PCIe 5 x16; measured on MI355X:
+// 24 / 48 / 96 / 192 MB chunks reach 0.70 / 0.80 / 0.90 / 0.91 of the pinned-copy rate on a 1.5 GB batch -- every chunk
+// costs a thread hand-over and a pipeline drain);
+// VS_INGEST_CHUNK_BYTES overrides it (the tests use it to run many small chunks through the pipeline)
+static size_t ingest_chunk_bytes() {
+    const char* e = getenv("VS_INGEST_CHUNK_BYTES");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? (size_t)v : (size_t)192 << 20;
+}
+#define kIngestBytes ingest_chunk_bytes()
+
 struct vs_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -232,7 +245,11 @@ struct vs_aligner {
     uint16_t* wd = nullptr;
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
-    void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area
+    void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area (single chunk)
+    // host-resident video: two upload areas filled alternately by an uploader thread on its own stream, so the
+    // upload of chunk c+1 runs under the pipeline of chunk c (alignment.cpp:210-218: every frame arrives as a host cv::Mat)
+    void* ingest[2] = {nullptr, nullptr}; size_t ingest_bytes = 0;
+    hipStream_t copy_stream = nullptr;
     // phase-correlation mode (allocated on first use): level-2 half spectra per slot, per-pair scratch and results
     vsp::Context phase;
     int phase_cap = 0;
@@ -281,7 +298,12 @@ struct vs_aligner {
         spans.clear();
     }
 
-    ~vs_aligner() { release(); for (hipEvent_t e : event_pool) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+    ~vs_aligner() {
+        release();
+        for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
     void release();
     int configure(int w, int h, int format, const vs_aligner_params& p);
     int ensure_capacity(int n);
@@ -324,8 +346,9 @@ int vs_aligner::ensure_phase() {
 
 void vs_aligner::release() {
     release_phase();
-    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, stage};
+    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, stage, ingest[0], ingest[1]};
     for (void* p : d) if (p) (void)hipFree(p);
+    ingest[0] = ingest[1] = nullptr; ingest_bytes = 0;
     void* hp[] = {h_wd, h_idx, h_states};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; idx = nullptr;
@@ -800,11 +823,49 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
         max_chunk -= max_chunk % a->clip_len;
     }
     int aligned = 0;
-    for (int off = 0; off < n; off += max_chunk) {
-        const int m = std::min(max_chunk, n - off);
-        VS_TRY(a->ensure_capacity(m));
-        const uint8_t* base = (const uint8_t*)frames + (size_t)off * frame_stride * esz;
-        VS_TRY(a->run_chunk(base, frame_stride, m, stride, mem, p, out + off, status + off, a->info.data() + off));
+    // Host-resident frames, more than one upload's worth: pipelined ingest.  The batch is cut into chunks of ~kIngestBytes;
+    // an uploader thread copies chunk c+1 into the other upload area (its own stream) while chunk c runs through the
+    // pipeline from device memory.  Same chunks, same arithmetic as the device-resident path: results are identical.
+    const size_t frame_bytes = ((size_t)(h - 1) * stride + (size_t)w * ch) * esz;
+    const size_t step_bytes = n > 1 ? frame_stride * esz : frame_bytes;
+    int host_chunk = (int)std::min<size_t>((size_t)max_chunk, std::max<size_t>(4, kIngestBytes / std::max<size_t>(1, step_bytes)));
+    if (a->clip_len > 0) host_chunk = std::max(a->clip_len, host_chunk - host_chunk % a->clip_len);
+    if (mem == VS_MEM_HOST && n > host_chunk) {
+        const size_t area = (size_t)(host_chunk - 1) * step_bytes + frame_bytes;
+        if (a->ingest_bytes < area) {
+            for (void*& q : a->ingest) { if (q) (void)hipFree(q); q = nullptr; }
+            a->ingest_bytes = 0;
+            VS_HIP(hipMalloc(&a->ingest[0], area));
+            VS_HIP(hipMalloc(&a->ingest[1], area));
+            a->ingest_bytes = area;
+        }
+        if (!a->copy_stream) VS_HIP(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
+        auto upload = [a, frames, step_bytes, frame_bytes, n, host_chunk](int c) -> hipError_t {
+            const int off = c * host_chunk, m = std::min(host_chunk, n - off);
+            hipError_t e = hipSetDevice(a->device);
+            if (e != hipSuccess) return e;
+            e = hipMemcpyAsync(a->ingest[c & 1], (const uint8_t*)frames + (size_t)off * step_bytes, (size_t)(m - 1) * step_bytes + frame_bytes,
+                               hipMemcpyHostToDevice, a->copy_stream);
+            return e != hipSuccess ? e : hipStreamSynchronize(a->copy_stream);
+        };
+        const int n_chunks = (n + host_chunk - 1) / host_chunk;
+        std::future<hipError_t> next = std::async(std::launch::async, upload, 0);
+        for (int c = 0; c < n_chunks; c++) {
+            const int off = c * host_chunk, m = std::min(host_chunk, n - off);
+            const hipError_t ue = next.get();                 // chunk c is in ingest[c & 1]
+            if (c + 1 < n_chunks) next = std::async(std::launch::async, upload, c + 1);   // chunk c-1 (same area) has been consumed
+            int r = ue == hipSuccess ? VS_OK : set_error(VS_ERR_HIP, "frame upload failed: %s", hipGetErrorString(ue));
+            if (r == VS_OK) r = a->ensure_capacity(m);
+            if (r == VS_OK) r = a->run_chunk(a->ingest[c & 1], frame_stride, m, stride, VS_MEM_DEVICE, p, out + off, status + off, a->info.data() + off);
+            if (r != VS_OK) { if (next.valid()) (void)next.get(); return r; }
+        }
+    } else {
+        for (int off = 0; off < n; off += max_chunk) {
+            const int m = std::min(max_chunk, n - off);
+            VS_TRY(a->ensure_capacity(m));
+            const uint8_t* base = (const uint8_t*)frames + (size_t)off * frame_stride * esz;
+            VS_TRY(a->run_chunk(base, frame_stride, m, stride, mem, p, out + off, status + off, a->info.data() + off));
+        }
     }
     for (int i = 0; i < n; i++) aligned += status[i];
     return aligned;
@@ -901,7 +962,13 @@ struct vs_stabilizer {
     std::vector<void*> pool;       // recycled frame buffers
     size_t frame_bytes = 0;
     void* batch_in = nullptr; size_t batch_in_bytes = 0;     // dense device copy of the current batch
-    void* batch_out = nullptr; size_t batch_out_bytes = 0;   // full-size warped frames of the current batch
+    // host callers: cropped outputs of the current chunk on their way down.  Two areas, used alternately by the chunks of a
+    // pipelined batch; a downloader thread drains area k on down_stream while the next chunk is computed into area k^1.
+    void* batch_out[2] = {nullptr, nullptr}; size_t batch_out_bytes[2] = {0, 0};
+    std::future<hipError_t> down[2];
+    hipEvent_t down_ev[2] = {nullptr, nullptr};
+    hipStream_t down_stream = nullptr, up_stream = nullptr;
+    void* pipe_in[2] = {nullptr, nullptr}; size_t pipe_in_bytes = 0;     // upload areas of a pipelined host batch
     std::vector<vs_transform> t_buf;
     std::vector<int32_t> st_buf;
     vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
@@ -934,8 +1001,13 @@ void vs_stabilizer_destroy(vs_stabilizer* s) {
     if (!s) return;
     (void)hipSetDevice(s->aligner->device);
     stab_drop_frames(s);
+    for (auto& f : s->down) if (f.valid()) (void)f.get();
     if (s->batch_in) (void)hipFree(s->batch_in);
-    if (s->batch_out) (void)hipFree(s->batch_out);
+    for (void* q : s->batch_out) if (q) (void)hipFree(q);
+    for (void* q : s->pipe_in) if (q) (void)hipFree(q);
+    for (hipEvent_t e : s->down_ev) if (e) (void)hipEventDestroy(e);
+    if (s->down_stream) (void)hipStreamDestroy(s->down_stream);
+    if (s->up_stream) (void)hipStreamDestroy(s->up_stream);
     vs_smoother_destroy(s->smoother);
     vs_aligner_destroy(s->aligner);
     delete s;
@@ -949,7 +1021,11 @@ int vs_stabilizer_reset(vs_stabilizer* s);
 // n successive processFrame calls; clip_len > 0: the n frames are n / clip_len independent clips, each run through a
 // fresh stabilizer (reset before every clip and after the last), all of them aligned and warped together.
 static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
-                         int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h);
+                         int format, int in_mem, int out_mem, int slot, void* out, size_t out_frame_stride, int32_t* has_output,
+                         int* out_w, int* out_h);
+static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int chunk, int w,
+                                   int h, int stride, int format, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
+                                   int* out_h);
 
 // While a batch is in flight the frame queue holds non-owned pointers into the caller's buffer (or into batch_in); they
 // become copies of our own only at the end of a successful run.  Whatever stops a run early -- a HIP error, a refused
@@ -957,8 +1033,24 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
 // "new clip" state (and the stream drained, so nothing still reads the caller's frames), and the error is passed on.
 static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
                     int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h) {
-    const int r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, out, out_frame_stride, has_output,
-                                out_w, out_h);
+    // host-resident batches longer than one upload chunk run as a three-stage pipeline: upload / compute / download
+    int chunk = 0;
+    if (s && mem == VS_MEM_HOST && n > 1 && w > 0 && h > 0) {
+        const size_t fb = (size_t)w * h * 3 * (vs_format_bits(format) > 8 ? 2 : 1);
+        chunk = (int)std::max<size_t>(4, kIngestBytes / std::max<size_t>(1, fb));
+        if (clip_len > 0) chunk = std::max(clip_len, chunk - chunk % clip_len);
+    }
+    int r;
+    if (chunk > 0 && n > chunk)
+        r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
+                                    out_w, out_h);
+    else
+        r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, mem, 0, out, out_frame_stride, has_output,
+                          out_w, out_h);
+    if (s) for (auto& f : s->down) if (f.valid()) {          // every download has landed before the call returns
+        const hipError_t de = f.get();
+        if (de != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "output download failed: %s", hipGetErrorString(de));
+    }
     if (r < 0 && s && s->aligner) {
         const std::string why = vs_last_error();             // the reset below must not hide the cause
         (void)hipStreamSynchronize(s->aligner->stream);
@@ -969,8 +1061,60 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     return r;
 }
 
+// The batch split into chunks of `chunk` frames (whole clips in clip mode): an uploader thread fills the other upload area
+// with chunk c+1 while chunk c is aligned and warped, and a downloader thread drains chunk c's outputs while chunk c+1 is
+// computed -- upload, compute and download overlap, and the link carries input and output at the same time (full duplex).
+// Every chunk goes through stab_run_impl exactly as a separate vs_stabilizer_process_batch call would, which is the
+// definition of the batched form ("n successive process calls"), so the results do not depend on the chunking.
+static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int chunk, int w,
+                                   int h, int stride, int format, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
+                                   int* out_h) {
+    VS_ARG(s && frames && out && has_output && out_w && out_h);
+    VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0 && stride >= 3 * w && w > 0 && h > 0);
+    VS_ARG(frame_stride >= (size_t)(h - 1) * stride + (size_t)3 * w);
+    vs_aligner* a = s->aligner;
+    VS_HIP(hipSetDevice(a->device));
+    const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
+    const size_t fbytes = (size_t)w * h * 3 * esz;
+    if (s->pipe_in_bytes < fbytes * chunk) {
+        for (void*& q : s->pipe_in) { if (q) (void)hipFree(q); q = nullptr; }
+        s->pipe_in_bytes = 0;
+        VS_HIP(hipMalloc(&s->pipe_in[0], fbytes * chunk));
+        VS_HIP(hipMalloc(&s->pipe_in[1], fbytes * chunk));
+        s->pipe_in_bytes = fbytes * chunk;
+    }
+    if (!s->up_stream) VS_HIP(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
+    const bool dense = stride == 3 * w && frame_stride == (size_t)h * stride;
+    auto upload = [=](int c) -> hipError_t {                 // chunk c -> pipe_in[c & 1], dense
+        const int off = c * chunk, m = std::min(chunk, n - off);
+        hipError_t e = hipSetDevice(a->device);
+        const uint8_t* src = (const uint8_t*)frames + (size_t)off * frame_stride * esz;
+        if (e == hipSuccess && dense) e = hipMemcpyAsync(s->pipe_in[c & 1], src, fbytes * m, hipMemcpyHostToDevice, s->up_stream);
+        for (int i = 0; e == hipSuccess && !dense && i < m; i++)
+            e = hipMemcpy2DAsync((uint8_t*)s->pipe_in[c & 1] + (size_t)i * fbytes, (size_t)w * 3 * esz, src + (size_t)i * frame_stride * esz,
+                                 (size_t)stride * esz, (size_t)w * 3 * esz, h, hipMemcpyHostToDevice, s->up_stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(s->up_stream);
+    };
+    const int n_chunks = (n + chunk - 1) / chunk;
+    std::future<hipError_t> next = std::async(std::launch::async, upload, 0);
+    int produced = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        const int off = c * chunk, m = std::min(chunk, n - off);
+        const hipError_t ue = next.get();
+        if (c + 1 < n_chunks) next = std::async(std::launch::async, upload, c + 1);
+        int r = ue == hipSuccess ? VS_OK : set_error(VS_ERR_HIP, "frame upload failed: %s", hipGetErrorString(ue));
+        if (r == VS_OK)
+            r = stab_run_impl(s, s->pipe_in[c & 1], (size_t)w * h * 3, m, clip_len, w, h, 3 * w, format, VS_MEM_DEVICE, VS_MEM_HOST, c & 1,
+                              (uint8_t*)out + (size_t)off * out_frame_stride * esz, out_frame_stride, has_output + off, out_w, out_h);
+        if (r < 0) { if (next.valid()) (void)next.get(); return r; }
+        produced += r;
+    }
+    return produced;
+}
+
 static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
-                         int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w, int* out_h) {
+                         int format, int mem, int out_mem, int slot, void* out, size_t out_frame_stride, int32_t* has_output,
+                         int* out_w, int* out_h) {
     VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
     VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0);
     VS_ARG(stride >= 3 * w);
@@ -1006,10 +1150,15 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
             VS_HIP(hipMalloc(&s->batch_in, fbytes * n));
             s->batch_in_bytes = fbytes * n;
         }
-        for (int i = 0; i < n; i++)
-            VS_HIP(hipMemcpy2DAsync((uint8_t*)s->batch_in + (size_t)i * fbytes, (size_t)w * 3 * esz,
-                                    (const uint8_t*)frames + (size_t)i * frame_stride * esz, (size_t)stride * esz,
-                                    (size_t)w * 3 * esz, h, mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+        const hipMemcpyKind kind = mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        if (stride == 3 * w && (n == 1 || frame_stride == (size_t)h * stride)) {
+            VS_HIP(hipMemcpyAsync(s->batch_in, frames, fbytes * n, kind, st));   // dense input: one linear copy at the full link rate
+        } else {
+            for (int i = 0; i < n; i++)
+                VS_HIP(hipMemcpy2DAsync((uint8_t*)s->batch_in + (size_t)i * fbytes, (size_t)w * 3 * esz,
+                                        (const uint8_t*)frames + (size_t)i * frame_stride * esz, (size_t)stride * esz,
+                                        (size_t)w * 3 * esz, h, kind, st));
+        }
         dense = (const uint8_t*)s->batch_in;
     }
 
@@ -1080,11 +1229,18 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
     // get the window written straight into `out`; host callers through a dense staging buffer and one copy per frame.
     if (!jobs.empty()) {
         const size_t obytes = (size_t)ow * oh * 3 * esz;
-        if (mem == VS_MEM_HOST && s->batch_out_bytes < obytes * jobs.size()) {
-            if (s->batch_out) (void)hipFree(s->batch_out);
-            s->batch_out = nullptr; s->batch_out_bytes = 0;
-            VS_HIP(hipMalloc(&s->batch_out, obytes * jobs.size()));
-            s->batch_out_bytes = obytes * jobs.size();
+        const bool to_host = out_mem == VS_MEM_HOST;
+        if (to_host) {
+            if (s->down[slot].valid()) {                     // the previous user of this area has been drained
+                const hipError_t de = s->down[slot].get();
+                if (de != hipSuccess) return set_error(VS_ERR_HIP, "output download failed: %s", hipGetErrorString(de));
+            }
+            if (s->batch_out_bytes[slot] < obytes * jobs.size()) {
+                if (s->batch_out[slot]) (void)hipFree(s->batch_out[slot]);
+                s->batch_out[slot] = nullptr; s->batch_out_bytes[slot] = 0;
+                VS_HIP(hipMalloc(&s->batch_out[slot], obytes * jobs.size()));
+                s->batch_out_bytes[slot] = obytes * jobs.size();
+            }
         }
         std::vector<vs_transform> ts;
         for (size_t j = 0; j < jobs.size();) {
@@ -1093,20 +1249,42 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
                    jobs[e].i == jobs[e - 1].i + 1) e++;
             ts.clear();
             for (size_t k = j; k < e; k++) ts.push_back(jobs[k].sampling);
-            void* dst = mem == VS_MEM_HOST ? (void*)((uint8_t*)s->batch_out + j * obytes)
-                                           : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
-            const size_t dst_fs = mem == VS_MEM_HOST ? (size_t)ow * oh * 3 : out_frame_stride;
+            void* dst = to_host ? (void*)((uint8_t*)s->batch_out[slot] + j * obytes)
+                                : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
+            const size_t dst_fs = to_host ? (size_t)ow * oh * 3 : out_frame_stride;
             int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
                                                  s->params.warp_mode, s->params.warp_border, (1 << fbits) - 1, crop, crop, ow, oh,
                                                  dst, dst_fs, ow * 3, VS_MEM_DEVICE, st);
             if (wr < 0) return wr;
             j = e;
         }
-        for (size_t j = 0; j < jobs.size(); j++) {
-            if (mem == VS_MEM_HOST)
-                VS_HIP(hipMemcpyAsync((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz, (const uint8_t*)s->batch_out + j * obytes,
-                                      obytes, hipMemcpyDeviceToHost, st));
+        for (size_t j = 0; j < jobs.size(); j++)
             if (jobs[j].release) s->pool.push_back(jobs[j].release);   // reused only by later work on this stream
+        if (to_host) {
+            // hand the area to the downloader: it waits (on its own stream) for the warps above, then copies every output
+            // to the caller's memory -- runs of outputs that are contiguous on both sides as one copy
+            if (!s->down_stream) VS_HIP(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
+            if (!s->down_ev[slot]) VS_HIP(hipEventCreateWithFlags(&s->down_ev[slot], hipEventDisableTiming));
+            VS_HIP(hipEventRecord(s->down_ev[slot], st));
+            std::vector<int> idx(jobs.size());
+            for (size_t j = 0; j < jobs.size(); j++) idx[j] = jobs[j].i;
+            const int device = a->device;
+            const uint8_t* area = (const uint8_t*)s->batch_out[slot];
+            hipStream_t ds = s->down_stream;
+            hipEvent_t ev = s->down_ev[slot];
+            const bool out_dense = out_frame_stride * esz == obytes;
+            s->down[slot] = std::async(std::launch::async, [=]() -> hipError_t {
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = hipStreamWaitEvent(ds, ev, 0);
+                for (size_t j = 0; e == hipSuccess && j < idx.size();) {
+                    size_t k = j + 1;
+                    while (out_dense && k < idx.size() && idx[k] == idx[k - 1] + 1) k++;
+                    e = hipMemcpyAsync((uint8_t*)out + (size_t)idx[j] * out_frame_stride * esz, area + j * obytes, obytes * (k - j),
+                                       hipMemcpyDeviceToHost, ds);
+                    j = k;
+                }
+                return e != hipSuccess ? e : hipStreamSynchronize(ds);
+            });
         }
     }
     if (clip_len > 0) VS_TRY(vs_stabilizer_reset(s));   // nothing carries over from the last clip
