@@ -1,5 +1,5 @@
 // vs_video_test -- stabilize every clip of a directory (the role of the reference's video_test.cpp:10-128).
-//   vs_video_test [input_dir=../recordings] [output_dir=output] [--chunk N] [--device D] [--crop N] [--bilinear] [--444]
+//   vs_video_test [input_dir=../recordings] [output_dir=output] [--chunk N] [--device D] [--crop N] [--bilinear | --lanczos2] [--444]
 // For each .y4m / .bgr clip writes output_dir/processed_<name>.  Like the reference's driver it runs the default
 // VideoStabilizerParams with crop_pixels = 0 (video_test.cpp:54-55) unless --crop is given.  Frames go to the GPU in
 // chunks of N (default 64) and through vs_stabilizer_process_batch, which is defined as N successive processFrame calls.
@@ -65,13 +65,14 @@ static bool process_clip(const std::string& in_path, const std::string& out_path
 int main(int argc, char** argv) {
     std::string input_dir = "../recordings", output_dir = "output";   // video_test.cpp:12-13
     int chunk = 64, device = 0, crop = 0, positional = 0;
-    bool bilinear = false, force444 = false;
+    bool bilinear = false, lanczos2 = false, force444 = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--chunk" && i + 1 < argc) chunk = std::max(1, std::atoi(argv[++i]));
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--crop" && i + 1 < argc) crop = std::atoi(argv[++i]);
         else if (a == "--bilinear") bilinear = true;
+        else if (a == "--lanczos2") lanczos2 = true;
         else if (a == "--444") force444 = true;
         else if (positional == 0) { input_dir = a; positional++; }
         else if (positional == 1) { output_dir = a; positional++; }
@@ -95,7 +96,8 @@ int main(int argc, char** argv) {
         vs_stabilizer_params params;
         vs_stabilizer_params_default(&params);
         params.crop_pixels = crop;                         // 0: disable crop so we can see what it is doing (video_test.cpp:55)
-        if (bilinear) params.warp_mode = VS_WARP_BILINEAR;
+        if (bilinear) params.warp_mode = VS_WARP_BILINEAR;    // the default (the reference's INTER_LINEAR)
+        if (lanczos2) params.warp_mode = VS_WARP_LANCZOS2;
         int failed = 0;
         for (const auto& name : clips) {
             const std::string in_path = (fs::path(input_dir) / name).string();

@@ -63,7 +63,7 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
 
     def run(count, k=None, done=None):
         if stabilizer:
-            st = O.Stabilizer(**params_kw)
+            st = O.Stabilizer(warp_mode=O.WARP_LANCZOS2, **params_kw)
             for i in range(count):
                 st.process(frames_host[i])
                 if done is not None:
@@ -89,9 +89,19 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
         x.join()
     dt = time.perf_counter() - t0
     what = "full stabilizer loop" if stabilizer else "align + Lanczos2 warp"
+    # SURVEY 8(d) mode (i): ONE clip, the image-sized stages row-parallel over the same cores (the analogue of the .parallel(y)
+    # of the reference's Halide schedules; the Gauss-Newton sums stay serial as sparse_ica.schedule.h has them)
+    O.set_threads(threads)
+    single_n = int(max(3, min(n, sample * threads // 4)))
+    t0 = time.perf_counter()
+    run(single_n)
+    dt1 = time.perf_counter() - t0
+    O.set_threads(1)
     return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "first %d frames of one clip, %s, %d threads x 1 clip copy each, CPU restatement of the Halide "
-                      "path (not Halide)" % (sample, what, threads)}
+            "sample": "first %d frames of one clip, %s, %d threads x 1 clip copy each (the reference's many-clip regime, "
+                      "grid_search_align.cpp:105-210), CPU restatement of the Halide path (not Halide)" % (sample, what, threads),
+            "single_clip": {"value": round(single_n / dt1, 2), "unit": "frames/s", "threads": threads,
+                            "sample": "first %d frames of one clip, stages row-parallel over %d threads" % (single_n, threads)}}
 
 
 def cpu_model():
@@ -272,7 +282,7 @@ def main():
 
     if wl["stabilizer"]:
         crop = 32
-        stab = capi.Stabilizer(device=local_rank, **params_kw)
+        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2, **params_kw)   # the library default is the reference's bilinear
         out_buf = torch.empty((n_clips * n, H - 2 * crop, W - 2 * crop, 3), dtype=clips[0].dtype, device=dev)
         aligner = None
 
@@ -287,17 +297,17 @@ def main():
         warped = torch.empty_like(all_frames)
         N = n_clips * n
 
-        def step(timed):
+        def step(timed, warp_mode=None):
             # all clips of the rank in one call (vs_aligner_align_clips): every stage is one launch over all clips
             status, ts = aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
             if not args.no_warp:
                 if timed:
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record(stream)
+                if warp_mode is None:
+                    warp_mode = capi.WARP_LANCZOS2 if args.warp_mode == "exact" else capi.WARP_LANCZOS2_FAST
                 capi.bgr_image_warp_batch_device(all_frames.data_ptr(), N, W, H, 3, 8 if bits == 8 else 16, ts, warped.data_ptr(),
-                                                 capi.WARP_LANCZOS2 if args.warp_mode == "exact" else capi.WARP_LANCZOS2_FAST,
-                                                 capi.BORDER_CLAMP, max_value=max_value,
-                                                 stream=stream.cuda_stream)
+                                                 warp_mode, capi.BORDER_CLAMP, max_value=max_value, stream=stream.cuda_stream)
                 if timed:
                     b.record(stream)
                     ev.append((a, b))
@@ -336,6 +346,15 @@ def main():
         dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=red_dev)
         align_only = (dt_a, frames_a, aligner.timings())
 
+    fast_warp = None
+    if aligner and not args.no_warp and args.warp_mode == "exact":
+        # third figure: the same step with the tolerance-gated warp arithmetic (VS_WARP_LANCZOS2_FAST: within the north star's
+        # "1 ULP of the Lanczos path", tests/test_warp_fast_gpu.py) -- reported beside `value`, never as `value`
+        step(False, capi.WARP_LANCZOS2_FAST)
+        dt_f, _ = timed_loop(lambda: step(False, capi.WARP_LANCZOS2_FAST), args.steps)
+        dt_f, frames_f, _ = vsdist.aggregate(dt_f, n * n_clips * args.steps, 0, device=red_dev)
+        fast_warp = (dt_f, frames_f)
+
     if rank == 0:
         def stage_table(t):
             return {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // max(1, args.steps)}
@@ -365,6 +384,11 @@ def main():
             out["align_only"] = {"value": round(frames_a / dt_a, 2), "unit": "frames/s",
                                  "ms_per_step": round(1e3 * dt_a / args.steps, 4), "stages": stage_table(tm_a),
                                  "note": "same clips, alignment stages only (no warp launch competing for the CUs)"}
+        if fast_warp:
+            out["fast_warp"] = {"value": round(fast_warp[1] / fast_warp[0], 2), "unit": "frames/s",
+                                "ms_per_step": round(1e3 * fast_warp[0] / args.steps, 4),
+                                "note": "same step with bgr_image_warp in VS_WARP_LANCZOS2_FAST (fused multiply-adds; float output within the "
+                                        "ULP bound and integer output <= 1 LSB / >= 99.99 % identical, tests/test_warp_fast_gpu.py)"}
         if ev:
             ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per step over all the rank's frames
             bytes_per_launch = W * H * 3 * 2 * (1 if bits == 8 else 2) * n * n_clips  # W*H*3*(in+out) B per frame

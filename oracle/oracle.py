@@ -90,6 +90,8 @@ def lib():
         "vso_bgr_image_warp_f32": (None, [vp, i32, i32, i32, i32, i32, TP, i32, i32, vp, i32]),
         "vso_bgr_to_gray": (None, [vp, i32, i32, i32, i32, i32, vp, i32]),
         "vso_format_bits": (i32, [i32]),
+        "vso_set_threads": (None, [i32]),
+        "vso_get_threads": (i32, []),
         "vso_transform_inverse": (Transform, [TP]),
         "vso_transform_compose": (Transform, [TP, TP]),
         "vso_transform_warp": (Point, [TP, Point]),
@@ -155,6 +157,11 @@ def stabilizer_params(**kw):
         else:
             setattr(p, k, v)
     return p
+
+
+def set_threads(n):
+    """worker threads of the row-parallel stage loops (1 = serial, the default); results are identical for every n"""
+    lib().vso_set_threads(int(n))
 
 
 def lanczos2(x):

@@ -13,6 +13,26 @@
 #include <cstring>
 #include <deque>
 #include <vector>
+#include <thread>
+
+/* Row parallelism for the CPU-baseline timing (mode (i): "stage-internal row parallelism over all host cores",
+ * the analogue of the .parallel(y) of the reference's Halide schedules).  Off by default (1 thread).  Only loops whose
+ * iterations are independent use it -- no reduction is split, so results are bit-identical for every thread count
+ * (sparse_ica's serial fp64 sums stay serial, as sparse_ica.schedule.h:59-66 has them). */
+static int g_vso_threads = 1;
+extern "C" void vso_set_threads(int n) { g_vso_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+extern "C" int vso_get_threads(void) { return g_vso_threads; }
+template <typename F>
+static void vso_parallel_rows(int n, int min_rows_per_thread, F&& body) {   /* body(begin, end) */
+    int t = g_vso_threads;
+    if (t > n / (min_rows_per_thread > 0 ? min_rows_per_thread : 1)) t = n / (min_rows_per_thread > 0 ? min_rows_per_thread : 1);
+    if (t <= 1) { body(0, n); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)t - 1);
+    for (int k = 1; k < t; k++) th.emplace_back([&, k] { body((int)((long long)n * k / t), (int)((long long)n * (k + 1) / t)); });
+    body(0, (int)((long long)n / t));
+    for (auto& x : th) x.join();
+}
 
 namespace {
 
@@ -102,7 +122,8 @@ void bgr_warp_impl(const T* src, int w, int h, int src_stride, int channels,
     vso_ul_params_warp(t, w, h, p);
     const float A = p[0], B = p[1], TX = p[2], TY = p[3];
     ImageRef<T> img{src, w, h, src_stride, channels};
-    for (int y = 0; y < h; y++) {
+    vso_parallel_rows(h, 8, [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; y++) {
         for (int x = 0; x < w; x++) {
             /* generators.cpp:141-142 */
             float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
@@ -127,6 +148,7 @@ void bgr_warp_impl(const T* src, int w, int h, int src_stride, int channels,
             }
         }
     }
+    });
 }
 
 /* ---- 4x4 symmetric eigen-solver (stands in for cv::SVD / Mat::inv(DECOMP_SVD)) ---------- */
@@ -176,7 +198,7 @@ void vso_stabilizer_params_default(vso_stabilizer_params* p) {
     vso_aligner_params_default(&p->aligner);
     p->lag = 10; p->smoother_memory = 5; p->lambda = 4.0; p->enable_smoother = 1; p->crop_pixels = 32;
     p->min_disp = 48.0; p->max_disp = 64.0; p->min_decay = 0.9; p->max_decay = 0.7;
-    p->warp_mode = VSO_WARP_LANCZOS2; p->warp_border = VSO_BORDER_CONSTANT;
+    p->warp_mode = VSO_WARP_BILINEAR; p->warp_border = VSO_BORDER_CONSTANT;   /* imgproc.cpp:472-481: INTER_LINEAR, BORDER_CONSTANT */
 }
 
 float vso_lanczos2(float x) { return lanczos2(x); }
@@ -190,23 +212,27 @@ void vso_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, 
         return (coeffs[0] * px(x, y - 2) + coeffs[1] * px(x, y - 1) + coeffs[2] * px(x, y) +
                 coeffs[3] * px(x, y + 1) + coeffs[4] * px(x, y + 2));
     };
-    for (int y = 0; y < oh; y++)
+    vso_parallel_rows(oh, 8, [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; y++)
         for (int x = 0; x < ow; x++) {
             int X = 2 * x, Y = 2 * y;
             float v = (coeffs[0] * blur_y(X - 2, Y) + coeffs[1] * blur_y(X - 1, Y) + coeffs[2] * blur_y(X, Y) +
                        coeffs[3] * blur_y(X + 1, Y) + coeffs[4] * blur_y(X + 2, Y));
             out[(size_t)y * out_stride + x] = (uint8_t)v;
         }
+    });
 }
 
 /* generators.cpp:215-223 */
 void vso_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy) {
     auto px = [&](int x, int y) { return (float)in[(size_t)clampi(y, 0, h - 1) * stride + clampi(x, 0, w - 1)]; };
-    for (int y = 0; y < h; y++)
+    vso_parallel_rows(h, 16, [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; y++)
         for (int x = 0; x < w; x++) {
             gx[(size_t)y * w + x] = 0.5f * (px(x + 1, y) - px(x - 1, y));
             gy[(size_t)y * w + x] = 0.5f * (px(x, y + 1) - px(x, y - 1));
         }
+    });
 }
 
 /* imgproc.cpp:151-162 */
@@ -229,7 +255,8 @@ void vso_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uin
     for (int pass = 0; pass < 2; pass++) {
         const float* g = pass == 0 ? gx : gy;
         uint16_t* lm = pass == 0 ? lmx : lmy;
-        for (int y = 0; y < ty; y++)
+        vso_parallel_rows(ty, 2, [&](int y_begin, int y_end) {
+        for (int y = y_begin; y < y_end; y++)
             for (int x = 0; x < tx; x++) {
                 int bx = 0, by = 0;
                 float best = std::fabs(g[(size_t)(y * ts) * w + x * ts]);
@@ -241,6 +268,7 @@ void vso_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uin
                 lm[(size_t)0 * tx * ty + y * tx + x] = (uint16_t)(bx + x * ts);
                 lm[(size_t)1 * tx * ty + y * tx + x] = (uint16_t)(by + y * ts);
             }
+        });
     }
 }
 
@@ -272,7 +300,8 @@ void vso_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, 
                          int tx, int ty, float A, float B, float TX, float TY, uint16_t* out) {
     const size_t n = (size_t)tx * ty;
     ImageRef<uint8_t> keyimg{key, w, h, stride, 1};
-    for (size_t i = 0; i < n; i++) {
+    vso_parallel_rows((int)n, 256, [&](int i_begin, int i_end) {
+    for (size_t i = (size_t)i_begin; i < (size_t)i_end; i++) {
         int tile_x = std::min<int>(lm[i], w - 1), tile_y = std::min<int>(lm[n + i], h - 1);
         float orig_x = (float)tile_x, orig_y = (float)tile_y;
         float Wx = (1.0f + A) * orig_x - B * orig_y + TX;
@@ -282,6 +311,7 @@ void vso_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, 
         diff = diff < 0.0f ? 0.0f : (diff > 65535.0f ? 65535.0f : diff);
         out[i] = (uint16_t)diff;
     }
+    });
 }
 
 /* generators.cpp:451-596.  reduce_4_x then reduce_4_y, each serial over r in index order
@@ -368,7 +398,8 @@ int vso_format_bits(int format) {
 
 void vso_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst,
                      int dst_stride) {
-    for (int y = 0; y < h; y++)
+    vso_parallel_rows(h, 16, [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; y++)
         for (int x = 0; x < w; x++) {
             uint32_t b, g, r;
             if (bits == 8) {
@@ -382,6 +413,7 @@ void vso_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, in
             v >>= shift_to_8;
             dst[(size_t)y * dst_stride + x] = (uint8_t)(v > 255u ? 255u : v);
         }
+    });
 }
 
 /* imgproc.cpp:333-359 */

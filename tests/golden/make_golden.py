@@ -69,7 +69,7 @@ def aligner_fixture():
 
 def stabilizer_fixture():
     frames, _ = synth.make_clip(160, 128, 9, seed=104, channels=3)
-    st = O.Stabilizer(lag=3, smoother_memory=1, crop_pixels=8)
+    st = O.Stabilizer(lag=3, smoother_memory=1, crop_pixels=8, warp_mode=O.WARP_LANCZOS2)   # the fixture predates the bilinear default
     meas, acc, outs = [], [], []
     for f in frames:
         o = st.process(f)

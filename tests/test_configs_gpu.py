@@ -72,14 +72,18 @@ def test_c4_many_1080p_clips_match_one_oracle_aligner_per_clip(gpu_vs, oracle):
     assert good == n_clips * (fpc - 1)
 
 
-def test_c5_10bit_stabilizer_clips_match_one_oracle_stabilizer_per_clip(gpu_vs, oracle):
+@pytest.mark.parametrize("sampler", ["default", "lanczos2"])
+def test_c5_10bit_stabilizer_clips_match_one_oracle_stabilizer_per_clip(gpu_vs, oracle, sampler):
     n_clips, fpc, w, h = 2, 14, 640, 360
     clips = [_device_clip(w, h, fpc, seed=2000 + c, bits=10)[0] for c in range(n_clips)]
-    g = gpu_vs.Stabilizer(device=0)                         # VideoStabilizerParams defaults: lag 10, smoother 5, crop 32
+    # VideoStabilizerParams defaults: lag 10, smoother 5, crop 32, and the reference's bilinear warp; "lanczos2" = bgr_image_warp
+    kw = {} if sampler == "default" else dict(warp_mode=gpu_vs.WARP_LANCZOS2)
+    g = gpu_vs.Stabilizer(device=0, **kw)
+    assert g.params.warp_mode == (gpu_vs.WARP_BILINEAR if sampler == "default" else gpu_vs.WARP_LANCZOS2)
     out, has = g.process_clips(np.concatenate(clips, 0), n_clips)
     produced = 0
     for c in range(n_clips):
-        cpu = oracle.Stabilizer()
+        cpu = oracle.Stabilizer(**kw)
         for k in range(fpc):
             oc = cpu.process(clips[c][k])
             i = c * fpc + k
@@ -103,18 +107,18 @@ def test_c5_4k_10bit_clip_properties(gpu_vs):
     and a static clip comes back as the crop of its input within 1 LSB (identity correction)."""
     lag, w, h = 10, 3840, 2160
     frames, _ = _device_clip(w, h, lag + 2, seed=2000, bits=10)
-    s = gpu_vs.Stabilizer(device=0)
+    s = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_LANCZOS2)
     out, has = s.process_clips(frames, 1)
     assert has == [0] * lag + [1, 1] and out.shape == (lag + 2, h - 64, w - 64, 3)
     assert int(out[lag:].max()) <= 1023
-    seq = gpu_vs.Stabilizer(device=0)
+    seq = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_LANCZOS2)
     for i, f in enumerate(frames):
         o = seq.process(f)
         assert (o is None) == (i < lag)
         if o is not None:
             assert np.array_equal(o, out[i]), i
     static = np.repeat(frames[:1], lag + 2, axis=0)
-    o2, h2 = gpu_vs.Stabilizer(device=0).process_clips(static, 1)
+    o2, h2 = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_LANCZOS2).process_clips(static, 1)
     assert h2 == has
     d = np.abs(o2[lag].astype(np.int32) - frames[0][32:-32, 32:-32].astype(np.int32))
     assert d.max() <= 1

@@ -54,7 +54,7 @@ def test_oracle_reproduces_aligner_and_stabilizer_fixtures(oracle):
         assert ok == bool(a["ok"][i]) and t.tup() == tuple(a["transforms"][i])
     s = np.load(os.path.join(G, "stabilizer_160x128.npz"))
     frames, _ = synth.make_clip(160, 128, len(s["meas"]), seed=int(s["seed"]), channels=3)
-    st = oracle.Stabilizer(lag=3, smoother_memory=1, crop_pixels=8)
+    st = oracle.Stabilizer(lag=3, smoother_memory=1, crop_pixels=8, warp_mode=oracle.WARP_LANCZOS2)
     for i, f in enumerate(frames):
         o = st.process(f)
         m, acc, _ = st.state()
@@ -91,7 +91,7 @@ def test_gpu_matches_aligner_and_stabilizer_fixtures(gpu_vs):
             assert list(al.info(i).iterations[:a["iterations"].shape[1]]) == list(a["iterations"][i])
     s = np.load(os.path.join(G, "stabilizer_160x128.npz"))
     frames, _ = synth.make_clip(160, 128, len(s["meas"]), seed=int(s["seed"]), channels=3)
-    sg = gpu_vs.Stabilizer(device=0, lag=3, smoother_memory=1, crop_pixels=8)
+    sg = gpu_vs.Stabilizer(device=0, lag=3, smoother_memory=1, crop_pixels=8, warp_mode=gpu_vs.WARP_LANCZOS2)
     for i, f in enumerate(frames):
         o = sg.process(f)
         m, acc, _ = sg.state()

@@ -484,3 +484,32 @@ def test_stabilizer_lag_and_static_clip(oracle):
     m, a, ok = st.state()
     assert ok and max(abs(v) for v in m.tup()) < 1e-3   # not exactly 0: the frac-0 Lanczos taps are -3.1e-5, not 0
     assert np.array_equal(outs[-1], frames[0][8:-8, 8:-8])
+
+
+def test_row_parallel_mode_changes_nothing(oracle):
+    """oracle.set_threads(n): the image-sized stage loops run row-parallel (CPU-baseline timing mode); no
+    reduction is split, so every output is bit-identical to the serial run"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(322, 246, 3, seed=19, channels=3)
+
+    def run():
+        a = oracle.Aligner()
+        out = []
+        for f in frames:
+            ok, t = a.align_next(f)
+            out.append((ok, t.tup(), oracle.bgr_image_warp(f, t if ok else oracle.Transform.of(0.01, -0.02, 1.5, 2.5))))
+        lv = a.level(0)
+        return out, lv["argmax"], lv["jac"]
+
+    try:
+        oracle.set_threads(1)
+        r1, am1, j1 = run()
+        oracle.set_threads(5)
+        assert oracle.lib().vso_get_threads() == 5
+        r5, am5, j5 = run()
+    finally:
+        oracle.set_threads(1)
+    for a, b in zip(r1, r5):
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+    for s in (0, 1):
+        assert np.array_equal(am1[s], am5[s]) and np.array_equal(j1[s], j5[s])

@@ -57,7 +57,9 @@ void vs_stabilizer_params_default(vs_stabilizer_params* p) {
     p->max_disp = 64.0;
     p->min_decay = 0.9;
     p->max_decay = 0.7;
-    p->warp_mode = VS_WARP_LANCZOS2;
+    // the reference warps with cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT) (imgproc.cpp:472-481): a drop-in user gets the
+    // same sampler class by default; VS_WARP_LANCZOS2 (the north star's bgr_image_warp) is one field away
+    p->warp_mode = VS_WARP_BILINEAR;
     p->warp_border = VS_BORDER_CONSTANT;
 }
 
