@@ -46,9 +46,6 @@ namespace {
 #ifndef VS_WARP_EXACT_MINWAVES
 #define VS_WARP_EXACT_MINWAVES 4
 #endif
-#ifndef VS_WARP_SKIP_SELECTS
-#define VS_WARP_SKIP_SELECTS 0           // exact mode: run the |x| >= 2 selects only in waves that need them
-#endif
 #ifndef VS_WARP_TILE_H
 #define VS_WARP_TILE_H 16                // output rows per workgroup (4 waves: VS_WARP_TILE_H / 4 rows per wave)
 #endif
@@ -77,45 +74,28 @@ __device__ __forceinline__ uint32_t store_u(float v, float maxv) {
     return (uint32_t)__builtin_amdgcn_fmed3f(v + 0.5f, 0.0f, maxv);
 }
 
-// u8 store: clamp(floor(v + 0.5), 0, 255) packed into byte `k` of `acc`.  v_cvt_pk_u8_f32 saturates to [0, 255] and packs
-// in one instruction; it rounds to nearest even, so it is fed the already floored (integer-valued) sum -- the result is
-// the build rule of store_u exactly (tools/probe_cvt.hip shows the instruction's rounding and saturation on gfx950).
-// Only valid for max_value == 255 (the launcher routes other 8-bit maxima to the generic kernel).
-__device__ __forceinline__ uint32_t store_u8_packed(float v, uint32_t k, uint32_t acc) {
-    const float t = floorf(v + 0.5f);
-    uint32_t r;
-    asm("v_cvt_pk_u8_f32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "v"(k), "v"(acc));
-    return r;
-}
-
 // Three correctly rounded quotients over one denominator.  This is hipcc's own fp32 division expansion
 // (v_div_scale, v_rcp, two Newton steps on the reciprocal-quotient pair, v_div_fmas, v_div_fixup) with the
 // parts that are no-ops here removed: den is a sum of Lanczos weights (0.99..1.05) and the numerators are
 // bounded byte sums, so no operand scaling and no special-case fix-up ever applies; what is left is the
 // same fma sequence, and the reciprocal refinement is shared by the three channels (18 instructions
 // instead of 33).  Outside the safe range the caller falls back to operator/ (wave-uniform branch).
-// The quotient steps run packed on the accumulator pairs as they stand: {numB, numG} and {numR, den} (the second half of
-// the latter computes den / den and is ignored) -- 10 packed + 3 scalar instructions per pixel.
-__device__ __forceinline__ void div3_core(f2 nbg, f2 nrd, float q[3]) {
-    const float den = nrd.y;
+__device__ __forceinline__ void div3_core(float n0, float n1, float n2, float den, float q[3]) {
     float r = __builtin_amdgcn_rcpf(den);
     const float e = __builtin_fmaf(-den, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
-    const f2 rr = {r, r}, nd = {-den, -den};
-    f2 a, t;
-    a = nbg * rr; t = __builtin_elementwise_fma(nd, a, nbg); a = __builtin_elementwise_fma(t, rr, a); t = __builtin_elementwise_fma(nd, a, nbg);
-    const f2 qbg = __builtin_elementwise_fma(t, rr, a);
-    a = nrd * rr; t = __builtin_elementwise_fma(nd, a, nrd); a = __builtin_elementwise_fma(t, rr, a); t = __builtin_elementwise_fma(nd, a, nrd);
-    const f2 qr = __builtin_elementwise_fma(t, rr, a);
-    q[0] = qbg.x; q[1] = qbg.y; q[2] = qr.x;
+    float a, t;
+    a = n0 * r; t = __builtin_fmaf(-den, a, n0); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n0); q[0] = __builtin_fmaf(t, r, a);
+    a = n1 * r; t = __builtin_fmaf(-den, a, n1); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n1); q[1] = __builtin_fmaf(t, r, a);
+    a = n2 * r; t = __builtin_fmaf(-den, a, n2); a = __builtin_fmaf(t, r, a); t = __builtin_fmaf(-den, a, n2); q[2] = __builtin_fmaf(t, r, a);
 }
 
 // Exact Lanczos2 of two output pixels (rows k, k+1 of one lane) from the LDS tile; t[j] = staged pixel (iy-1, ix-1) of
 // pixel j.  Per pixel: the four live taps of the 5-tap window per axis (tap 0 has weight exactly 0) as four packed Horner
 // chains, each holding two adjacent taps of one axis, so the tap products are packed too; {B,G} and {R,den} accumulate as
 // pairs (the tile's trailing 1.0 makes den += w2d part of the same instruction; w2d*1.0 is exact).  Every component sees
-// exactly the reference's sequence of roundings (generators.cpp:31-47, 684-697).  Out: {numB, numG} and {numR, den} per pixel.
-__device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], f2 nbg_out[2], f2 nrd_out[2]) {
+// exactly the reference's sequence of roundings (generators.cpp:31-47, 684-697).  num[j] = {numB, numG, numR, den}.
+__device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], float num[2][4]) {
     // chain c of pixel j: 0 = x taps {1,2}, 1 = x taps {3,4}, 2 = y taps {1,2}, 3 = y taps {3,4}
     f2 x[2][4], x2[2][4], v[2][4], mm[2][4];
 #pragma unroll
@@ -140,24 +120,13 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], f2
 #pragma unroll
             for (int j = 0; j < 2; j++) v[j][c] = C[s] + mm[j][c];
     }
-    // |x| >= 2 (generators.cpp:46) can only happen for taps 1 (-1-frac) and 4 (2-frac): when frac is exactly 0, or so close
-    // to 1 that -1-frac rounds to -2 (frac >= 1 - 2^-24).  With VS_WARP_SKIP_SELECTS the eight selects of a pixel pair run
-    // only in waves where some lane has such a fraction (integer translations, mostly): two min/max trees and one
-    // wave-uniform branch instead.
-    bool edge = true;
-    if (VS_WARP_SKIP_SELECTS) {
-        const float mn = fminf(fminf(fr[0].x, fr[0].y), fminf(fr[1].x, fr[1].y));
-        const float mx = fmaxf(fmaxf(fr[0].x, fr[0].y), fmaxf(fr[1].x, fr[1].y));
-        edge = __any(!(mn > 0.0f && mx < 0.99999994f));
-    }
-    if (edge) {
+    // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            v[j][0].x = fabsf(x[j][0].x) >= 2.0f ? 0.0f : v[j][0].x;
-            v[j][1].y = fabsf(x[j][1].y) >= 2.0f ? 0.0f : v[j][1].y;
-            v[j][2].x = fabsf(x[j][2].x) >= 2.0f ? 0.0f : v[j][2].x;
-            v[j][3].y = fabsf(x[j][3].y) >= 2.0f ? 0.0f : v[j][3].y;
-        }
+    for (int j = 0; j < 2; j++) {
+        v[j][0].x = fabsf(x[j][0].x) >= 2.0f ? 0.0f : v[j][0].x;
+        v[j][1].y = fabsf(x[j][1].y) >= 2.0f ? 0.0f : v[j][1].y;
+        v[j][2].x = fabsf(x[j][2].x) >= 2.0f ? 0.0f : v[j][2].x;
+        v[j][3].y = fabsf(x[j][3].y) >= 2.0f ? 0.0f : v[j][3].y;
     }
     f2 nbg[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, nrd[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
@@ -188,7 +157,8 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], f2
             }
         }
     }
-    nbg_out[0] = nbg[0]; nbg_out[1] = nbg[1]; nrd_out[0] = nrd[0]; nrd_out[1] = nrd[1];
+#pragma unroll
+    for (int j = 0; j < 2; j++) { num[j][0] = nbg[j].x; num[j][1] = nbg[j].y; num[j][2] = nrd[j].x; num[j][3] = nrd[j].y; }
 }
 
 // VS_WARP_LANCZOS2_FAST of two output pixels: vs_device.hpp's lanczos2_fma / lanczos_fast_rden / lanczos_fast_combine,
@@ -477,8 +447,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
     const float c0 = -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
-    uint32_t o[RPW][3];                                      // u16: the three channel values; u8: o[k][0] = B | G << 8 | R << 16
-    f2 nbg[RPW], nrd[RPW];                                   // exact mode: {numB, numG}, {numR, den}, kept for the operator/ fallback
+    uint32_t o[RPW][3];
+    float num[RPW][4];                                         // exact mode: {numB, numG, numR, den} kept for the operator/ fallback
     bool all_ok = true;
     // rows are processed two at a time, the two rows' instructions alternating in source order: a packed-fp32 result
     // cannot feed the very next VALU instruction without a wait state on gfx950, and the other row's operation fills it
@@ -486,27 +456,24 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     for (int kp = 0; kp < RPW; kp += 2) {
         f2 fr[2];
         lds_f4 t[2];
-        {
-            // both rows' coordinates as {row j, row j+1} pairs: per component the operations of generators.cpp:141-142
-            // rows below the window repeat its last row (masked at the store)
-            const f2 fy = {(float)(min(yw + kp, roi.h - 1) + roi.y), (float)(min(yw + kp + 1, roi.h - 1) + roi.y)};
-            const f2 Wx = (f2{A1x, A1x} - f2{B, B} * fy) + f2{TX, TX};
-            const f2 Wy = (f2{Bx, Bx} + f2{A1, A1} * fy) + f2{TY, TY};
-            const f2 flx = {floorf(Wx.x), floorf(Wx.y)}, fly = {floorf(Wy.x), floorf(Wy.y)};
-            const f2 frx = Wx - flx, fry = Wy - fly;
-            fr[0] = f2{frx.x, fry.x}; fr[1] = f2{frx.y, fry.y};
-            // LDS byte offset: exact small integers in fp32, so the fused form changes nothing
-            const f2 bo = __builtin_elementwise_fma(fly, f2{16.0f * WS_RS, 16.0f * WS_RS}, __builtin_elementwise_fma(flx, f2{16.0f, 16.0f}, f2{c0, c0}));
-            t[0] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + (int)bo.x);
-            t[1] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + (int)bo.y);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int yq = min(yw + kp + j, roi.h - 1);      // rows below the window repeat its last row (masked below)
+            const float fy = (float)(yq + roi.y);
+            const float Wx = A1x - B * fy + TX;              // generators.cpp:141
+            const float Wy = Bx + A1 * fy + TY;              // generators.cpp:142
+            const float flx = floorf(Wx), fly = floorf(Wy);
+            fr[j] = f2{Wx - flx, Wy - fly};
+            const int boff = (int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0));
+            t[j] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
         }
         float q[2][3];
         if (MODE == 0) {
-            exact_pair(t, fr, &nbg[kp], &nrd[kp]);
+            exact_pair(t, fr, &num[kp]);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                all_ok = all_ok && (nrd[kp + j].y > 0.5f && nrd[kp + j].y < 2.0f);
-                div3_core(nbg[kp + j], nrd[kp + j], q[j]);
+                all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
+                div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else if (MODE == 2) {
             fast_pair(t, fr, q);
@@ -516,14 +483,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            if (sizeof(T) == 1) {
-                o[kp + j][0] = store_u8_packed(q[j][2], 2, store_u8_packed(q[j][1], 1, store_u8_packed(q[j][0], 0, 0)));
-                o[kp + j][1] = o[kp + j][2] = 0;
-            } else {
-                o[kp + j][0] = store_u(q[j][0], maxv);
-                o[kp + j][1] = store_u(q[j][1], maxv);
-                o[kp + j][2] = store_u(q[j][2], maxv);
-            }
+            o[kp + j][0] = store_u(q[j][0], maxv);
+            o[kp + j][1] = store_u(q[j][1], maxv);
+            o[kp + j][2] = store_u(q[j][2], maxv);
         }
         if (MODE == 2 && VS_WARP_FAST_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // keeps the second pair's 32 LDS reads (128 VGPRs) behind the first pair
     }
@@ -531,11 +493,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
         for (int k = 0; k < RPW; k++) {
-            float den = nrd[k].y;
+            float den = num[k][3];
             asm volatile("" : "+v"(den));                    // keeps the three divisions inside this branch (no speculation)
-            const uint32_t b = store_u(nbg[k].x / den, maxv), g = store_u(nbg[k].y / den, maxv), r = store_u(nrd[k].x / den, maxv);
-            if (sizeof(T) == 1) { o[k][0] = b | (g << 8) | (r << 16); }
-            else { o[k][0] = b; o[k][1] = g; o[k][2] = r; }
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[k][c] = store_u(num[k][c] / den, maxv);
         }
     }
 
@@ -552,16 +513,16 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 #pragma unroll
         for (int k = 0; k < RPW; k++) {
             const int y = yw + k;
-            const uint32_t p = o[k][0];
+            const uint32_t p = o[k][0] | (o[k][1] << 8) | (o[k][2] << 16);
             const uint32_t d = quad_pack_bgr(p, sel);        // every lane of the wave takes part in the shuffle
             if (y < roi.h) {                                 // wave-uniform
                 uint8_t* orow = (uint8_t*)dst + (size_t)y * dst_stride;
                 if (rows_aligned && quad_in) {
                     if (m < 3) *(uint32_t*)(orow + loff) = d;
                 } else if (lane_in) {
-                    orow[(size_t)x * 3] = (uint8_t)p;
-                    orow[(size_t)x * 3 + 1] = (uint8_t)(p >> 8);
-                    orow[(size_t)x * 3 + 2] = (uint8_t)(p >> 16);
+                    orow[(size_t)x * 3] = (uint8_t)o[k][0];
+                    orow[(size_t)x * 3 + 1] = (uint8_t)o[k][1];
+                    orow[(size_t)x * 3 + 2] = (uint8_t)o[k][2];
                 }
             }
         }
@@ -623,7 +584,6 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
 
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
                        int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
-    if (bits == 8 && max_value != 255) return hipErrorNotSupported;   // the u8 store saturates at 255 (generic kernel otherwise)
     if (bits == 8)
         return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, mode, border, (uint8_t*)dst, dst_stride, n_frames,
                                   src_fs, dst_fs, (float)max_value, roi, s);
