@@ -397,7 +397,7 @@ def main():
             # this launch's frame count; null when there is no profile for this frame format
             traffic = None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
                 key, per = {(1920, 8): ("c2_1080p_240_frames", 240), (3840, 8): ("c3_4k_32_frames", 32)}[(W, bits)]
                 traffic = int(tj[key]["traffic_bytes"] / per * n * n_clips)
             except Exception:
@@ -405,7 +405,7 @@ def main():
             out["roofline"] = {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm", "binding": "valu",
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                               "traffic_source": "scaled from the committed PMC passes (profiles/r01_traffic.json), not measured in this run",
+                               "traffic_source": "scaled from the committed PMC passes (profiles/r02_traffic.json), not measured in this run",
                                "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
                                "note": "VALU-issue-bound, not HBM-bound: ~230 VALU instructions per output pixel in the "
                                        "reference's exact fp32 order (DESIGN.md, profiles/r02_bgr_image_warp.md); launches "
