@@ -515,7 +515,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
     for (int l = (fmt == VS_FMT_GRAY8 ? 1 : 2); l < levels; l++)
         VS_HIP(vsk::pyr_down(slot1 + L[l - 1].img_off, L[l - 1].w, L[l - 1].h, L[l - 1].w, slot1 + L[l].img_off, L[l].w,
                              L[l].h, L[l].w, n, pyr_frame, pyr_frame, s));
-    t_end(levels - 1);
+    t_end(levels - (fmt == VS_FMT_GRAY8 ? 1 : 2));
 
     // ---- PhaseImage (alignment.cpp:225-229): half spectra of level 2, for the carry-over slot too ------------
     if (p.phase_correlate) {
@@ -537,21 +537,34 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         if (clip_len > 0 && (clip_len & 1)) for (int c0 = 0; c0 < n; c0 += clip_len) runs.emplace_back(c0, std::min(clip_len, n - c0));
         else runs.emplace_back(0, n);
         bool any = false;
+        int kf_launches = 0;
         for (auto& r : runs) {
             const int first_odd = r.first + ((gidx(r.first) & 1) ? 0 : 1);
             const int n_odd = first_odd < r.first + r.second ? (r.first + r.second - first_odd + 1) / 2 : 0;
             if (n_odd <= 0) continue;
             if (!any) { t_begin(VS_STAGE_KEYFRAME); any = true; }
             const size_t so = (size_t)(first_odd + 1);
-            for (int l = 0; l < levels; l++) {
-                uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
-                float* jx = jac + so * jac_frame + L[l].jac_off;
-                VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
-                                     lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
-                                     2 * lm_frame, 2 * jac_frame, s));
+            vsk::KeyframeLevels KL{};
+            KL.n = levels;
+            for (int l = 0; l < levels; l++)
+                KL.lv[l] = vsk::KeyframeLevel{L[l].w, L[l].h, L[l].ts, L[l].tx, L[l].ty, 0, 0, L[l].img_off, L[l].lm_off, L[l].jac_off};
+            if (vsk::keyframe_levels_supported(KL)) {
+                // one launch for every level of every keyframe of the run
+                VS_HIP(vsk::keyframe_levels(pyr + so * pyr_frame, lm + so * lm_frame, jac + so * jac_frame, KL, n_odd, 2 * pyr_frame,
+                                            2 * lm_frame, 2 * jac_frame, s));
+                kf_launches += 1;
+            } else {
+                for (int l = 0; l < levels; l++) {
+                    uint16_t* lmx = lm + so * lm_frame + L[l].lm_off;
+                    float* jx = jac + so * jac_frame + L[l].jac_off;
+                    VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
+                                         lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
+                                         2 * lm_frame, 2 * jac_frame, s));
+                }
+                kf_launches += levels;
             }
         }
-        if (any) t_end(levels * (int)runs.size());
+        if (any) t_end(kf_launches);
     }
 
     // ---- frame pairs --------------------------------------------------------------------------

@@ -511,24 +511,19 @@ __device__ __forceinline__ void position_row(const RowFetch f, bool first, bool 
     p[GW + 1] = __builtin_amdgcn_perm(0u, right, 0x0c000c0cu);
 }
 
+// body of one 256-thread workgroup (4 strips); `block` = the workgroup's index within its level, pointers already at the frame
 template <int TS>
-__global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restrict__ img, int w, int h, int stride, int tx,
-                                                          int ty, uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy,
-                                                          float* __restrict__ jx, float* __restrict__ jy,
-                                                          size_t img_frame_stride, size_t lm_frame_stride,
-                                                          size_t jac_frame_stride, int strips_x) {
+__device__ __forceinline__ void keyframe_rows_body(const uint8_t* __restrict__ img, int w, int h, int stride, int tx, int ty,
+                                                   uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy, float* __restrict__ jx,
+                                                   float* __restrict__ jy, int strips_x, int block, unsigned (*s_key)[64][2]) {
     constexpr int GW = (TS % 4 == 0) ? 4 : 2;    // columns per lane
     constexpr int LPT = TS / GW;                 // lanes per tile
     constexpr int TPW = 64 / LPT;                // tiles per wave (a strip of TPW tiles along x)
-    __shared__ unsigned s_key[4][64][2];
-    img += blockIdx.y * img_frame_stride;
-    lmx += blockIdx.y * lm_frame_stride; lmy += blockIdx.y * lm_frame_stride;
-    jx += blockIdx.y * jac_frame_stride; jy += blockIdx.y * jac_frame_stride;
     ((unsigned*)s_key)[threadIdx.x] = 0u;
     ((unsigned*)s_key)[threadIdx.x + 256] = 0u;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + wave;     // strip index: tile row tyi, TPW tiles starting at tile column sx0
+    const int strip = block * 4 + wave;          // strip index: tile row tyi, TPW tiles starting at tile column sx0
     const int tyi = strip / strips_x, sx0 = (strip - tyi * strips_x) * TPW;
     const int tw = lane / LPT, g = lane - tw * LPT;
     const int txi = sx0 + tw;
@@ -546,6 +541,7 @@ __global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restr
         // D rows are in flight before the first one is needed and every step refills the slot it consumed (3 registers per
         // row).  The loop stays rolled: fully unrolled, the compiler hoists all TS + 2 row loads and the kernel drops to
         // 2 waves / SIMD.
+        // (deeper rings measured slower: D = 10 at TS = 20 takes 0.182 ms per 120 x 1080p keyframes x 3 levels against 0.141)
         constexpr int D = (TS % 4 == 0) ? 4 : 2;
         RowFetch ring[D];
 #pragma unroll
@@ -601,6 +597,39 @@ __global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restr
         jy[2 * nt + tile] = 0.f;
         jy[3 * nt + tile] = 2.f * g1;
     }
+}
+
+template <int TS>
+__global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restrict__ img, int w, int h, int stride, int tx,
+                                                          int ty, uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy,
+                                                          float* __restrict__ jx, float* __restrict__ jy,
+                                                          size_t img_frame_stride, size_t lm_frame_stride,
+                                                          size_t jac_frame_stride, int strips_x) {
+    __shared__ unsigned s_key[4][64][2];
+    keyframe_rows_body<TS>(img + blockIdx.y * img_frame_stride, w, h, stride, tx, ty, lmx + blockIdx.y * lm_frame_stride,
+                           lmy + blockIdx.y * lm_frame_stride, jx + blockIdx.y * jac_frame_stride, jy + blockIdx.y * jac_frame_stride,
+                           strips_x, (int)blockIdx.x, s_key);
+}
+
+// The keyframe pass of EVERY pyramid level of every keyframe in one launch (alignment.cpp:237-276 loops GradXY -> GradArgMax ->
+// SparseJacobian over the levels; here: blockIdx.x walks the levels' workgroups back to back, blockIdx.y = keyframe).  Levels
+// are dense images inside one pyramid slot, keypoint / Jacobian tables likewise (vs_engine.hip "Data layout").  The tile size
+// differs per level (imgproc.cpp:151-162), so the body is selected by a switch over the ten sizes the rule can return; the
+// branch is workgroup-uniform.
+__global__ __launch_bounds__(256) void vs_k_keyframe_levels(const uint8_t* __restrict__ pyr, uint16_t* __restrict__ lm,
+                                                            float* __restrict__ jac, size_t pyr_frame_stride,
+                                                            size_t lm_frame_stride, size_t jac_frame_stride, vsk::KeyframeLevels L) {
+    __shared__ unsigned s_key[4][64][2];
+    int l = 0, block = (int)blockIdx.x;
+    while (l + 1 < L.n && block >= L.lv[l].blocks) { block -= L.lv[l].blocks; l++; }     // scalar: <= 16 levels
+    const vsk::KeyframeLevel& q = L.lv[l];
+    const size_t nt = (size_t)q.tx * q.ty;
+    const uint8_t* img = pyr + blockIdx.y * pyr_frame_stride + q.img_off;
+    uint16_t* lmx = lm + blockIdx.y * lm_frame_stride + q.lm_off;
+    float* jx = jac + blockIdx.y * jac_frame_stride + q.jac_off;
+#define VS_KF(TS) case TS: keyframe_rows_body<TS>(img, q.w, q.h, q.w, q.tx, q.ty, lmx, lmx + 2 * nt, jx, jx + 4 * nt, q.strips_x, block, s_key); break;
+    switch (q.ts) { VS_KF(2) VS_KF(4) VS_KF(6) VS_KF(8) VS_KF(10) VS_KF(12) VS_KF(14) VS_KF(16) VS_KF(18) VS_KF(20) default: break; }
+#undef VS_KF
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,6 +903,25 @@ hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16
                            lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs);
     }
 #undef VS_ROWS
+    return hipGetLastError();
+}
+
+// all levels of n_frames keyframes in one launch; false = a level's tile size has no row-walking body (caller launches per level)
+bool keyframe_levels_supported(const KeyframeLevels& L) {
+    for (int i = 0; i < L.n; i++)
+        if (L.lv[i].ts < 2 || L.lv[i].ts > 20 || (L.lv[i].ts & 1) || L.lv[i].tx * L.lv[i].ty == 0) return false;
+    return L.n >= 1 && L.n <= 16;
+}
+hipError_t keyframe_levels(const uint8_t* pyr, uint16_t* lm, float* jac, KeyframeLevels L, int n_frames, size_t pyr_fs, size_t lm_fs,
+                           size_t jac_fs, hipStream_t s) {
+    int total = 0;
+    for (int i = 0; i < L.n; i++) {
+        const int ts = L.lv[i].ts, tpw = 64 / (ts / ((ts % 4 == 0) ? 4 : 2));
+        L.lv[i].strips_x = cdiv(L.lv[i].tx, tpw);
+        L.lv[i].blocks = cdiv(L.lv[i].strips_x * L.lv[i].ty, 4);
+        total += L.lv[i].blocks;
+    }
+    hipLaunchKernelGGL(vs_k_keyframe_levels, dim3(total, n_frames), dim3(256), 0, s, pyr, lm, jac, pyr_fs, lm_fs, jac_fs, L);
     return hipGetLastError();
 }
 

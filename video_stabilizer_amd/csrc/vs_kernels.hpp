@@ -28,6 +28,13 @@ hipError_t sparse_jac(const float* gx, const float* gy, int w, int h, const uint
 hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
                     float* jy, int n_frames, size_t img_frame_stride, size_t lm_frame_stride, size_t jac_frame_stride,
                     hipStream_t s);
+// every pyramid level of n_frames keyframes in ONE launch: pyr / lm / jac = slot of the first keyframe, levels at the given
+// element offsets inside a slot (x-set table at lm_off, y-set 2*nt later; x-set Jacobians at jac_off, y-set 4*nt later)
+struct KeyframeLevel { int w, h, ts, tx, ty, strips_x, blocks; size_t img_off, lm_off, jac_off; };
+struct KeyframeLevels { int n; KeyframeLevel lv[16]; };
+bool keyframe_levels_supported(const KeyframeLevels& L);
+hipError_t keyframe_levels(const uint8_t* pyr, uint16_t* lm, float* jac, KeyframeLevels L, int n_frames, size_t pyr_frame_stride,
+                           size_t lm_frame_stride, size_t jac_frame_stride, hipStream_t s);
 hipError_t sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm,
                            int nt, float A, float B, float TX, float TY, uint16_t* out, hipStream_t s);
 hipError_t sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
