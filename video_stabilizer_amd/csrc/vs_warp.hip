@@ -380,6 +380,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                 if (sizeof(T) == 2) q1[s] = *(const u32x3*)(rowp[s] + sx * 3 + 6);
             }
         }
+        uint32_t one = 1u;
+        asm volatile("" : "+v"(one));                        // opaque: keeps the conversion below from folding to a constant
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
             if (!live[s]) continue;
@@ -387,10 +389,12 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
             if (direct[s]) {
                 if (sizeof(T) == 1) {
                     const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                    t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), 1.f};
-                    t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), 1.f};
-                    t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), 1.f};
-                    t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), 1.f};
+                    // the trailing 1.0 is converted from a byte like its three neighbours: four v_cvt_f32_ubyte into four
+                    // consecutive registers per pixel (with a literal 1.f the compiler builds the vector through moves)
+                    t[0] = f4{ub(q.x, 0), ub(q.x, 1), ub(q.x, 2), ub(one, 0)};
+                    t[1] = f4{ub(q.x, 3), ub(q.y, 0), ub(q.y, 1), ub(one, 0)};
+                    t[2] = f4{ub(q.y, 2), ub(q.y, 3), ub(q.z, 0), ub(one, 0)};
+                    t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), ub(one, 0)};
                 } else {
                     const u32x3 a = q0[s], b = q1[s];        // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3 (16 bits each)
                     t[0] = f4{(float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), 1.f};
