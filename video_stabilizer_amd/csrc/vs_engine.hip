@@ -220,6 +220,17 @@ static size_t ingest_chunk_bytes() {
 }
 #define kIngestBytes ingest_chunk_bytes()
 
+// Runs `fn(args...)` on a worker thread.  std::async may throw (std::system_error) when no thread can be started; no exception
+// may cross the C ABI, so in that case the task runs on the calling thread (std::launch::deferred) -- no overlap, same result.
+template <typename F, typename... A>
+static std::future<hipError_t> run_async(F&& fn, A&&... args) {
+    try {
+        return std::async(std::launch::async, fn, args...);
+    } catch (...) {
+        return std::async(std::launch::deferred, fn, args...);
+    }
+}
+
 struct vs_aligner {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -862,11 +873,11 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
             return e != hipSuccess ? e : hipStreamSynchronize(a->copy_stream);
         };
         const int n_chunks = (n + host_chunk - 1) / host_chunk;
-        std::future<hipError_t> next = std::async(std::launch::async, upload, 0);
+        std::future<hipError_t> next = run_async(upload, 0);
         for (int c = 0; c < n_chunks; c++) {
             const int off = c * host_chunk, m = std::min(host_chunk, n - off);
             const hipError_t ue = next.get();                 // chunk c is in ingest[c & 1]
-            if (c + 1 < n_chunks) next = std::async(std::launch::async, upload, c + 1);   // chunk c-1 (same area) has been consumed
+            if (c + 1 < n_chunks) next = run_async(upload, c + 1);   // chunk c-1 (same area) has been consumed
             int r = ue == hipSuccess ? VS_OK : set_error(VS_ERR_HIP, "frame upload failed: %s", hipGetErrorString(ue));
             if (r == VS_OK) r = a->ensure_capacity(m);
             if (r == VS_OK) r = a->run_chunk(a->ingest[c & 1], frame_stride, m, stride, VS_MEM_DEVICE, p, out + off, status + off, a->info.data() + off);
@@ -1109,12 +1120,12 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
         return e != hipSuccess ? e : hipStreamSynchronize(s->up_stream);
     };
     const int n_chunks = (n + chunk - 1) / chunk;
-    std::future<hipError_t> next = std::async(std::launch::async, upload, 0);
+    std::future<hipError_t> next = run_async(upload, 0);
     int produced = 0;
     for (int c = 0; c < n_chunks; c++) {
         const int off = c * chunk, m = std::min(chunk, n - off);
         const hipError_t ue = next.get();
-        if (c + 1 < n_chunks) next = std::async(std::launch::async, upload, c + 1);
+        if (c + 1 < n_chunks) next = run_async(upload, c + 1);
         int r = ue == hipSuccess ? VS_OK : set_error(VS_ERR_HIP, "frame upload failed: %s", hipGetErrorString(ue));
         if (r == VS_OK)
             r = stab_run_impl(s, s->pipe_in[c & 1], (size_t)w * h * 3, m, clip_len, w, h, 3 * w, format, VS_MEM_DEVICE, VS_MEM_HOST, c & 1,
@@ -1286,7 +1297,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
             hipStream_t ds = s->down_stream;
             hipEvent_t ev = s->down_ev[slot];
             const bool out_dense = out_frame_stride * esz == obytes;
-            s->down[slot] = std::async(std::launch::async, [=]() -> hipError_t {
+            s->down[slot] = run_async([=]() -> hipError_t {
                 hipError_t e = hipSetDevice(device);
                 if (e == hipSuccess) e = hipStreamWaitEvent(ds, ev, 0);
                 for (size_t j = 0; e == hipSuccess && j < idx.size();) {
