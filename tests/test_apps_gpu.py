@@ -147,6 +147,23 @@ def test_video_test_crop_and_bilinear(gpu_vs, clip, tmp_path):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("flag,mode", [("--bilinear", "WARP_BILINEAR"), ("--lanczos2", "WARP_LANCZOS2")])
+def test_video_test_output_matches_the_oracle_stabilizer(gpu_vs, oracle, clip, tmp_path, flag, mode):
+    """Parity, not plumbing: the file the harness writes against the CPU oracle's VideoStabilizer run on the same frames
+    (transforms agree to 1e-4 px, so a pixel may land on the other side of a rounding boundary: <= 1 LSB, almost all equal)."""
+    d, frames, raw = clip
+    only = tmp_path / "in"
+    only.mkdir()
+    os.symlink(raw, only / raw.name)
+    run("vs_video_test", only, tmp_path / "out", "--crop", 16, "--chunk", 13, flag)
+    got = np.fromfile(tmp_path / "out" / ("processed_" + raw.name), np.uint8).reshape(-1, H - 32, W - 32, 3)
+    cpu = oracle.Stabilizer(crop_pixels=16, warp_mode=getattr(oracle, mode))
+    want = np.stack([o for o in (cpu.process(f) for f in frames) if o is not None])
+    assert got.shape == want.shape
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-2, (int(diff.max()), float((diff != 0).mean()))
+
+
 def test_grid_search_align(gpu_vs, clip):
     d, frames, raw = clip
     out = run("vs_grid_search_align", raw, "-j", 3, "--frames", 32)
