@@ -6,6 +6,8 @@ to the host once, so the GPU path and the oracle see identical bytes.
   C4  many independent 1080p clips through vs_aligner_align_clips == one oracle aligner per clip
   C5  10-bit BGR through the full stabilizer loop (vs_stabilizer_process_clips) == one oracle stabilizer per clip;
       one 3840x2160 10-bit clip of lag + 2 frames through size-independent properties
+  C4 / C5 at full size: one GPU's share of the 64-clip configs (8 clips x 120 x 1080p; 8 clips x 60 x 4K 10-bit), resident
+      in HBM, in one call -- clip independence (a clip re-run alone is bit-identical), latency pattern, value range
 """
 import numpy as np
 import pytest
@@ -122,3 +124,56 @@ def test_c5_4k_10bit_clip_properties(gpu_vs):
     assert h2 == has
     d = np.abs(o2[lag].astype(np.int32) - frames[0][32:-32, 32:-32].astype(np.int32))
     assert d.max() <= 1
+
+
+def _device_clips(w, h, n_clips, fpc, seed, bits=8):
+    """n_clips clips back to back in ONE device tensor (the layout vs_aligner_align_clips / vs_stabilizer_process_clips take)"""
+    import torch
+    from video_stabilizer_amd import synth
+    dev = torch.device("cuda", 0)
+    fac = synth.TorchClipFactory(w, h, seed, dev, channels=3, bits=bits)
+    allf = torch.empty((n_clips * fpc, h, w, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
+    for c in range(n_clips):
+        fac.make(fpc, seed + 1000 * c, out=allf[c * fpc:(c + 1) * fpc])
+    torch.cuda.synchronize()
+    return allf
+
+
+def test_c4_one_gpus_share_at_full_size(gpu_vs):
+    """configs[3] as one of 8 GPUs sees it: 8 clips x 120 frames of 1080p, resident in HBM, through ONE
+    vs_aligner_align_clips call.  Size-independent properties: every clip starts with a first frame, every other frame
+    aligns, and a clip's results do not depend on its neighbours -- clips 0, 3 and 7 re-run alone through a fresh aligner
+    give the same transforms bit for bit."""
+    n_clips, fpc, w, h = 8, 120, 1920, 1080
+    allf = _device_clips(w, h, n_clips, fpc, seed=1000)
+    kw = dict(pyramid_min_width=256)
+    al = gpu_vs.Aligner(device=0, **kw)
+    st, ts = al.align_clips(n_clips * fpc, n_clips, mem_ptr=allf.data_ptr(), w=w, h=h, fmt=gpu_vs.FMT_BGR8)
+    assert [st[c * fpc] for c in range(n_clips)] == [0] * n_clips
+    assert sum(st) == n_clips * (fpc - 1)
+    for c in (0, 3, 7):
+        alone = gpu_vs.Aligner(device=0, **kw)
+        s1, t1 = alone.align_batch_device(allf[c * fpc].data_ptr(), fpc, w, h, gpu_vs.FMT_BGR8)
+        assert list(s1) == list(st[c * fpc:(c + 1) * fpc])
+        assert [t.tup() for t in t1] == [t.tup() for t in ts[c * fpc:(c + 1) * fpc]], c
+
+
+def test_c5_one_gpus_share_at_full_size(gpu_vs):
+    """configs[4] as one of 8 GPUs sees it: 8 clips x 60 frames of 4K 10-bit through the full stabilizer loop in ONE
+    vs_stabilizer_process_clips call on device memory (24 GB in, 23 GB out).  Properties: `lag` frames of latency per clip,
+    the 10-bit range is kept, and clip 5 re-run alone through a fresh stabilizer gives the same pixels bit for bit."""
+    import torch
+    n_clips, fpc, w, h, lag, crop = 8, 60, 3840, 2160, 10, 32
+    allf = _device_clips(w, h, n_clips, fpc, seed=2000, bits=10)
+    out = torch.zeros((n_clips * fpc, h - 2 * crop, w - 2 * crop, 3), dtype=torch.int16, device=allf.device)
+    s = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_LANCZOS2, pyramid_min_width=256)
+    r, has = s.process_clips_device(allf.data_ptr(), n_clips, fpc, w, h, gpu_vs.FMT_BGR10, out.data_ptr())
+    assert has == ([0] * lag + [1] * (fpc - lag)) * n_clips and r == n_clips * (fpc - lag)
+    produced = out.view(n_clips, fpc, h - 2 * crop, w - 2 * crop, 3)[:, lag:]
+    assert int(produced.max()) <= 1023 and int(produced.min()) >= 0
+    c = 5
+    alone = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_LANCZOS2, pyramid_min_width=256)
+    out1 = torch.zeros((fpc, h - 2 * crop, w - 2 * crop, 3), dtype=torch.int16, device=allf.device)
+    r1, has1 = alone.process_batch_device(allf[c * fpc].data_ptr(), fpc, w, h, gpu_vs.FMT_BGR10, out1.data_ptr())
+    assert has1 == has[:fpc] and r1 == fpc - lag
+    assert torch.equal(out1[lag:], out[c * fpc + lag:(c + 1) * fpc])
