@@ -166,22 +166,37 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(vs_lbytes p) {
     return __builtin_amdgcn_alignbyte(q[1], q[0], addr & 3u);
 }
 
-// requires w >= 4.  P: const uint8_t* (generic) or vs_gbytes (global)
+// requires w >= 4.  P: const uint8_t* (generic), vs_gbytes (global) or vs_lbytes (LDS).
+// Split in two so that a caller can put the gathers of several points in flight before it consumes the first of them
+// (one workgroup owns a frame pair: nothing else hides the memory latency): lanczos_fetch issues the four row loads,
+// lanczos_finish does the arithmetic.  lanczos_sample_u8_fast = finish(fetch), the same fp32 operations either way.
+struct LanczosFetch {
+    uint32_t r[4];
+    float frx, fry;
+    int ix;
+};
 template <typename P>
-__device__ __forceinline__ float lanczos_sample_u8_fast(P img, int w, int h, int stride, float Wx, float Wy) {
+__device__ __forceinline__ LanczosFetch lanczos_fetch(P img, int w, int h, int stride, float Wx, float Wy) {
+    LanczosFetch f;
     const float flx = floorf(Wx), fly = floorf(Wy);
     const int ix = (int)flx, iy = (int)fly;
-    const f2v fr = {Wx - flx, Wy - fly};
+    f.frx = Wx - flx; f.fry = Wy - fly; f.ix = ix;
+    const int xb = clampi(ix - 1, 0, w - 4);                  // window origin, always inside the row
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++)
+        f.r[ry] = load_u32_unaligned(img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride + xb);
+    return f;
+}
+__device__ __forceinline__ float lanczos_finish(const LanczosFetch& f, int w) {
+    const int ix = f.ix;
+    const f2v fr = {f.frx, f.fry};
     const f2v w0 = lanczos2_pk<true>(f2v{-1.0f, -1.0f} - fr), w1 = lanczos2_pk<false>(f2v{0.0f, 0.0f} - fr),
               w2 = lanczos2_pk<false>(f2v{1.0f, 1.0f} - fr), w3 = lanczos2_pk<true>(f2v{2.0f, 2.0f} - fr);
     const float wx[4] = {w0.x, w1.x, w2.x, w3.x}, wy[4] = {w0.y, w1.y, w2.y, w3.y};
-    const int xb = clampi(ix - 1, 0, w - 4);                  // window origin, always inside the row
-    uint32_t r[4];
-#pragma unroll
-    for (int ry = 0; ry < 4; ry++)
-        r[ry] = load_u32_unaligned(img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride + xb);
+    uint32_t r[4] = {f.r[0], f.r[1], f.r[2], f.r[3]};
     const bool edge = ix < 1 || ix + 2 >= w;
     if (__any(edge)) {                                        // wave-uniform branch
+        const int xb = clampi(ix - 1, 0, w - 4);
         uint32_t sel = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) sel |= (uint32_t)(clampi(ix - 1 + k, 0, w - 1) - xb) << (8 * k);
@@ -200,6 +215,10 @@ __device__ __forceinline__ float lanczos_sample_u8_fast(P img, int w, int h, int
         }
     }
     return num / den;
+}
+template <typename P>
+__device__ __forceinline__ float lanczos_sample_u8_fast(P img, int w, int h, int stride, float Wx, float Wy) {
+    return lanczos_finish(lanczos_fetch(img, w, h, stride, Wx, Wy), w);
 }
 
 // imgproc.cpp:69-75 / 98-103: centre-based double transform -> float kernel arguments.
@@ -297,8 +316,8 @@ __device__ __forceinline__ void block_sum(double v[K], double* lds) {
 }
 
 // first half of block_sum only: per-wave sums parked in LDS (lds[wave*K + k]); the caller puts a barrier behind it
-template <int K>
-__device__ __forceinline__ void wave_partials(const double v[K], double* lds) {
+template <int K, typename LP = double*>
+__device__ __forceinline__ void wave_partials(const double v[K], LP lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; k++) {
