@@ -187,12 +187,36 @@ __device__ __forceinline__ LanczosFetch lanczos_fetch(P img, int w, int h, int s
         f.r[ry] = load_u32_unaligned(img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride + xb);
     return f;
 }
+// the scalar form of lanczos2_pk (same operations per value)
+template <bool EDGE>
+__device__ __forceinline__ float lanczos2_s(float x) {
+    const float x2 = x * x;
+    float v = 0.000858519f;
+    v = -0.0158853f + v * x2;
+    v = 0.128693f + v * x2;
+    v = -0.583468f + v * x2;
+    v = 1.52229f + v * x2;
+    v = -2.05238f + v * x2;
+    v = 0.999861f + v * x2;
+    if (EDGE) v = fabsf(x) >= 2.0f ? 0.0f : v;
+    return v;
+}
+#ifndef VS_SAMPLE_SCALAR_WEIGHTS
+#define VS_SAMPLE_SCALAR_WEIGHTS 0
+#endif
 __device__ __forceinline__ float lanczos_finish(const LanczosFetch& f, int w) {
     const int ix = f.ix;
+#if VS_SAMPLE_SCALAR_WEIGHTS
+    const float wx[4] = {lanczos2_s<true>(-1.0f - f.frx), lanczos2_s<false>(0.0f - f.frx), lanczos2_s<false>(1.0f - f.frx),
+                         lanczos2_s<true>(2.0f - f.frx)};
+    const float wy[4] = {lanczos2_s<true>(-1.0f - f.fry), lanczos2_s<false>(0.0f - f.fry), lanczos2_s<false>(1.0f - f.fry),
+                         lanczos2_s<true>(2.0f - f.fry)};
+#else
     const f2v fr = {f.frx, f.fry};
     const f2v w0 = lanczos2_pk<true>(f2v{-1.0f, -1.0f} - fr), w1 = lanczos2_pk<false>(f2v{0.0f, 0.0f} - fr),
               w2 = lanczos2_pk<false>(f2v{1.0f, 1.0f} - fr), w3 = lanczos2_pk<true>(f2v{2.0f, 2.0f} - fr);
     const float wx[4] = {w0.x, w1.x, w2.x, w3.x}, wy[4] = {w0.y, w1.y, w2.y, w3.y};
+#endif
     uint32_t r[4] = {f.r[0], f.r[1], f.r[2], f.r[3]};
     const bool edge = ix < 1 || ix + 2 >= w;
     if (__any(edge)) {                                        // wave-uniform branch
@@ -326,12 +350,108 @@ __device__ __forceinline__ void wave_partials(const double v[K], LP lds) {
     }
 }
 
+// Eight sums over the wave at once: a butterfly that halves the number of values a lane carries at each of the first three
+// steps (lane pairs at distance 1, 2, 4 exchange the half the partner keeps), then three steps on the one value that is
+// left -- 10 fp64 additions per lane instead of the 48 of eight separate wave_sum trees.  Lanes 0..7 end up holding the
+// totals (lane j the value with index bit-reversed j) and write lds[wave_slot * 8 + index].  The tree is fixed, so the
+// result does not depend on anything but the inputs.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov_keep(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+template <typename LP>
+__device__ __forceinline__ void wave_partials8_butterfly(const double v[8], LP lds, int wave_slot) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double k4[4], k2[2], k1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                               // distance 1: quad_perm [1,0,3,2]
+        const double keep = b0 ? v[4 + i] : v[i], send = b0 ? v[i] : v[4 + i];
+        k4[i] = keep + dpp_mov_keep<0xB1>(send, send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                               // distance 2: quad_perm [2,3,0,1]
+        const double keep = b1 ? k4[2 + i] : k4[i], send = b1 ? k4[i] : k4[2 + i];
+        k2[i] = keep + dpp_mov_keep<0x4E>(send, send);
+    }
+    {                                                           // distance 4: row_shl:4 into banks 0,2; row_shr:4 into banks 1,3
+        const double keep = b2 ? k2[1] : k2[0], send = b2 ? k2[0] : k2[1];
+        double recv = dpp_mov_keep<0x104, 0xf, 0x5>(send, send);
+        recv = dpp_mov_keep<0x114, 0xf, 0xa>(recv, send);
+        k1 = keep + recv;
+    }
+    k1 = k1 + dpp_mov_keep<0x128>(k1, k1);                      // distance 8: row_ror:8
+    {                                                           // distance 16: swizzle, xor 0x10 inside each half
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(k1), (0x10 << 10) | 0x1f);
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(k1), (0x10 << 10) | 0x1f);
+        k1 = k1 + __hiloint2double(hi, lo);
+    }
+    {                                                           // distance 32
+        const int src = (lane ^ 32) << 2;
+        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(k1));
+        const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(k1));
+        k1 = k1 + __hiloint2double(hi, lo);
+    }
+    if (lane < 8) lds[wave_slot * 8 + ((lane & 1) << 2 | (lane & 2) | (lane >> 2))] = k1;
+}
+
 // ---- 4x4 symmetric eigen-solver + conditioned pseudo-inverse --------------------------------
 // alignment.cpp:555-583 uses cv::SVD and Mat::inv(DECOMP_SVD) on the symmetric PSD Hessian.
-// Singular values of such a matrix are its eigenvalues; a cyclic Jacobi sweep (fixed order
-// (0,1),(0,2),(0,3),(1,2),(1,3),(2,3)) delivers them to ~1e-16 relative.
+// Singular values of such a matrix are its eigenvalues; cyclic Jacobi sweeps deliver them to ~1e-16 relative.
+// One wave runs this alone, so the time is the length of the dependent fp64 chain: the six rotations of a sweep are taken in
+// the order (0,1)(2,3) | (0,2)(1,3) | (0,3)(1,2) -- the two rotations of a stage touch disjoint rows and columns, their
+// angles do not depend on each other, and their sqrt / divide / rsqrt chains run interleaved.  (The CPU oracle sweeps
+// (0,1),(0,2),(0,3),(1,2),(1,3),(2,3); both converge to the same eigenvalues, the results differ in the last bits.)
 // Fully unrolled with compile-time indices so that a[][] and V[] live in registers (behind a pointer they would
 // be scratch memory: ~500 cycles per element access).
+struct JacobiRot { double c, s; };
+__device__ __forceinline__ JacobiRot jacobi_rot(double app, double aqq, double apq) {
+    // t = tan of the rotation angle = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq-app)/(2 apq),
+    // written with d = aqq - app so that it costs one sqrt and one divide; c = 1/sqrt(t^2+1) by rsqrt.
+    // apq == 0: the identity (c = 1, s = 0), without a branch.
+    const double d = aqq - app;
+    const double r = sqrt(d * d + 4.0 * apq * apq);
+    // (the divide runs unconditionally, on 0 / 1 when apq == 0: a select around it would become a branch and keep the two
+    // rotations of a stage from interleaving)
+    const double den = apq == 0.0 ? 1.0 : fabs(d) + r;
+    const double tt = (d >= 0.0 ? 2.0 * apq : -2.0 * apq) / den;
+    JacobiRot R;
+    R.c = rsqrt(tt * tt + 1.0);
+    R.s = tt * R.c;
+    return R;
+}
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_apply_cols(double a[4][4], double* V, const JacobiRot& R) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double akp = a[k][P], akq = a[k][Q];
+        a[k][P] = R.c * akp - R.s * akq; a[k][Q] = R.s * akp + R.c * akq;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double vkp = V[k * 4 + P], vkq = V[k * 4 + Q];
+        V[k * 4 + P] = R.c * vkp - R.s * vkq; V[k * 4 + Q] = R.s * vkp + R.c * vkq;
+    }
+}
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_apply_rows(double a[4][4], const JacobiRot& R) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double apk = a[P][k], aqk = a[Q][k];
+        a[P][k] = R.c * apk - R.s * aqk; a[Q][k] = R.s * apk + R.c * aqk;
+    }
+}
+// rotations (P1,Q1) and (P2,Q2), {P1,Q1} and {P2,Q2} disjoint: the same operations, element by element, as one after the other
+template <int P1, int Q1, int P2, int Q2>
+__device__ __forceinline__ void jacobi_stage(double a[4][4], double* V) {
+    const JacobiRot R1 = jacobi_rot(a[P1][P1], a[Q1][Q1], a[P1][Q1]), R2 = jacobi_rot(a[P2][P2], a[Q2][Q2], a[P2][Q2]);
+    jacobi_apply_cols<P1, Q1>(a, V, R1);
+    jacobi_apply_cols<P2, Q2>(a, V, R2);
+    jacobi_apply_rows<P1, Q1>(a, R1);
+    jacobi_apply_rows<P2, Q2>(a, R2);
+}
 __device__ __forceinline__ void jacobi_eig4(const double* Hin, double* eval, double* V) {
     double a[4][4];
 #pragma unroll
@@ -347,43 +467,20 @@ __device__ __forceinline__ void jacobi_eig4(const double* Hin, double* eval, dou
             for (int j = i + 1; j < 4; j++) off += a[i][j] * a[i][j];
         }
         if (off <= 1e-300 || off <= 1e-32 * diag) break;   // off-diagonal mass below 1e-16 of the diagonal's
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-#pragma unroll
-            for (int q = p + 1; q < 4; q++) {
-                double apq = a[p][q];
-                if (apq == 0.0) continue;
-                // t = tan of the rotation angle = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq-app)/(2 apq),
-                // written with d = aqq - app so that it costs one sqrt and one divide; c = 1/sqrt(t^2+1) by rsqrt
-                const double d = a[q][q] - a[p][p];
-                const double r = sqrt(d * d + 4.0 * apq * apq);
-                const double tt = (d >= 0.0 ? 2.0 * apq : -2.0 * apq) / (fabs(d) + r);
-                const double c = rsqrt(tt * tt + 1.0), s = tt * c;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    double akp = a[k][p], akq = a[k][q];
-                    a[k][p] = c * akp - s * akq; a[k][q] = s * akp + c * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    double apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = c * apk - s * aqk; a[q][k] = s * apk + c * aqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    double vkp = V[k * 4 + p], vkq = V[k * 4 + q];
-                    V[k * 4 + p] = c * vkp - s * vkq; V[k * 4 + q] = s * vkp + c * vkq;
-                }
-            }
-        }
+        jacobi_stage<0, 1, 2, 3>(a, V);
+        jacobi_stage<0, 2, 1, 3>(a, V);
+        jacobi_stage<0, 3, 1, 2>(a, V);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) eval[i] = a[i][i];
 }
 
+#ifndef VS_COND_INLINE
+#define VS_COND_INLINE __noinline__
+#endif
 // cond = smax/(smin+1e-10); cond > 1e6 => H += 1e-6*smax*I (alignment.cpp:561-572);
 // Hinv = V diag(1/w) V^T dropping w <= 2*eps*sum(w) (OpenCV's DECOMP_SVD back-substitution).
-__device__ __noinline__ double condition_and_invert(double* Hio, double* Hinv_out) {
+__device__ VS_COND_INLINE double condition_and_invert(double* Hio, double* Hinv_out) {
     double H[16], Hinv[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) H[i] = Hio[i];
@@ -403,15 +500,20 @@ __device__ __noinline__ double condition_and_invert(double* Hio, double* Hinv_ou
 #pragma unroll
     for (int i = 0; i < 4; i++) sum += fabs(ev[i]);
     double thresh = 2.0 * 2.220446049250313e-16 * sum;
+    // one reciprocal per eigenvalue (as OpenCV's own back-substitution does: wi = 1 / wi) and the upper triangle only --
+    // sixty-four fp64 divisions on one wave were a third of this function's time
+    double inv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) inv[k] = fabs(ev[k]) > thresh ? 1.0 / ev[k] : 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = r; c < 4; c++) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (fabs(ev[k]) > thresh) s += V[r * 4 + k] * V[c * 4 + k] / ev[k];
+            for (int k = 0; k < 4; k++) s += V[r * 4 + k] * V[c * 4 + k] * inv[k];
             Hinv[r * 4 + c] = s;
+            Hinv[c * 4 + r] = s;
         }
 #pragma unroll
     for (int i = 0; i < 16; i++) { Hio[i] = H[i]; Hinv_out[i] = Hinv[i]; }
