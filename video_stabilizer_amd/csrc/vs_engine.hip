@@ -71,6 +71,7 @@ struct PairDesc {
 struct GnParams {
     double threshold, max_displacement;
     int max_iters;
+    int pipeline;   // 1: the one-barrier iteration loop on the LDS-resident level (latency mode, few pairs in flight)
 };
 
 // ---- phase-correlation start value (alignment.cpp:376-387) -----------------------------------------
@@ -202,7 +203,8 @@ constexpr int kGnThreads = VS_NT_SMALL;
 #ifndef VS_SMALL_WG_TILES
 #define VS_SMALL_WG_TILES 26000
 #endif
-constexpr int kSmallWgTiles = VS_SMALL_WG_TILES;   // largest level handled by the 512-thread kernels (<= kSelectCap <= 64 * 512)
+constexpr int kSmallWgTiles = VS_SMALL_WG_TILES;
+constexpr int kPipelineMaxPairs = 128;   // half the CUs   // largest level handled by the 512-thread kernels (<= kSelectCap <= 64 * 512)
 
 }  // namespace
 
@@ -634,7 +636,11 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         VS_HIP(hipStreamSynchronize(s));   // hd, hp, hneg go out of use; also orders the pinned h_states reuse below
 
         const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 24;
-        GnParams gp{p.threshold, p.max_displacement, p.max_iters};
+        // The pipelined iteration loop shortens one pair's critical path at the price of a speculative sampling pass per level:
+        // worth it while the launch does not fill the chip (the results are bit-identical either way).
+        static const int pipe_env = []() { const char* e = getenv("VS_GN_PIPELINE"); return e ? atoi(e) : -1; }();
+        const int pipeline = pipe_env >= 0 ? pipe_env : (n_pairs <= kPipelineMaxPairs ? 1 : 0);
+        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline};
         bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
         if (!use_host) {
             // VS_SELECT_DEVICE: every level of every pair in one launch (selection = on-device introselect)
