@@ -177,6 +177,37 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
     write_rec(pair_recs(recs, recs_pair, p, nt_cap), set * nsel + j, lm, jac, nt, t, tmpl, w, h);
 }
 
+// ---- helper workgroups (latency mode) -------------------------------------------------------------------
+// When only a few pairs are in flight, a pair is launched as kCoopGroup workgroups: the leader runs the algorithm as
+// always, the others take slices of the one embarrassingly parallel pass of the large levels -- sparse_warpdiff of every
+// tile (generators.cpp:646-700), which on one CU is bound by that CU's L1 fill rate (every 4-byte window pulls a
+// 128-byte line).  The pass is exact per point and every sum stays with the leader, so the results are bit-identical to
+// the one-workgroup launch.
+// Protocol (one CoopCtrl per pair in device memory, zeroed at allocation; every launch has a new `epoch`, flags hold the
+// epoch they were raised in, so nothing is ever reset): helper g raises arrived[g]; at a shared level the leader hands
+// slices to the helpers that have arrived BY THEN (assign[g], nslices, T, then t_ready) and never waits for one that has
+// not; a helper writes the packed keys of its slice and raises wd_done[g]; the leader reads all keys into LDS and goes on
+// alone.  `abort` releases helpers when the pair ends early.  All waits are bounded.
+constexpr int kCoopGroup = 16;         // workgroups per pair in latency mode (1080p: 8 and 16 alike; 4K: 16 is 3 % faster)
+constexpr int kCoopMaxGroup = 16;
+constexpr int kCoopMaxPairs = 16;      // latency mode for launches of at most this many pairs
+constexpr int kCoopMinTiles = 4096;    // levels with at least this many tiles are shared
+struct CoopLevel {
+    int t_ready, nslices, pad[2];
+    int assign[kCoopMaxGroup];         // slice number of helper g at this level, -1: not taking part
+    int wd_done[kCoopMaxGroup];
+    double T[4];                       // the transform the level starts from
+};
+struct CoopCtrl {
+    int arrived[kCoopMaxGroup];
+    int abort;
+    int pad[15];
+    CoopLevel lv[kMaxLevels];
+};
+constexpr size_t kCoopCtrlBytes = (sizeof(CoopCtrl) + 255) & ~(size_t)255;
+// per pair: CoopCtrl | u32 keys[2 * nt_cap] (sparse_warpdiff, packed for the selection)
+__host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrlBytes + (((size_t)nt_cap * 8 + 255) & ~(size_t)255); }
+
 // ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
 struct FusedLevels {
     int levels;
@@ -258,6 +289,8 @@ struct vs_aligner {
     uint16_t* wd = nullptr;
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
+    uint8_t* coop = nullptr;      // helper-workgroup control blocks + exchange buffers (kCoopMaxPairs pairs), see CoopCtrl
+    int coop_epoch = 0;
     void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area (single chunk)
     // host-resident video: two upload areas filled alternately by an uploader thread on its own stream, so the
     // upload of chunk c+1 runs under the pipeline of chunk c (alignment.cpp:210-218: every frame arrives as a host cv::Mat)
@@ -359,13 +392,13 @@ int vs_aligner::ensure_phase() {
 
 void vs_aligner::release() {
     release_phase();
-    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, stage, ingest[0], ingest[1]};
+    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, coop, stage, ingest[0], ingest[1]};
     for (void* p : d) if (p) (void)hipFree(p);
     ingest[0] = ingest[1] = nullptr; ingest_bytes = 0;
     void* hp[] = {h_wd, h_idx, h_states};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; idx = nullptr;
-    recs = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
+    recs = nullptr; coop = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
     cap = 0;
 }
 
@@ -426,7 +459,7 @@ int vs_aligner::ensure_capacity(int n) {
         VS_HIP(hipStreamSynchronize(stream));
         last_n = 0;   // carry-over now lives in slot 0 of the new slabs
     }
-    void* old[] = {pyr, lm, jac, states, descs, wd, idx, recs};
+    void* old[] = {pyr, lm, jac, states, descs, wd, idx, recs, coop};
     for (void* p : old) if (p) (void)hipFree(p);
     void* oldh[] = {h_wd, h_idx, h_states};
     for (void* p : oldh) if (p) (void)hipHostFree(p);
@@ -436,6 +469,9 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
     VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 24));
+    VS_HIP(hipMalloc((void**)&coop, kCoopMaxPairs * coop_pair_bytes(nt_max)));
+    VS_HIP(hipMemset(coop, 0, kCoopMaxPairs * coop_pair_bytes(nt_max)));
+    coop_epoch = 0;
     VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
     VS_HIP(hipHostMalloc((void**)&h_states, sizeof(PairState) * newcap));
@@ -663,14 +699,19 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
             VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             t_begin(VS_STAGE_GN);
-            hipLaunchKernelGGL(kernel, dim3(n_pairs), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, states, descs,
-                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp);
+            // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
+            static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
+            int group = 1;
+            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles) group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : kCoopGroup;
+            const int epoch = ++coop_epoch;
+            hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, states, descs,
+                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp, group, coop, epoch);
             VS_HIP(hipGetLastError());
             t_end(1);
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
             VS_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < n_pairs; q++)
-                if (h_states[q].fail_reason == 100) use_host = true;   // libstdc++ would have heap-selected: redo on the host
+                if (h_states[q].fail_reason >= 100) use_host = true;   // 100: libstdc++ would have heap-selected; 101: a helper workgroup timed out -- redo on the host
             if (use_host) {
                 for (int q = 0; q < n_pairs; q++) { memset(&h_states[q], 0, sizeof(PairState)); h_states[q].status = 1; }
                 VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
