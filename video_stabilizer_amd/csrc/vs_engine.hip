@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __re
                                                            size_t img_off, int w, int h,
                                                            const uint16_t* __restrict__ lm_tab, size_t lm_frame,
                                                            size_t lm_off, int nt, uint16_t* __restrict__ wd,
-                                                           size_t wd_pair) {
+                                                           float* __restrict__ wv, size_t wd_pair) {
     const int p = blockIdx.y, set = blockIdx.z;
     const PairState& st = states[p];
     if (st.status != 1) return;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __re
     float diff = fabsf(v - (float)tmpl[(size_t)tile_y * w + tile_x]);
     diff = fminf(fmaxf(diff, 0.0f), 65535.0f);
     wd[(size_t)p * wd_pair + (size_t)set * nt + i] = (uint16_t)diff;
+    wv[(size_t)p * wd_pair + (size_t)set * nt + i] = v;   // the first Gauss-Newton iteration samples the same point (PointRecs::r0)
 }
 
 // ---- gather of the selected keypoints + Jacobians: alignment.cpp:523-546 ------------------------
@@ -134,10 +135,15 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
+//   r0  f32    tv - (the key frame sampled at the point warped by the transform the level STARTS from): the residual of the
+//              first Gauss-Newton iteration.  sparse_warpdiff (generators.cpp:672-697) has just computed exactly that sample
+//              for every tile -- same image, same fp32 kernel parameters, same point -- so the first sparse_ica pass
+//              (generators.cpp:469-498) takes it from here instead of sampling again; the value is the same bit for bit.
 struct PointRecs {
     uint32_t* xy;
     float* tv;
     float4* j;
+    float* r0;
 };
 __device__ __forceinline__ PointRecs pair_recs(uint8_t* recs, size_t recs_pair, int p, int nt_cap) {
     uint8_t* base = recs + (size_t)p * recs_pair;
@@ -145,14 +151,17 @@ __device__ __forceinline__ PointRecs pair_recs(uint8_t* recs, size_t recs_pair, 
     r.j = (float4*)base;                                      // 2*nt_cap float4
     r.xy = (uint32_t*)(base + (size_t)2 * nt_cap * 16);       // 2*nt_cap u32
     r.tv = (float*)(base + (size_t)2 * nt_cap * 20);          // 2*nt_cap f32
+    r.r0 = (float*)(base + (size_t)2 * nt_cap * 24);          // 2*nt_cap f32
     return r;
 }
 __device__ __forceinline__ void write_rec(const PointRecs& rc, int slot, const uint16_t* __restrict__ lm,
                                           const float* __restrict__ jac, int nt, int t, const uint8_t* __restrict__ tmpl,
-                                          int w, int h) {
+                                          int w, int h, const float* __restrict__ wv_set) {
     const int px = lm[t], py = lm[nt + t];
     rc.xy[slot] = (uint32_t)px | ((uint32_t)py << 16);
-    rc.tv[slot] = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
+    const float tv = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
+    rc.tv[slot] = tv;
+    rc.r0[slot] = tv - wv_set[t];
     rc.j[slot] = make_float4(jac[t], jac[(size_t)nt + t], jac[2 * (size_t)nt + t], jac[3 * (size_t)nt + t]);
 }
 
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
                                                             size_t lm_off, const float* __restrict__ jac_tab,
                                                             size_t jac_frame, size_t jac_off, int nt, int nsel,
                                                             const int32_t* __restrict__ idx, size_t idx_pair,
+                                                            const float* __restrict__ wv,
                                                             uint8_t* __restrict__ recs, size_t recs_pair, int nt_cap) {
     const int p = blockIdx.y, set = blockIdx.z;
     if (states[p].status != 1) return;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
     const float* jac = jac_tab + (size_t)d.key_slot * jac_frame + jac_off + (size_t)set * 4 * nt;
     const uint8_t* tmpl = pyr + (size_t)d.tmpl_slot * pyr_frame + img_off;
     const int t = idx[(size_t)p * idx_pair + (size_t)set * nt + j];
-    write_rec(pair_recs(recs, recs_pair, p, nt_cap), set * nsel + j, lm, jac, nt, t, tmpl, w, h);
+    write_rec(pair_recs(recs, recs_pair, p, nt_cap), set * nsel + j, lm, jac, nt, t, tmpl, w, h, wv + (size_t)p * idx_pair + (size_t)set * nt);
 }
 
 // ---- helper workgroups (latency mode) -------------------------------------------------------------------
@@ -205,8 +215,9 @@ struct CoopCtrl {
     CoopLevel lv[kMaxLevels];
 };
 constexpr size_t kCoopCtrlBytes = (sizeof(CoopCtrl) + 255) & ~(size_t)255;
-// per pair: CoopCtrl | u32 keys[2 * nt_cap] (sparse_warpdiff, packed for the selection)
-__host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrlBytes + (((size_t)nt_cap * 8 + 255) & ~(size_t)255); }
+// per pair: CoopCtrl | u32 keys[2 * nt_cap] (sparse_warpdiff, packed for the selection) | f32 values[2 * nt_cap] (the samples);
+// these two arrays are only ever touched with sc1 stores and sc1 loads (a line one XCD's L2 kept from a plain access would go stale)
+__host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrlBytes + (((size_t)nt_cap * 16 + 255) & ~(size_t)255); }
 
 // ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
 struct FusedLevels {
@@ -287,6 +298,7 @@ struct vs_aligner {
     PairState* states = nullptr;
     PairDesc* descs = nullptr;
     uint16_t* wd = nullptr;
+    float* wv = nullptr;          // per pair: the 2*nt_max sparse_warpdiff samples of the current level (-> PointRecs::r0)
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
     uint8_t* coop = nullptr;      // helper-workgroup control blocks + exchange buffers (kCoopMaxPairs pairs), see CoopCtrl
@@ -392,12 +404,12 @@ int vs_aligner::ensure_phase() {
 
 void vs_aligner::release() {
     release_phase();
-    void* d[] = {pyr, lm, jac, states, descs, wd, idx, recs, coop, stage, ingest[0], ingest[1]};
+    void* d[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop, stage, ingest[0], ingest[1]};
     for (void* p : d) if (p) (void)hipFree(p);
     ingest[0] = ingest[1] = nullptr; ingest_bytes = 0;
     void* hp[] = {h_wd, h_idx, h_states};
     for (void* p : hp) if (p) (void)hipHostFree(p);
-    pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; idx = nullptr;
+    pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; wv = nullptr; idx = nullptr;
     recs = nullptr; coop = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
     cap = 0;
 }
@@ -459,7 +471,7 @@ int vs_aligner::ensure_capacity(int n) {
         VS_HIP(hipStreamSynchronize(stream));
         last_n = 0;   // carry-over now lives in slot 0 of the new slabs
     }
-    void* old[] = {pyr, lm, jac, states, descs, wd, idx, recs, coop};
+    void* old[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop};
     for (void* p : old) if (p) (void)hipFree(p);
     void* oldh[] = {h_wd, h_idx, h_states};
     for (void* p : oldh) if (p) (void)hipHostFree(p);
@@ -468,7 +480,8 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipMalloc((void**)&descs, sizeof(PairDesc) * newcap));
     VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
-    VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 24));
+    VS_HIP(hipMalloc((void**)&wv, (size_t)newcap * 2 * nt_max * sizeof(float)));
+    VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 28));
     VS_HIP(hipMalloc((void**)&coop, kCoopMaxPairs * coop_pair_bytes(nt_max)));
     VS_HIP(hipMemset(coop, 0, kCoopMaxPairs * coop_pair_bytes(nt_max)));
     coop_epoch = 0;
@@ -671,7 +684,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         }
         VS_HIP(hipStreamSynchronize(s));   // hd, hp, hneg go out of use; also orders the pinned h_states reuse below
 
-        const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 24;
+        const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 28;
         // The pipelined iteration loop shortens one pair's critical path at the price of a speculative sampling pass per level:
         // worth it while the launch does not fill the chip (the results are bit-identical either way).
         static const int pipe_env = []() { const char* e = getenv("VS_GN_PIPELINE"); return e ? atoi(e) : -1; }();
@@ -705,7 +718,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles) group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : kCoopGroup;
             const int epoch = ++coop_epoch;
             hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, states, descs,
-                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp, group, coop, epoch);
+                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp, group, coop, epoch, wv);
             VS_HIP(hipGetLastError());
             t_end(1);
             VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
@@ -723,7 +736,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             const LevelDims& ld = L[l];
             t_begin(VS_STAGE_WARPDIFF);
             hipLaunchKernelGGL(vs_k_warpdiff_batch, dim3((ld.nt + 255) / 256, n_pairs, 2), dim3(256), 0, s, states, descs, pyr,
-                               pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, ld.nt, wd, wd_pair);
+                               pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, ld.nt, wd, wv, wd_pair);
             VS_HIP(hipGetLastError());
             t_end(1);
             {
@@ -739,7 +752,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 t_begin(VS_STAGE_GATHER);
                 hipLaunchKernelGGL(vs_k_gather_selected, dim3((ld.nsel + 255) / 256, n_pairs, 2), dim3(256), 0, s, states,
                                    descs, pyr, pyr_frame, ld.img_off, ld.w, ld.h, lm, lm_frame, ld.lm_off, jac, jac_frame,
-                                   ld.jac_off, ld.nt, ld.nsel, idx, wd_pair, recs, recs_pair, nt_max);
+                                   ld.jac_off, ld.nt, ld.nsel, idx, wd_pair, wv, recs, recs_pair, nt_max);
                 VS_HIP(hipGetLastError());
                 t_end(1);
             }
