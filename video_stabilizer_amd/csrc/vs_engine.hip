@@ -322,6 +322,7 @@ struct vs_aligner {
     uint16_t* h_wd = nullptr;
     int32_t* h_idx = nullptr;
     PairState* h_states = nullptr;
+    PairDesc* h_descs = nullptr;   // pinned: the descriptor upload needs no host synchronisation before the launch
 
     std::vector<vs_align_info> info;   // last call
     int last_n = 0;
@@ -407,10 +408,10 @@ void vs_aligner::release() {
     void* d[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop, stage, ingest[0], ingest[1]};
     for (void* p : d) if (p) (void)hipFree(p);
     ingest[0] = ingest[1] = nullptr; ingest_bytes = 0;
-    void* hp[] = {h_wd, h_idx, h_states};
+    void* hp[] = {h_wd, h_idx, h_states, h_descs};
     for (void* p : hp) if (p) (void)hipHostFree(p);
     pyr = nullptr; lm = nullptr; jac = nullptr; states = nullptr; descs = nullptr; wd = nullptr; wv = nullptr; idx = nullptr;
-    recs = nullptr; coop = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr;
+    recs = nullptr; coop = nullptr; stage = nullptr; stage_bytes = 0; h_wd = nullptr; h_idx = nullptr; h_states = nullptr; h_descs = nullptr;
     cap = 0;
 }
 
@@ -473,7 +474,7 @@ int vs_aligner::ensure_capacity(int n) {
     }
     void* old[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop};
     for (void* p : old) if (p) (void)hipFree(p);
-    void* oldh[] = {h_wd, h_idx, h_states};
+    void* oldh[] = {h_wd, h_idx, h_states, h_descs};
     for (void* p : oldh) if (p) (void)hipHostFree(p);
     pyr = npyr; lm = nlm; jac = njac;
     VS_HIP(hipMalloc((void**)&states, sizeof(PairState) * newcap));
@@ -488,6 +489,7 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
     VS_HIP(hipHostMalloc((void**)&h_states, sizeof(PairState) * newcap));
+    VS_HIP(hipHostMalloc((void**)&h_descs, sizeof(PairDesc) * newcap));
     cap = newcap;
     return VS_OK;
 }
@@ -643,7 +645,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
     }
     const int n_pairs = (int)pair_frame.size();
     if (n_pairs > 0) {
-        std::vector<PairDesc> hd(n_pairs);
+        PairDesc* hd = h_descs;
         for (int q = 0; q < n_pairs; q++) {
             const int i = pair_frame[q];
             const int cur = i + 1, prev = i;
@@ -654,7 +656,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             memset(&h_states[q], 0, sizeof(PairState));
             h_states[q].status = 1;
         }
-        VS_HIP(hipMemcpyAsync(descs, hd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
+        VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
         VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
         // alignment.cpp:369-388: cv::phaseCorrelate(PhaseImage[Prev], PhaseImage[Curr]) starts TX,TY of every pair
         std::vector<vsp::Pair> hp;
@@ -682,7 +684,9 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             h_pres.resize(n_pairs);
             VS_HIP(hipMemcpyAsync(h_pres.data(), pres, sizeof(vsp::Result) * n_pairs, hipMemcpyDeviceToHost, s));
         }
-        VS_HIP(hipStreamSynchronize(s));   // hd, hp, hneg go out of use; also orders the pinned h_states reuse below
+        // (the descriptors and the start states come from pinned memory that is not touched again before the final
+        // synchronisation of this call: no host synchronisation in front of the launch -- it would expose the launch latency)
+        if (p.phase_correlate) VS_HIP(hipStreamSynchronize(s));   // hp, hneg go out of use
 
         const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 28;
         // The pipelined iteration loop shortens one pair's critical path at the price of a speculative sampling pass per level:
