@@ -406,7 +406,7 @@ __device__ __forceinline__ void wave_partials8_butterfly(const double v[8], LP l
 // (0,1),(0,2),(0,3),(1,2),(1,3),(2,3); both converge to the same eigenvalues, the results differ in the last bits.)
 // Fully unrolled with compile-time indices so that a[][] and V[] live in registers (behind a pointer they would
 // be scratch memory: ~500 cycles per element access).
-struct JacobiRot { double c, s; };
+struct JacobiRot { double c, s, t; };
 __device__ __forceinline__ JacobiRot jacobi_rot(double app, double aqq, double apq) {
     // t = tan of the rotation angle = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq-app)/(2 apq),
     // written with d = aqq - app so that it costs one sqrt and one divide; c = 1/sqrt(t^2+1) by rsqrt.
@@ -416,41 +416,44 @@ __device__ __forceinline__ JacobiRot jacobi_rot(double app, double aqq, double a
     // (the divide runs unconditionally, on 0 / 1 when apq == 0: a select around it would become a branch and keep the two
     // rotations of a stage from interleaving)
     const double den = apq == 0.0 ? 1.0 : fabs(d) + r;
-    const double tt = (d >= 0.0 ? 2.0 * apq : -2.0 * apq) / den;
     JacobiRot R;
-    R.c = rsqrt(tt * tt + 1.0);
-    R.s = tt * R.c;
+    R.t = (d >= 0.0 ? 2.0 * apq : -2.0 * apq) / den;
+    R.c = rsqrt(R.t * R.t + 1.0);
+    R.s = R.t * R.c;
     return R;
 }
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_apply_cols(double a[4][4], double* V, const JacobiRot& R) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double akp = a[k][P], akq = a[k][Q];
-        a[k][P] = R.c * akp - R.s * akq; a[k][Q] = R.s * akp + R.c * akq;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double vkp = V[k * 4 + P], vkq = V[k * 4 + Q];
-        V[k * 4 + P] = R.c * vkp - R.s * vkq; V[k * 4 + Q] = R.s * vkp + R.c * vkq;
-    }
-}
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_apply_rows(double a[4][4], const JacobiRot& R) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double apk = a[P][k], aqk = a[Q][k];
-        a[P][k] = R.c * apk - R.s * aqk; a[Q][k] = R.s * apk + R.c * aqk;
-    }
-}
-// rotations (P1,Q1) and (P2,Q2), {P1,Q1} and {P2,Q2} disjoint: the same operations, element by element, as one after the other
+// Rotations (P1,Q1) and (P2,Q2), {P1,Q1} and {P2,Q2} disjoint, on the symmetric matrix a (both halves kept): the 2x2
+// diagonal blocks by the closed form (app - t apq, aqq + t apq, 0), the 2x2 cross block as R1^T B R2, V's four columns --
+// 78 multiply-adds where two full two-sided products take 144.
 template <int P1, int Q1, int P2, int Q2>
 __device__ __forceinline__ void jacobi_stage(double a[4][4], double* V) {
     const JacobiRot R1 = jacobi_rot(a[P1][P1], a[Q1][Q1], a[P1][Q1]), R2 = jacobi_rot(a[P2][P2], a[Q2][Q2], a[P2][Q2]);
-    jacobi_apply_cols<P1, Q1>(a, V, R1);
-    jacobi_apply_cols<P2, Q2>(a, V, R2);
-    jacobi_apply_rows<P1, Q1>(a, R1);
-    jacobi_apply_rows<P2, Q2>(a, R2);
+    {
+        const double x1 = R1.t * a[P1][Q1], x2 = R2.t * a[P2][Q2];
+        a[P1][P1] = a[P1][P1] - x1; a[Q1][Q1] = a[Q1][Q1] + x1; a[P1][Q1] = 0.0; a[Q1][P1] = 0.0;
+        a[P2][P2] = a[P2][P2] - x2; a[Q2][Q2] = a[Q2][Q2] + x2; a[P2][Q2] = 0.0; a[Q2][P2] = 0.0;
+    }
+    // cross block: rows P1,Q1 x columns P2,Q2
+    double bpp = a[P1][P2], bpq = a[P1][Q2], bqp = a[Q1][P2], bqq = a[Q1][Q2];
+    {   // rows by R1
+        const double n_pp = R1.c * bpp - R1.s * bqp, n_qp = R1.s * bpp + R1.c * bqp;
+        const double n_pq = R1.c * bpq - R1.s * bqq, n_qq = R1.s * bpq + R1.c * bqq;
+        bpp = n_pp; bqp = n_qp; bpq = n_pq; bqq = n_qq;
+    }
+    {   // columns by R2
+        const double n_pp = R2.c * bpp - R2.s * bpq, n_pq = R2.s * bpp + R2.c * bpq;
+        const double n_qp = R2.c * bqp - R2.s * bqq, n_qq = R2.s * bqp + R2.c * bqq;
+        bpp = n_pp; bpq = n_pq; bqp = n_qp; bqq = n_qq;
+    }
+    a[P1][P2] = bpp; a[P2][P1] = bpp; a[P1][Q2] = bpq; a[Q2][P1] = bpq;
+    a[Q1][P2] = bqp; a[P2][Q1] = bqp; a[Q1][Q2] = bqq; a[Q2][Q1] = bqq;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double vkp = V[k * 4 + P1], vkq = V[k * 4 + Q1];
+        V[k * 4 + P1] = R1.c * vkp - R1.s * vkq; V[k * 4 + Q1] = R1.s * vkp + R1.c * vkq;
+        const double wkp = V[k * 4 + P2], wkq = V[k * 4 + Q2];
+        V[k * 4 + P2] = R2.c * wkp - R2.s * wkq; V[k * 4 + Q2] = R2.s * wkp + R2.c * wkq;
+    }
 }
 __device__ __forceinline__ void jacobi_eig4(const double* Hin, double* eval, double* V) {
     double a[4][4];
@@ -476,7 +479,7 @@ __device__ __forceinline__ void jacobi_eig4(const double* Hin, double* eval, dou
 }
 
 #ifndef VS_COND_INLINE
-#define VS_COND_INLINE __noinline__
+#define VS_COND_INLINE __forceinline__   // (out of line its 32 doubles travel through scratch memory)
 #endif
 // cond = smax/(smin+1e-10); cond > 1e6 => H += 1e-6*smax*I (alignment.cpp:561-572);
 // Hinv = V diag(1/w) V^T dropping w <= 2*eps*sum(w) (OpenCV's DECOMP_SVD back-substitution).
