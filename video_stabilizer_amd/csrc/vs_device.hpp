@@ -184,7 +184,8 @@ __device__ __forceinline__ LanczosFetch lanczos_fetch(P img, int w, int h, int s
     const int xb = clampi(ix - 1, 0, w - 4);                  // window origin, always inside the row
 #pragma unroll
     for (int ry = 0; ry < 4; ry++)
-        f.r[ry] = load_u32_unaligned(img + (size_t)clampi(iy + ry - 1, 0, h - 1) * stride + xb);
+        f.r[ry] = load_u32_unaligned(img + (__mul24(clampi(iy + ry - 1, 0, h - 1), stride) + xb));   // (a level image is far below 2^31 bytes,
+                                                                                                        // rows and stride below 2^24: no 64-bit multiply)
     return f;
 }
 // the scalar form of lanczos2_pk (same operations per value)

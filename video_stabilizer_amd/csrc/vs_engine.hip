@@ -215,9 +215,10 @@ struct CoopCtrl {
     CoopLevel lv[kMaxLevels];
 };
 constexpr size_t kCoopCtrlBytes = (sizeof(CoopCtrl) + 255) & ~(size_t)255;
-// per pair: CoopCtrl | u32 keys[2 * nt_cap] (sparse_warpdiff, packed for the selection) | f32 values[2 * nt_cap] (the samples);
-// these two arrays are only ever touched with sc1 stores and sc1 loads (a line one XCD's L2 kept from a plain access would go stale)
-__host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrlBytes + (((size_t)nt_cap * 16 + 255) & ~(size_t)255); }
+// per pair: CoopCtrl | u32 keys[2 * nt_cap] (sparse_warpdiff, packed for the selection) | f32 values[2 * nt_cap] (the samples) |
+// f32 template pixels[2 * nt_cap];
+// these arrays are only ever touched with sc1 stores and sc1 loads (a line one XCD's L2 kept from a plain access would go stale)
+__host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrlBytes + (((size_t)nt_cap * 24 + 255) & ~(size_t)255); }
 
 // ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
 struct FusedLevels {
@@ -298,7 +299,7 @@ struct vs_aligner {
     PairState* states = nullptr;
     PairDesc* descs = nullptr;
     uint16_t* wd = nullptr;
-    float* wv = nullptr;          // per pair: the 2*nt_max sparse_warpdiff samples of the current level (-> PointRecs::r0)
+    float* wv = nullptr;          // per pair: the 2*nt_max sparse_warpdiff samples of the current level (-> PointRecs::r0); fused kernel: + the template pixels
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
     uint8_t* coop = nullptr;      // helper-workgroup control blocks + exchange buffers (kCoopMaxPairs pairs), see CoopCtrl
@@ -481,7 +482,7 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipMalloc((void**)&descs, sizeof(PairDesc) * newcap));
     VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
-    VS_HIP(hipMalloc((void**)&wv, (size_t)newcap * 2 * nt_max * sizeof(float)));
+    VS_HIP(hipMalloc((void**)&wv, (size_t)newcap * 2 * nt_max * sizeof(float) * 2));   // samples of all pairs, then template pixels
     VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 28));
     VS_HIP(hipMalloc((void**)&coop, kCoopMaxPairs * coop_pair_bytes(nt_max)));
     VS_HIP(hipMemset(coop, 0, kCoopMaxPairs * coop_pair_bytes(nt_max)));
