@@ -712,6 +712,9 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             {
                 const size_t img_bytes = (size_t)L[levels - 1].w * L[levels - 1].h + 8;     // the coarsest level
                 if (img_bytes <= 150 * 1024) dyn = std::max(dyn, (img_bytes + 15) & ~(size_t)15);
+                // ... and its selection arrays behind the image, so that the level's sparse_warpdiff samples from LDS too
+                const size_t both = ((img_bytes + 15) & ~(size_t)15) + (size_t)L[levels - 1].nt * 12;
+                if (both <= 150 * 1024) dyn = std::max(dyn, (both + 15) & ~(size_t)15);
             }
             const bool small_wg = nt_max <= kSmallWgTiles;
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
