@@ -1,0 +1,78 @@
+"""Latency mode of the fused aligner kernel (few pairs in flight): the pipelined one-barrier Gauss-Newton loop on the
+LDS-resident level and the helper workgroups that share the sparse_warpdiff pass of the large levels must not change a
+bit of the result.  The switches are read once per process (VS_GN_PIPELINE, VS_GN_HELPERS), so every configuration runs in
+a process of its own; the frames come from the same seeded generator.
+
+  plain    VS_GN_PIPELINE=0 VS_GN_HELPERS=1   one workgroup per pair, two-barrier loop (what a full batch runs)
+  default  (unset)                             pipelined loop + 16 workgroups per pair for <= 16 pairs
+  few      VS_GN_HELPERS=2 / 3                 few, large slices: several staging passes per helper
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import torch                      # before the library: one HIP runtime per process (tests/conftest.py)
+torch.cuda.init()
+from video_stabilizer_amd import capi, synth
+w, h, n, batch = (int(a) for a in sys.argv[2:6])
+frames, _ = synth.make_clip(w, h, n, seed=77, channels=3)
+al = capi.Aligner(device=0, pyramid_min_width=256)
+out = []
+def rec(i, st, t):
+    inf = al.info(i)
+    out.append([int(st), [float(x).hex() for x in t.tup()], int(inf.fail_reason), [int(x) for x in inf.iterations[:inf.levels]],
+                [float(c).hex() for c in inf.condition[:inf.levels]]])
+if batch:
+    st, ts = al.align_batch(frames)
+    for i in range(n): rec(i, st[i], ts[i])
+else:
+    for i in range(n):
+        ok, t = al.align_next(frames[i])
+        rec(0, ok, t)
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(w, h, n, batch, **env):
+    e = dict(os.environ)
+    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS"):
+        e.pop(k, None)
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch))], env=e, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_1080p_one_frame_at_a_time_equals_the_plain_launch():
+    plain = _run(1920, 1080, 5, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    assert sum(r[0] for r in plain) == 4 and all(r[2] == 0 for r in plain[1:])
+    assert _run(1920, 1080, 5, False) == plain                                  # pipelined + 16 workgroups per pair
+    assert _run(1920, 1080, 5, False, VS_GN_PIPELINE=1, VS_GN_HELPERS=1) == plain
+    assert _run(1920, 1080, 5, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=3) == plain
+
+
+def test_1080p_small_batch_equals_the_plain_launch():
+    # four pairs in one launch: 64 workgroups, every leader with its own helpers
+    plain = _run(1920, 1080, 5, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    assert _run(1920, 1080, 5, True) == plain
+
+
+def test_4k_set_by_set_levels_equal_the_plain_launch():
+    # 4K level 0 has 20736 tiles per set: selected set by set, keys and samples read back in two halves; with two
+    # workgroups per pair a slice does not fit the staging area in one pass
+    plain = _run(3840, 2160, 3, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    assert sum(r[0] for r in plain) == 2
+    assert _run(3840, 2160, 3, False) == plain
+    assert _run(3840, 2160, 3, False, VS_GN_HELPERS=2) == plain
