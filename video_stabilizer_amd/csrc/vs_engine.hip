@@ -68,6 +68,10 @@ struct PairDesc {
     int32_t key_slot;    // slot of the odd (keyframe) frame:      ScalePyramid[KeyframeIndex]
 };
 
+// latency mode: the descriptors of a small launch travel in the kernel arguments (no upload in front of the launch)
+constexpr int kDirectMaxPairs = 16;
+struct PairDescPack { PairDesc d[kDirectMaxPairs]; };
+
 struct GnParams {
     double threshold, max_displacement;
     int max_iters;
@@ -657,8 +661,14 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             memset(&h_states[q], 0, sizeof(PairState));
             h_states[q].status = 1;
         }
-        VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
-        VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
+        // Latency mode (a few pairs, device-side selection, identity start): no copies around the launch at all -- the
+        // descriptors travel in the kernel arguments, the kernel starts from the identity itself and writes its result straight
+        // into the pinned host block the host reads after the synchronisation.
+        const bool direct = n_pairs <= kDirectMaxPairs && !p.phase_correlate && select_mode != VS_SELECT_STL_HOST && nt_max <= kSelectCap;
+        if (!direct) {
+            VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
+            VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
+        }
         // alignment.cpp:369-388: cv::phaseCorrelate(PhaseImage[Prev], PhaseImage[Curr]) starts TX,TY of every pair
         std::vector<vsp::Pair> hp;
         std::vector<uint8_t> hneg;
@@ -725,16 +735,20 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             int group = 1;
             if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles) group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : kCoopGroup;
             const int epoch = ++coop_epoch;
-            hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, states, descs,
-                               pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn, fl, gp, group, coop, epoch, wv);
+            PairDescPack dpack{};
+            if (direct) for (int q = 0; q < n_pairs; q++) dpack.d[q] = hd[q];
+            hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s,
+                               direct ? h_states : states, descs, pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn,
+                               fl, gp, group, coop, epoch, wv, dpack, direct ? 1 : 0);
             VS_HIP(hipGetLastError());
             t_end(1);
-            VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+            if (!direct) VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
             VS_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < n_pairs; q++)
                 if (h_states[q].fail_reason >= 100) use_host = true;   // 100: libstdc++ would have heap-selected; 101: a helper workgroup timed out -- redo on the host
             if (use_host) {
                 for (int q = 0; q < n_pairs; q++) { memset(&h_states[q], 0, sizeof(PairState)); h_states[q].status = 1; }
+                if (direct) VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
                 VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
                 if (p.phase_correlate) VS_TRY(apply_phase());
                 VS_HIP(hipStreamSynchronize(s));
