@@ -82,7 +82,10 @@ __device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint32
 // fused ingest kernel still runs on its LDS tile).
 // ------------------------------------------------------------------------------------------------
 namespace {
-constexpr int PR_OUT = 16;           // output rows per wave (batches); a single frame is cut into bands of 4 rows: 4x the waves, a quarter of the walk
+#ifndef VS_PR_OUT
+#define VS_PR_OUT 16
+#endif
+constexpr int PR_OUT = VS_PR_OUT;           // output rows per wave (batches); a single frame is cut into bands of 4 rows: 4x the waves, a quarter of the walk
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 struct PdRow { uint32_t own, left, right; };   // in(x0..x0+3); in(x0-2), in(x0-1) in bytes 2, 3; in(x0+4) in byte 0
 }
