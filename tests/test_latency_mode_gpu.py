@@ -45,7 +45,7 @@ print("RESULT " + json.dumps(out))
 
 def _run(w, h, n, batch, **env):
     e = dict(os.environ)
-    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS"):
+    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch))], env=e, capture_output=True, text=True,
@@ -76,3 +76,11 @@ def test_4k_set_by_set_levels_equal_the_plain_launch():
     assert sum(r[0] for r in plain) == 2
     assert _run(3840, 2160, 3, False) == plain
     assert _run(3840, 2160, 3, False, VS_GN_HELPERS=2) == plain
+
+
+def test_a_helper_that_never_reports_back_costs_a_timeout_not_a_hang():
+    # every wait inside the kernel is bounded: with the helpers silenced (test hook) the leader gives up after ~0.3 s per call,
+    # flags the pair, and the engine redoes it through the per-level host path -- same result as the plain launch
+    plain = _run(1920, 1080, 3, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    stalled = _run(1920, 1080, 3, False, VS_GN_STALL_HELPERS=1)
+    assert stalled == plain

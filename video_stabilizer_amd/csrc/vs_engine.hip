@@ -76,6 +76,7 @@ struct GnParams {
     double threshold, max_displacement;
     int max_iters;
     int pipeline;   // 1: the one-barrier iteration loop on the LDS-resident level (latency mode, few pairs in flight)
+    int stall_helpers;   // test hook (VS_GN_STALL_HELPERS=1): helpers never report back, the leader's bounded wait must expire
 };
 
 // ---- phase-correlation start value (alignment.cpp:376-387) -----------------------------------------
@@ -704,7 +705,8 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         // worth it while the launch does not fill the chip (the results are bit-identical either way).
         static const int pipe_env = []() { const char* e = getenv("VS_GN_PIPELINE"); return e ? atoi(e) : -1; }();
         const int pipeline = pipe_env >= 0 ? pipe_env : (n_pairs <= kPipelineMaxPairs ? 1 : 0);
-        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline};
+        static const int stall_env = []() { const char* e = getenv("VS_GN_STALL_HELPERS"); return e ? atoi(e) : 0; }();
+        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env};
         bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
         if (!use_host) {
             // VS_SELECT_DEVICE: every level of every pair in one launch (selection = on-device introselect)
