@@ -228,7 +228,7 @@ __host__ __device__ inline size_t coop_pair_bytes(int nt_cap) { return kCoopCtrl
 // ---- fused per-pair aligner: every level of alignment.cpp:390-688 in ONE launch ---------------------
 struct FusedLevels {
     int levels;
-    int w[kMaxLevels], h[kMaxLevels], nt[kMaxLevels], nsel[kMaxLevels];
+    int w[kMaxLevels], h[kMaxLevels], nt[kMaxLevels], nsel[kMaxLevels], tx[kMaxLevels];
     unsigned long long img_off[kMaxLevels], lm_off[kMaxLevels], jac_off[kMaxLevels];
 };
 
@@ -713,7 +713,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             FusedLevels fl;
             fl.levels = levels;
             for (int l = 0; l < levels; l++) {
-                fl.w[l] = L[l].w; fl.h[l] = L[l].h; fl.nt[l] = L[l].nt; fl.nsel[l] = L[l].nsel;
+                fl.w[l] = L[l].w; fl.h[l] = L[l].h; fl.nt[l] = L[l].nt; fl.nsel[l] = L[l].nsel; fl.tx[l] = L[l].tx;
                 fl.img_off[l] = L[l].img_off; fl.lm_off[l] = L[l].lm_off; fl.jac_off[l] = L[l].jac_off;
             }
             // selection arrays in LDS: 6 B per tile for one point set; 12 B when both sets fit, so that they are selected
