@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void vs_k_warpdiff_batch(const PairState* __re
     double T[4] = {st.T[0], st.T[1], st.T[2], st.T[3]};
     float P[4];
     ul_params_sparse(T, w, h, P);
-    int tile_x = min((int)lm[i], w - 1), tile_y = min((int)lm[nt + i], h - 1);
+    const uint32_t xy = ((const uint32_t*)lm)[i];           // {x, y} pair of tile i
+    int tile_x = min((int)(xy & 0xffffu), w - 1), tile_y = min((int)(xy >> 16), h - 1);
     float ox = (float)tile_x, oy = (float)tile_y;
     float Wx = (1.0f + P[0]) * ox - P[1] * oy + P[2];
     float Wy = P[1] * ox + (1.0f + P[0]) * oy + P[3];
@@ -162,12 +163,13 @@ __device__ __forceinline__ PointRecs pair_recs(uint8_t* recs, size_t recs_pair, 
 __device__ __forceinline__ void write_rec(const PointRecs& rc, int slot, const uint16_t* __restrict__ lm,
                                           const float* __restrict__ jac, int nt, int t, const uint8_t* __restrict__ tmpl,
                                           int w, int h, const float* __restrict__ wv_set) {
-    const int px = lm[t], py = lm[nt + t];
-    rc.xy[slot] = (uint32_t)px | ((uint32_t)py << 16);
+    const uint32_t xy = ((const uint32_t*)lm)[t];
+    const int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
+    rc.xy[slot] = xy;
     const float tv = (float)tmpl[(size_t)min(py, h - 1) * w + min(px, w - 1)];
     rc.tv[slot] = tv;
     rc.r0[slot] = tv - wv_set[t];
-    rc.j[slot] = make_float4(jac[t], jac[(size_t)nt + t], jac[2 * (size_t)nt + t], jac[3 * (size_t)nt + t]);
+    rc.j[slot] = ((const float4*)jac)[t];
 }
 
 __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __restrict__ states,
@@ -629,7 +631,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                     float* jx = jac + so * jac_frame + L[l].jac_off;
                     VS_HIP(vsk::keyframe(pyr + so * pyr_frame + L[l].img_off, L[l].w, L[l].h, L[l].w, L[l].ts, lmx,
                                          lmx + 2 * (size_t)L[l].nt, jx, jx + 4 * (size_t)L[l].nt, n_odd, 2 * pyr_frame,
-                                         2 * lm_frame, 2 * jac_frame, s));
+                                         2 * lm_frame, 2 * jac_frame, s, true));
                 }
                 kf_launches += levels;
             }
@@ -1041,16 +1043,23 @@ int vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set,
     VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
     const LevelDims& l = a->L[level];
     VS_HIP(hipSetDevice(a->device));
-    VS_HIP(hipMemcpy(out, a->lm + (size_t)(i + 1) * a->lm_frame + l.lm_off + (size_t)set * 2 * l.nt, (size_t)l.nt * 4,
+    // the table holds {x, y} pairs per tile; the API hands out the reference's planar form (x[nt] then y[nt])
+    std::vector<uint16_t> pairs((size_t)l.nt * 2);
+    VS_HIP(hipMemcpy(pairs.data(), a->lm + (size_t)(i + 1) * a->lm_frame + l.lm_off + (size_t)set * 2 * l.nt, (size_t)l.nt * 4,
                      hipMemcpyDeviceToHost));
+    for (int t = 0; t < l.nt; t++) { out[t] = pairs[2 * (size_t)t]; out[(size_t)l.nt + t] = pairs[2 * (size_t)t + 1]; }
     return VS_OK;
 }
 int vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out) {
     VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
     const LevelDims& l = a->L[level];
     VS_HIP(hipSetDevice(a->device));
-    VS_HIP(hipMemcpy(out, a->jac + (size_t)(i + 1) * a->jac_frame + l.jac_off + (size_t)set * 4 * l.nt, (size_t)l.nt * 16,
+    // the table holds one float4 per tile; the API hands out the reference's planar form (4 planes of nt)
+    std::vector<float> quads((size_t)l.nt * 4);
+    VS_HIP(hipMemcpy(quads.data(), a->jac + (size_t)(i + 1) * a->jac_frame + l.jac_off + (size_t)set * 4 * l.nt, (size_t)l.nt * 16,
                      hipMemcpyDeviceToHost));
+    for (int t = 0; t < l.nt; t++)
+        for (int c = 0; c < 4; c++) out[(size_t)c * l.nt + t] = quads[4 * (size_t)t + c];
     return VS_OK;
 }
 

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void vs_k_keyframe(const uint8_t* __restrict__
                                                      int ts, int tx, int ty, uint16_t* __restrict__ lmx,
                                                      uint16_t* __restrict__ lmy, float* __restrict__ jx,
                                                      float* __restrict__ jy, size_t img_frame_stride,
-                                                     size_t lm_frame_stride, size_t jac_frame_stride) {
+                                                     size_t lm_frame_stride, size_t jac_frame_stride, bool aos) {
     img += blockIdx.y * img_frame_stride;
     lmx += blockIdx.y * lm_frame_stride; lmy += blockIdx.y * lm_frame_stride;
     jx += blockIdx.y * jac_frame_stride; jy += blockIdx.y * jac_frame_stride;
@@ -451,21 +451,27 @@ __global__ __launch_bounds__(256) void vs_k_keyframe(const uint8_t* __restrict__
         const size_t nt = (size_t)tx * ty;
         int sx = (int)(0xffffu - (kx & 0xffffu)), sy = (int)(0xffffu - (ky & 0xffffu));
         int ix0 = bx + sx % ts, iy0 = by + sx / ts, ix1 = bx + sy % ts, iy1 = by + sy / ts;
-        lmx[tile] = (uint16_t)ix0; lmx[nt + tile] = (uint16_t)iy0;
-        lmy[tile] = (uint16_t)ix1; lmy[nt + tile] = (uint16_t)iy1;
+        if (aos) {     // engine tables: one {x, y} pair / one float4 per tile and set (a gather then touches one line, not six)
+            ((uint32_t*)lmx)[tile] = (uint32_t)ix0 | ((uint32_t)iy0 << 16);
+            ((uint32_t*)lmy)[tile] = (uint32_t)ix1 | ((uint32_t)iy1 << 16);
+        } else {
+            lmx[tile] = (uint16_t)ix0; lmx[nt + tile] = (uint16_t)iy0;
+            lmy[tile] = (uint16_t)ix1; lmy[nt + tile] = (uint16_t)iy1;
+        }
         // generators.cpp:346-385 (the min(.., w-1) clamps are no-ops: keypoints lie inside the image)
         const float cx = (float)w * 0.5f, cy = (float)h * 0.5f, scale = 1.f / (float)w;
         float g0 = 0.5f * ((float)img[(size_t)iy0 * stride + min(ix0 + 1, w - 1)] - (float)img[(size_t)iy0 * stride + max(ix0 - 1, 0)]);
         float g1 = 0.5f * ((float)img[(size_t)min(iy1 + 1, h - 1) * stride + ix1] - (float)img[(size_t)max(iy1 - 1, 0) * stride + ix1]);
         float u0 = (float)ix0 - cx, v0 = (float)iy0 - cy, u1 = (float)ix1 - cx, v1 = (float)iy1 - cy;
-        jx[tile] = 2.f * g0 * u0 * scale;
-        jx[nt + tile] = 2.f * g0 * (-v0) * scale;
-        jx[2 * nt + tile] = 2.f * g0;
-        jx[3 * nt + tile] = 0.f;
-        jy[tile] = 2.f * g1 * v1 * scale;
-        jy[nt + tile] = 2.f * g1 * u1 * scale;
-        jy[2 * nt + tile] = 0.f;
-        jy[3 * nt + tile] = 2.f * g1;
+        const float jx0 = 2.f * g0 * u0 * scale, jx1 = 2.f * g0 * (-v0) * scale, jx2 = 2.f * g0, jx3 = 0.f;
+        const float jy0 = 2.f * g1 * v1 * scale, jy1 = 2.f * g1 * u1 * scale, jy2 = 0.f, jy3 = 2.f * g1;
+        if (aos) {
+            ((float4*)jx)[tile] = make_float4(jx0, jx1, jx2, jx3);
+            ((float4*)jy)[tile] = make_float4(jy0, jy1, jy2, jy3);
+        } else {
+            jx[tile] = jx0; jx[nt + tile] = jx1; jx[2 * nt + tile] = jx2; jx[3 * nt + tile] = jx3;
+            jy[tile] = jy0; jy[nt + tile] = jy1; jy[2 * nt + tile] = jy2; jy[3 * nt + tile] = jy3;
+        }
     }
 }
 
@@ -519,7 +525,7 @@ __device__ __forceinline__ void position_row(const RowFetch f, bool first, bool 
 template <int TS>
 __device__ __forceinline__ void keyframe_rows_body(const uint8_t* __restrict__ img, int w, int h, int stride, int tx, int ty,
                                                    uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy, float* __restrict__ jx,
-                                                   float* __restrict__ jy, int strips_x, int block, unsigned (*s_key)[64][2]) {
+                                                   float* __restrict__ jy, int strips_x, int block, unsigned (*s_key)[64][2], bool aos) {
     constexpr int GW = (TS % 4 == 0) ? 4 : 2;    // columns per lane
     constexpr int LPT = TS / GW;                 // lanes per tile
     constexpr int TPW = 64 / LPT;                // tiles per wave (a strip of TPW tiles along x)
@@ -585,21 +591,27 @@ __device__ __forceinline__ void keyframe_rows_body(const uint8_t* __restrict__ i
         const size_t nt = (size_t)tx * ty;
         const int sx = (int)(0xffffu - (kx & 0xffffu)), sy = (int)(0xffffu - (ky & 0xffffu));
         const int ix0 = bx + sx % TS, iy0 = by + sx / TS, ix1 = bx + sy % TS, iy1 = by + sy / TS;
-        lmx[tile] = (uint16_t)ix0; lmx[nt + tile] = (uint16_t)iy0;
-        lmy[tile] = (uint16_t)ix1; lmy[nt + tile] = (uint16_t)iy1;
+        if (aos) {     // engine tables: one {x, y} pair / one float4 per tile and set (a gather then touches one line, not six)
+            ((uint32_t*)lmx)[tile] = (uint32_t)ix0 | ((uint32_t)iy0 << 16);
+            ((uint32_t*)lmy)[tile] = (uint32_t)ix1 | ((uint32_t)iy1 << 16);
+        } else {
+            lmx[tile] = (uint16_t)ix0; lmx[nt + tile] = (uint16_t)iy0;
+            lmy[tile] = (uint16_t)ix1; lmy[nt + tile] = (uint16_t)iy1;
+        }
         // generators.cpp:346-385 (the min(.., w-1) clamps are no-ops: keypoints lie inside the image)
         const float cxf = (float)w * 0.5f, cyf = (float)h * 0.5f, scale = 1.f / (float)w;
         const float g0 = 0.5f * ((float)img[(size_t)iy0 * stride + min(ix0 + 1, w - 1)] - (float)img[(size_t)iy0 * stride + max(ix0 - 1, 0)]);
         const float g1 = 0.5f * ((float)img[(size_t)min(iy1 + 1, h - 1) * stride + ix1] - (float)img[(size_t)max(iy1 - 1, 0) * stride + ix1]);
         const float u0 = (float)ix0 - cxf, v0 = (float)iy0 - cyf, u1 = (float)ix1 - cxf, v1 = (float)iy1 - cyf;
-        jx[tile] = 2.f * g0 * u0 * scale;
-        jx[nt + tile] = 2.f * g0 * (-v0) * scale;
-        jx[2 * nt + tile] = 2.f * g0;
-        jx[3 * nt + tile] = 0.f;
-        jy[tile] = 2.f * g1 * v1 * scale;
-        jy[nt + tile] = 2.f * g1 * u1 * scale;
-        jy[2 * nt + tile] = 0.f;
-        jy[3 * nt + tile] = 2.f * g1;
+        const float jx0 = 2.f * g0 * u0 * scale, jx1 = 2.f * g0 * (-v0) * scale, jx2 = 2.f * g0, jx3 = 0.f;
+        const float jy0 = 2.f * g1 * v1 * scale, jy1 = 2.f * g1 * u1 * scale, jy2 = 0.f, jy3 = 2.f * g1;
+        if (aos) {
+            ((float4*)jx)[tile] = make_float4(jx0, jx1, jx2, jx3);
+            ((float4*)jy)[tile] = make_float4(jy0, jy1, jy2, jy3);
+        } else {
+            jx[tile] = jx0; jx[nt + tile] = jx1; jx[2 * nt + tile] = jx2; jx[3 * nt + tile] = jx3;
+            jy[tile] = jy0; jy[nt + tile] = jy1; jy[2 * nt + tile] = jy2; jy[3 * nt + tile] = jy3;
+        }
     }
 }
 
@@ -608,11 +620,11 @@ __global__ __launch_bounds__(256) void vs_k_keyframe_rows(const uint8_t* __restr
                                                           int ty, uint16_t* __restrict__ lmx, uint16_t* __restrict__ lmy,
                                                           float* __restrict__ jx, float* __restrict__ jy,
                                                           size_t img_frame_stride, size_t lm_frame_stride,
-                                                          size_t jac_frame_stride, int strips_x) {
+                                                          size_t jac_frame_stride, int strips_x, bool aos) {
     __shared__ unsigned s_key[4][64][2];
     keyframe_rows_body<TS>(img + blockIdx.y * img_frame_stride, w, h, stride, tx, ty, lmx + blockIdx.y * lm_frame_stride,
                            lmy + blockIdx.y * lm_frame_stride, jx + blockIdx.y * jac_frame_stride, jy + blockIdx.y * jac_frame_stride,
-                           strips_x, (int)blockIdx.x, s_key);
+                           strips_x, (int)blockIdx.x, s_key, aos);
 }
 
 // The keyframe pass of EVERY pyramid level of every keyframe in one launch (alignment.cpp:237-276 loops GradXY -> GradArgMax ->
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(256) void vs_k_keyframe_levels(const uint8_t* __res
     const uint8_t* img = pyr + blockIdx.y * pyr_frame_stride + q.img_off;
     uint16_t* lmx = lm + blockIdx.y * lm_frame_stride + q.lm_off;
     float* jx = jac + blockIdx.y * jac_frame_stride + q.jac_off;
-#define VS_KF(TS) case TS: keyframe_rows_body<TS>(img, q.w, q.h, q.w, q.tx, q.ty, lmx, lmx + 2 * nt, jx, jx + 4 * nt, q.strips_x, block, s_key); break;
+#define VS_KF(TS) case TS: keyframe_rows_body<TS>(img, q.w, q.h, q.w, q.tx, q.ty, lmx, lmx + 2 * nt, jx, jx + 4 * nt, q.strips_x, block, s_key, true); break;
     switch (q.ts) { VS_KF(2) VS_KF(4) VS_KF(6) VS_KF(8) VS_KF(10) VS_KF(12) VS_KF(14) VS_KF(16) VS_KF(18) VS_KF(20) default: break; }
 #undef VS_KF
 }
@@ -898,7 +910,7 @@ hipError_t sparse_jac(const float* gx, const float* gy, int w, int h, const uint
 }
 
 hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
-                    float* jy, int n_frames, size_t img_fs, size_t lm_fs, size_t jac_fs, hipStream_t s) {
+                    float* jy, int n_frames, size_t img_fs, size_t lm_fs, size_t jac_fs, hipStream_t s, bool aos) {
     int tx = w / ts, ty = h / ts;
     if (tx * ty == 0) return hipSuccess;
 #define VS_ROWS(TS)                                                                                                     \
@@ -906,14 +918,14 @@ hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16
         constexpr int tpw = 64 / (TS / ((TS % 4 == 0) ? 4 : 2));                                                        \
         const int strips_x = cdiv(tx, tpw);                                                                             \
         hipLaunchKernelGGL(vs_k_keyframe_rows<TS>, dim3(cdiv(strips_x * ty, 4), n_frames), dim3(256), 0, s, img, w, h,  \
-                           stride, tx, ty, lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs, strips_x);                          \
+                           stride, tx, ty, lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs, strips_x, aos);                     \
         break;                                                                                                          \
     }
     switch (ts) {   // the sizes vs_tile_size can return (imgproc.cpp:151-162)
         VS_ROWS(2) VS_ROWS(4) VS_ROWS(6) VS_ROWS(8) VS_ROWS(10) VS_ROWS(12) VS_ROWS(14) VS_ROWS(16) VS_ROWS(18) VS_ROWS(20)
     default:
         hipLaunchKernelGGL(vs_k_keyframe, dim3(cdiv(tx * ty, 16), n_frames), dim3(256), 0, s, img, w, h, stride, ts, tx, ty,
-                           lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs);
+                           lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs, aos);
     }
 #undef VS_ROWS
     return hipGetLastError();

@@ -27,9 +27,10 @@ hipError_t sparse_jac(const float* gx, const float* gy, int w, int h, const uint
                       float* jx, float* jy, hipStream_t s);
 hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
                     float* jy, int n_frames, size_t img_frame_stride, size_t lm_frame_stride, size_t jac_frame_stride,
-                    hipStream_t s);
+                    hipStream_t s, bool aos = false);   // aos: the engine's table layout ({x, y} pairs, float4 Jacobians), see vs_engine.hip
 // every pyramid level of n_frames keyframes in ONE launch: pyr / lm / jac = slot of the first keyframe, levels at the given
-// element offsets inside a slot (x-set table at lm_off, y-set 2*nt later; x-set Jacobians at jac_off, y-set 4*nt later)
+// element offsets inside a slot (x-set table at lm_off, y-set 2*nt later; x-set Jacobians at jac_off, y-set 4*nt later);
+// always the engine's layout: {x, y} pairs and float4 Jacobians per tile
 struct KeyframeLevel { int w, h, ts, tx, ty, strips_x, blocks; size_t img_off, lm_off, jac_off; };
 struct KeyframeLevels { int n; KeyframeLevel lv[16]; };
 bool keyframe_levels_supported(const KeyframeLevels& L);
