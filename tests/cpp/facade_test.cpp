@@ -67,6 +67,68 @@ static void TestImageWarpCorrectness() {                               // align_
     for (int y = 0; y < 64; y++) for (int x = 0; x < 64; x++)
         CHECK(out(x, y) == ((x >= 25 && x < 35 && y >= 27 && y < 37) ? 255.f : 0.f));
 }
+// A test double with the part of Halide::Runtime::Buffer<T>'s interface that imgproc.cpp uses (HalideBuffer.h: data(), width(),
+// height(), channels(), dimensions(), dim(i).stride() / .extent(), (w, h[, c]) constructors, planar dense allocation): the
+// operator templates of the facade must give the same bytes through it as through vs::Buffer<T>.
+namespace halide_like {
+struct Dim { int e, s; int extent() const { return e; } int stride() const { return s; } };
+template <typename T, int Dims = -1, int InClassDimStorage = 4>
+class Buffer {
+public:
+    Buffer() = default;
+    Buffer(int w) : d_{{w, 1}}, own_((size_t)w) {}
+    Buffer(int w, int h) : d_{{w, 1}, {h, w}}, own_((size_t)w * h) {}
+    Buffer(int w, int h, int c) : d_{{w, 1}, {h, w}, {c, w * h}}, own_((size_t)w * h * c) {}
+    int dimensions() const { return (int)d_.size(); }
+    Dim dim(int i) const { return d_[i]; }
+    int width() const { return d_.size() > 0 ? d_[0].e : 1; }
+    int height() const { return d_.size() > 1 ? d_[1].e : 1; }
+    int channels() const { return d_.size() > 2 ? d_[2].e : 1; }
+    T* data() { return own_.data(); }
+    const T* data() const { return own_.data(); }
+    T& operator()(int x, int y = 0, int c = 0) { return own_[((size_t)c * height() + y) * width() + x]; }
+private:
+    std::vector<Dim> d_;
+    std::vector<T> own_;
+};
+}  // namespace halide_like
+
+template <typename U8, typename U16, typename F32, typename F64>
+static std::vector<double> run_chain(const std::vector<uint8_t>& g0, const std::vector<uint8_t>& g1, int w, int h) {
+    // the per-level sequence of alignment.cpp:220-276 + one sparse_warpdiff / sparse_ica call, kernel by kernel
+    U8 a(w, h), b(w, h), half(w / 2, h / 2);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) { a(x, y) = g0[(size_t)y * w + x]; b(x, y) = g1[(size_t)y * w + x]; }
+    std::vector<double> sig;
+    CHECK(PyrDown(a, half));
+    for (int y = 0; y < h / 2; y += 7) for (int x = 0; x < w / 2; x += 5) sig.push_back(half(x, y));
+    F32 gx(w, h), gy(w, h);
+    CHECK(GradXY(a, gx, gy));
+    int ts = 0;
+    U16 lmx, lmy;
+    CHECK(GradArgMax(gx, gy, ts, lmx, lmy));
+    F32 jx, jy;
+    CHECK(SparseJacobian(gx, gy, lmx, lmy, jx, jy));
+    SimilarityTransform T; T.TX = 0.75; T.TY = -0.5; T.A = 0.001;
+    U16 wdx, wdy;
+    CHECK(SparseWarpDiff(b, a, lmx, T, wdx));
+    CHECK(SparseWarpDiff(b, a, lmy, T, wdy));
+    const int nt = lmx.width() * lmx.height();
+    sig.push_back(ts); sig.push_back(nt);
+    for (int i = 0; i < nt; i += 3) { sig.push_back(lmx.data()[i]); sig.push_back(lmy.data()[nt + i]); sig.push_back(jx.data()[i]); sig.push_back(wdx.data()[i]); sig.push_back(wdy.data()[i]); }
+    // "selected" = every tile (n, 2) / (n, 4): the tables already have that layout
+    U16 selx(nt, 2), sely(nt, 2);
+    F32 sjx(nt, 4), sjy(nt, 4);
+    for (int i = 0; i < 2 * nt; i++) { selx.data()[i] = lmx.data()[i]; sely.data()[i] = lmy.data()[i]; }
+    for (int i = 0; i < 4 * nt; i++) { sjx.data()[i] = jx.data()[i]; sjy.data()[i] = jy.data()[i]; }
+    F64 jtr;
+    CHECK(SparseICA(b, a, selx, sely, sjx, sjy, T, jtr));
+    for (int i = 0; i < 4; i++) sig.push_back(jtr.data()[i]);
+    F32 warped(w, h);
+    CHECK(ImageWarp(a, T, warped));
+    for (int y = 3; y < h; y += 11) for (int x = 2; x < w; x += 9) sig.push_back(warped(x, y));
+    return sig;
+}
+
 static std::vector<uint8_t> texture(int w, int h, double dx, double dy) {   // smooth synthetic BGR frame, shifted by (dx,dy)
     std::vector<uint8_t> f((size_t)w * h * 3);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
@@ -97,6 +159,19 @@ static void AlignImagePair() {                                         // align_
     CHECK(produced == 3);
 }
 
+static void TestOperatorsThroughBothBufferClasses() {
+    const int w = 320, h = 240;
+    auto c0 = texture(w, h, 0, 0), c1 = texture(w, h, 0.75, -0.5);
+    std::vector<uint8_t> g0((size_t)w * h), g1((size_t)w * h);
+    for (size_t i = 0; i < g0.size(); i++) { g0[i] = c0[3 * i]; g1[i] = c1[3 * i]; }
+    const auto a = run_chain<vs::Buffer<uint8_t>, vs::Buffer<uint16_t>, vs::Buffer<float>, vs::Buffer<double>>(g0, g1, w, h);
+    const auto b = run_chain<halide_like::Buffer<uint8_t>, halide_like::Buffer<uint16_t>, halide_like::Buffer<float>, halide_like::Buffer<double>>(g0, g1, w, h);
+    CHECK(a.size() > 1000 && a.size() == b.size());
+    bool same = a.size() == b.size();
+    for (size_t i = 0; same && i < a.size(); i++) same = a[i] == b[i];
+    CHECK(same);
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     TestSimilarityTransformInverse();
@@ -104,6 +179,7 @@ int main(int argc, char** argv) {
     TestRandomized();
     if (mode == "gpu") {
         TestImageWarpCorrectness();
+        TestOperatorsThroughBothBufferClasses();
         AlignImagePair();
     }
     std::printf(fails ? "FAILED (%d)\n" : "ALL PASS\n", fails);

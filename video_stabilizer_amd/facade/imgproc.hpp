@@ -3,9 +3,9 @@
 // (true iff the underlying call succeeded; outputs passed by non-const reference and (re)allocated by the
 // callee when their shape does not match -- imgproc.cpp:34-40,56-60,87-92,166-172).
 //
-// The reference's Halide::Runtime::Buffer<T> / cv::Mat are replaced by the small owning vs::Buffer<T> below
-// (dense, dim0 stride 1, "planar" like Halide: element (x,y,c) at c*w*h + y*w + x).  With OpenCV present a
-// caller wraps cv::Mat data with vs::Buffer<T>::view().
+// The operator functions are templates over the buffer class (see below): the small owning vs::Buffer<T> of this header
+// (dense, dim0 stride 1, "planar" like Halide: element (x,y,c) at c*w*h + y*w + x) or Halide::Runtime::Buffer<T> itself.
+// With OpenCV present a caller wraps cv::Mat data with vs::Buffer<T>::view().
 #pragma once
 
 #include <cmath>
@@ -14,6 +14,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/vs_amd.h"
@@ -71,42 +73,83 @@ struct SimilarityTransform {
 };
 static_assert(sizeof(SimilarityTransform) == sizeof(vs_transform), "layout must match vs_transform");
 
+// ---- the seven operator functions of imgproc.hpp:8-32 ---------------------------------------------------------------
+// Written against the buffer INTERFACE, not a buffer class: anything with data() / width() / height() / dimensions() that is
+// constructible from (w, h[, c]) and assignable -- vs::Buffer<T> above, and Halide::Runtime::Buffer<T> where a caller still has
+// Halide's headers, so that the reference's own call sites (alignment.cpp:220-276, 435-546) compile unchanged.  The element
+// types are the reference's (static_assert), the layout is dense planar (checked at run time where the class exposes
+// dim(i).stride(), as Halide's does: freshly allocated Halide buffers are dense).
+namespace vs {
+template <class B> using elem_t = std::remove_cv_t<std::remove_pointer_t<decltype(std::declval<B&>().data())>>;
+template <class B, class = void> struct has_dim : std::false_type {};
+template <class B> struct has_dim<B, std::void_t<decltype(std::declval<const B&>().dim(0).stride())>> : std::true_type {};
+template <class B>
+inline bool dense(const B& b) {
+    if constexpr (has_dim<B>::value) {
+        long want = 1;
+        for (int d = 0; d < b.dimensions(); d++) { if (b.dim(d).stride() != want) return false; want *= b.dim(d).extent(); }
+    }
+    return b.data() != nullptr;
+}
+template <class B>
+inline int channels_of(const B& b) {
+    if constexpr (has_dim<B>::value) return b.dimensions() > 2 ? (int)b.dim(2).extent() : 1;
+    else return b.channels();
+}
+}  // namespace vs
+
 // imgproc.cpp:108-114
-inline bool PyrDown(vs::Buffer<uint8_t>& input, vs::Buffer<uint8_t>& output) {
+template <class BIn, class BOut>
+inline bool PyrDown(BIn& input, BOut& output) {
+    static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, uint8_t>::value, "PyrDown: u8 -> u8");
+    if (!vs::dense(input) || !vs::dense(output)) return false;
     return vs_pyr_down(input.data(), input.width(), input.height(), input.width(), output.data(), output.width(), output.height(),
                        output.width(), VS_MEM_HOST, nullptr) == 0;
 }
 // imgproc.cpp:135-142
-inline bool GradXY(vs::Buffer<uint8_t>& input, vs::Buffer<float>& output_x, vs::Buffer<float>& output_y) {
+template <class BIn, class BOut>
+inline bool GradXY(BIn& input, BOut& output_x, BOut& output_y) {
+    static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, float>::value, "GradXY: u8 -> f32, f32");
+    if (!vs::dense(input) || !vs::dense(output_x) || !vs::dense(output_y)) return false;
     return vs_grad_xy(input.data(), input.width(), input.height(), input.width(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
 }
 // imgproc.cpp:144-202 (tile-size rule + (re)allocation + dispatch)
-inline bool GradArgMax(vs::Buffer<float>& grad_x, vs::Buffer<float>& grad_y, int& tile_size, vs::Buffer<uint16_t>& local_max_x,
-                       vs::Buffer<uint16_t>& local_max_y) {
+template <class BGrad, class BMax>
+inline bool GradArgMax(BGrad& grad_x, BGrad& grad_y, int& tile_size, BMax& local_max_x, BMax& local_max_y) {
+    static_assert(std::is_same<vs::elem_t<BGrad>, float>::value && std::is_same<vs::elem_t<BMax>, uint16_t>::value, "GradArgMax: f32, f32 -> u16, u16");
     tile_size = vs_tile_size(grad_x.width(), grad_y.height());
     const int wt = grad_x.width() / tile_size, ht = grad_y.height() / tile_size;
     if (local_max_x.dimensions() != 3 || local_max_x.width() != wt || local_max_x.height() != ht) {
-        local_max_x = vs::Buffer<uint16_t>(wt, ht, 2);
-        local_max_y = vs::Buffer<uint16_t>(wt, ht, 2);
+        local_max_x = BMax(wt, ht, 2);
+        local_max_y = BMax(wt, ht, 2);
     }
+    if (!vs::dense(grad_x) || !vs::dense(grad_y)) return false;
     return vs_grad_argmax(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), tile_size, local_max_x.data(), local_max_y.data(),
                           VS_MEM_HOST, nullptr) == 0;
 }
 // imgproc.cpp:26-44
-inline bool SparseJacobian(vs::Buffer<float>& grad_x, vs::Buffer<float>& grad_y, vs::Buffer<uint16_t>& local_max_x,
-                           vs::Buffer<uint16_t>& local_max_y, vs::Buffer<float>& output_x, vs::Buffer<float>& output_y) {
+template <class BGrad, class BMax, class BJac>
+inline bool SparseJacobian(BGrad& grad_x, BGrad& grad_y, BMax& local_max_x, BMax& local_max_y, BJac& output_x, BJac& output_y) {
+    static_assert(std::is_same<vs::elem_t<BGrad>, float>::value && std::is_same<vs::elem_t<BMax>, uint16_t>::value &&
+                  std::is_same<vs::elem_t<BJac>, float>::value, "SparseJacobian: f32, f32, u16, u16 -> f32, f32");
     if (output_x.dimensions() != 3 || output_x.width() != local_max_x.width() || output_x.height() != local_max_x.height()) {
-        output_x = vs::Buffer<float>(local_max_x.width(), local_max_x.height(), 4);
-        output_y = vs::Buffer<float>(local_max_x.width(), local_max_x.height(), 4);
+        output_x = BJac(local_max_x.width(), local_max_x.height(), 4);
+        output_y = BJac(local_max_x.width(), local_max_x.height(), 4);
     }
+    if (!vs::dense(grad_x) || !vs::dense(grad_y) || !vs::dense(local_max_x) || !vs::dense(local_max_y)) return false;
     return vs_sparse_jac(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), local_max_x.data(), local_max_y.data(),
                          local_max_x.width(), local_max_x.height(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
 }
 // imgproc.cpp:46-78: selected_pixels (n,2) u16, selected_jacobians (n,4) f32
-inline bool SparseICA(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8_t>& input_keyframe, vs::Buffer<uint16_t>& selected_pixels_x,
-                      vs::Buffer<uint16_t>& selected_pixels_y, vs::Buffer<float>& selected_jacobians_x,
-                      vs::Buffer<float>& selected_jacobians_y, const SimilarityTransform& transform, vs::Buffer<double>& output) {
-    if (output.dimensions() != 1 || output.width() != 4) output = vs::Buffer<double>(4);
+template <class BImg, class BPix, class BJac, class BOut>
+inline bool SparseICA(BImg& input_template, BImg& input_keyframe, BPix& selected_pixels_x, BPix& selected_pixels_y, BJac& selected_jacobians_x,
+                      BJac& selected_jacobians_y, const SimilarityTransform& transform, BOut& output) {
+    static_assert(std::is_same<vs::elem_t<BImg>, uint8_t>::value && std::is_same<vs::elem_t<BPix>, uint16_t>::value &&
+                  std::is_same<vs::elem_t<BJac>, float>::value && std::is_same<vs::elem_t<BOut>, double>::value,
+                  "SparseICA: u8, u8, u16, u16, f32, f32 -> f64");
+    if (output.dimensions() != 1 || output.width() != 4) output = BOut(4);
+    if (!vs::dense(input_template) || !vs::dense(input_keyframe) || !vs::dense(selected_pixels_x) || !vs::dense(selected_pixels_y) ||
+        !vs::dense(selected_jacobians_x) || !vs::dense(selected_jacobians_y)) return false;
     float p[4];
     vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
     return vs_sparse_ica(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(), input_keyframe.width(),
@@ -115,10 +158,12 @@ inline bool SparseICA(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8_t>& 
                          nullptr) == 0;
 }
 // imgproc.cpp:80-106
-inline bool SparseWarpDiff(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8_t>& input_keyframe, vs::Buffer<uint16_t>& local_max,
-                           const SimilarityTransform& transform, vs::Buffer<uint16_t>& output) {
+template <class BImg, class BMax>
+inline bool SparseWarpDiff(BImg& input_template, BImg& input_keyframe, BMax& local_max, const SimilarityTransform& transform, BMax& output) {
+    static_assert(std::is_same<vs::elem_t<BImg>, uint8_t>::value && std::is_same<vs::elem_t<BMax>, uint16_t>::value, "SparseWarpDiff: u8, u8, u16 -> u16");
     if (output.dimensions() != 2 || output.width() != local_max.width() || output.height() != local_max.height())
-        output = vs::Buffer<uint16_t>(local_max.width(), local_max.height());
+        output = BMax(local_max.width(), local_max.height());
+    if (!vs::dense(input_template) || !vs::dense(input_keyframe) || !vs::dense(local_max)) return false;
     float p[4];
     vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
     return vs_sparse_warpdiff(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(),
@@ -126,7 +171,10 @@ inline bool SparseWarpDiff(vs::Buffer<uint8_t>& input_template, vs::Buffer<uint8
                               output.data(), VS_MEM_HOST, nullptr) == 0;
 }
 // imgproc.cpp:116-133
-inline bool ImageWarp(vs::Buffer<uint8_t>& input, const SimilarityTransform& transform, vs::Buffer<float>& output) {
+template <class BIn, class BOut>
+inline bool ImageWarp(BIn& input, const SimilarityTransform& transform, BOut& output) {
+    static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, float>::value, "ImageWarp: u8 -> f32");
+    if (!vs::dense(input) || !vs::dense(output)) return false;
     float p[4];
     vs_ul_params_warp(&transform.c(), input.width(), input.height(), p);
     return vs_image_warp(input.data(), input.width(), input.height(), input.width(), p[0], p[1], p[2], p[3], output.data(), output.width(),
