@@ -19,6 +19,7 @@
 #include "vs_device.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -668,6 +669,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         // descriptors travel in the kernel arguments, the kernel starts from the identity itself and writes its result straight
         // into the pinned host block the host reads after the synchronisation.
         const bool direct = n_pairs <= kDirectMaxPairs && !p.phase_correlate && select_mode != VS_SELECT_STL_HOST && nt_max <= kSelectCap;
+        static const bool poll_done = []() { const char* e = getenv("VS_GN_POLL"); return e ? atoi(e) != 0 : true; }();
         if (!direct) {
             VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
             VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
@@ -732,7 +734,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             }
             const bool small_wg = nt_max <= kSmallWgTiles;
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
-            VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            {   // (set once per kernel and size: the call costs a few microseconds of host time)
+                static std::atomic<size_t> dyn_set[2];
+                if (dyn_set[small_wg ? 0 : 1].load() < dyn) {
+                    VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                    dyn_set[small_wg ? 0 : 1].store(dyn);
+                }
+            }
             t_begin(VS_STAGE_GN);
             // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
             static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
@@ -747,7 +755,23 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipGetLastError());
             t_end(1);
             if (!direct) VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
-            VS_HIP(hipStreamSynchronize(s));
+            if (direct && poll_done && !timing) {
+                // the kernel writes a pair's `pad` word last, behind a system-scope fence: the results are in host memory when
+                // every pair's word has arrived -- the host spins on them instead of sleeping in the runtime (the stream itself
+                // is ordered by the next enqueue); after ~2 ms it falls back to the synchronisation, which also reports faults
+                const auto t0 = std::chrono::steady_clock::now();
+                bool all = false;
+                while (!all) {
+                    all = true;
+                    for (int q = 0; q < n_pairs; q++)
+                        if (reinterpret_cast<volatile int32_t*>(&h_states[q].pad)[0] != (int32_t)epoch) { all = false; break; }
+                    if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (!all) VS_HIP(hipStreamSynchronize(s));
+            } else {
+                VS_HIP(hipStreamSynchronize(s));
+            }
             for (int q = 0; q < n_pairs; q++)
                 if (h_states[q].fail_reason >= 100) use_host = true;   // 100: libstdc++ would have heap-selected; 101: a helper workgroup timed out -- redo on the host
             if (use_host) {
