@@ -6,6 +6,7 @@ a process of its own; the frames come from the same seeded generator.
   plain    VS_GN_PIPELINE=0 VS_GN_HELPERS=1   one workgroup per pair, two-barrier loop (what a full batch runs)
   default  (unset)                             pipelined loop + 16 workgroups per pair for <= 16 pairs
   few      VS_GN_HELPERS=2 / 3                 few, large slices: several staging passes per helper
+  sync     VS_GN_POLL=0                        completion through hipStreamSynchronize instead of the polled result block
 """
 import json
 import os
@@ -45,7 +46,7 @@ print("RESULT " + json.dumps(out))
 
 def _run(w, h, n, batch, **env):
     e = dict(os.environ)
-    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS"):
+    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS", "VS_GN_POLL"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch))], env=e, capture_output=True, text=True,
@@ -67,6 +68,17 @@ def test_1080p_small_batch_equals_the_plain_launch():
     # four pairs in one launch: 64 workgroups, every leader with its own helpers
     plain = _run(1920, 1080, 5, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
     assert _run(1920, 1080, 5, True) == plain
+
+
+def test_sixteen_pairs_in_one_launch_equal_the_plain_launch():
+    # the largest launch that still gets helpers (16 pairs x 16 workgroups) and the direct (kernel-argument) descriptors
+    plain = _run(1920, 1080, 17, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    assert sum(r[0] for r in plain) == 16
+    assert _run(1920, 1080, 17, True) == plain
+
+
+def test_polled_and_synchronised_completion_agree():
+    assert _run(1920, 1080, 4, False, VS_GN_POLL=0) == _run(1920, 1080, 4, False)
 
 
 def test_4k_set_by_set_levels_equal_the_plain_launch():

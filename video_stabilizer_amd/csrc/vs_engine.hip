@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
 // slices to the helpers that have arrived BY THEN (assign[g], nslices, T, then t_ready) and never waits for one that has
 // not; a helper writes the packed keys of its slice and raises wd_done[g]; the leader reads all keys into LDS and goes on
 // alone.  `abort` releases helpers when the pair ends early.  All waits are bounded.
+constexpr int kMaxDevices = 64;              // devices the per-device launch caches index; beyond that they are bypassed
 constexpr int kCoopGroup = 16;         // workgroups per pair in latency mode (1080p: 8 and 16 alike; 4K: 16 is 3 % faster)
 constexpr int kCoopMaxGroup = 16;
 constexpr int kCoopMaxPairs = 16;      // latency mode for launches of at most this many pairs
@@ -734,11 +736,15 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             }
             const bool small_wg = nt_max <= kSmallWgTiles;
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
-            {   // (set once per kernel and size: the call costs a few microseconds of host time)
-                static std::atomic<size_t> dyn_set[2];
-                if (dyn_set[small_wg ? 0 : 1].load() < dyn) {
-                    VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-                    dyn_set[small_wg ? 0 : 1].store(dyn);
+            {   // The limit belongs to (kernel, device) and is shared by every handle of the process: it is only ever raised,
+                // and only when a launch needs more than was granted before (the call costs microseconds of host time).
+                static std::mutex dyn_mu;
+                static size_t dyn_set[2][kMaxDevices];
+                std::lock_guard<std::mutex> g(dyn_mu);
+                size_t& granted = dyn_set[small_wg ? 0 : 1][std::min(std::max(device, 0), kMaxDevices - 1)];
+                if (granted < dyn || device >= kMaxDevices) {
+                    VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(dyn, granted)));
+                    granted = std::max(dyn, granted);
                 }
             }
             t_begin(VS_STAGE_GN);
