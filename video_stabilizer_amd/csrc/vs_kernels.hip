@@ -478,48 +478,27 @@ __global__ __launch_bounds__(256) void vs_k_keyframe(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 // The same pass for the tile sizes the reference instantiates (even 2..20, CMakeLists.txt:212-253), laid out for
 // coalescing: a wave owns a horizontal strip of tiles, one lane per group of GW = 4 (2 when TS % 4 != 0) adjacent columns,
-// and walks down the TS rows of the strip.  Per row a lane issues ONE aligned load of its own GW bytes (a wave reads up to
-// 256 contiguous bytes of the row); the pixels left and right of the group come from the neighbouring lanes (wave_shr /
-// wave_shl DPP moves), the rows above / below from a 3-row sliding window in registers, so every row is loaded once
-// (+ 2 halo rows per strip).  Bytes are moved to bits 16..23 with v_perm_b32 and each arg-max key
-// (|a - b| << 16) | (GW - 1 - k) is ONE v_sad_u32 (|a - b| + inline constant); the best of the group plus
-// (0xffff - (ry * TS + cx + GW - 1)) is the tile-scan key of the generic kernel.  The TS / GW lanes of a tile meet in an
-// LDS atomic max.  Measured against the 16-lanes-per-tile kernel above (unaligned 8-byte gathers): 1.55x faster at 1080p,
-// 1.6x at 4K; unaligned per-lane vector loads and one-row-per-lane layouts were slower than either.
+// and walks down the TS rows of the strip.  Per row EVERY lane issues one load of GW bytes at (scalar row pointer + its own
+// constant byte offset): lanes 1 .. n_live carry the tiles' column groups, lane 0 and lane n_live + 1 fetch the words that
+// hold the strip's left / right neighbour columns (at the image border: the word that holds the clamped column), so the
+// pixels left and right of a group always come from the neighbouring lanes (wave_shr / wave_shl DPP moves) through a
+// per-lane v_perm selector that is fixed before the loop -- no per-row border cases, no address arithmetic on the vector
+// unit.  Rows above / below live in a 3-row window of registers (the row loop is unrolled by three so that the window
+// rotates by renaming), every row is loaded once (+ 2 halo rows per strip).  Bytes are moved to bits 16..23 with
+// v_perm_b32 and each arg-max key (|a - b| << 16) | (0xffff - (ry * TS + k)) is ONE v_sad_u32 whose addend is a scalar
+// register (the row term is wave-uniform); a lane's column offset is subtracted once after the loop, which gives the
+// tile-scan key of the generic kernel.  The TS / GW lanes of a tile meet in an LDS atomic max.
+// Round 2: 43 -> 21 vector instructions per row and lane (the border loads, their branches and the 64-bit address
+// arithmetic went away).
 // ------------------------------------------------------------------------------------------------
-template <int IMM>
-__device__ __forceinline__ unsigned sad_u32_imm(unsigned a, unsigned b) {
+__device__ __forceinline__ unsigned sad_u32_s(unsigned a, unsigned b, unsigned c) {      // |a - b| + c, c wave-uniform
     unsigned r;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "n"(IMM));
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
     return r;
 }
+__device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }
 
-// one row step of a lane: its own GW bytes in(x .. x+GW-1, y) by one aligned load; in(x-1) and in(x+GW) are the last /
-// first byte of the neighbouring lanes' words (wave_shr / wave_shl DPP moves), except at the two ends of the wave's strip,
-// where the lane also fetches that single clamped byte.  Everything a row needs from memory is in RowFetch, so rows can
-// be requested several steps before they are used.
-struct RowFetch { uint32_t own, left, right; };
-template <int GW>
-__device__ __forceinline__ RowFetch fetch_row(const uint8_t* __restrict__ row, int x, int xl, int xr, bool first, bool last) {
-    RowFetch f{0, 0, 0};
-    if (GW == 4) __builtin_memcpy(&f.own, row + x, 4);
-    else { uint16_t t; __builtin_memcpy(&t, row + x, 2); f.own = t; }
-    if (first) f.left = row[xl];
-    if (last) f.right = row[xr];
-    return f;
-}
-// p[k] = in(x - 1 + k, y) << 16, k = 0 .. GW + 1
-template <int GW>
-__device__ __forceinline__ void position_row(const RowFetch f, bool first, bool last, unsigned (&p)[GW + 2]) {
-    uint32_t left = (uint32_t)dpp_mov0<0x138>((int)f.own);     // wave_shr:1 -> lane - 1
-    uint32_t right = (uint32_t)dpp_mov0<0x130>((int)f.own);    // wave_shl:1 -> lane + 1
-    if (first) left = f.left << (8 * (GW - 1));
-    if (last) right = f.right;
-    p[0] = __builtin_amdgcn_perm(0u, left, 0x0c000c0cu | ((unsigned)(GW - 1) << 16));
-#pragma unroll
-    for (int k = 0; k < GW; k++) p[k + 1] = __builtin_amdgcn_perm(0u, f.own, 0x0c000c0cu | ((unsigned)k << 16));
-    p[GW + 1] = __builtin_amdgcn_perm(0u, right, 0x0c000c0cu);
-}
+constexpr int keyframe_rows_tiles_per_wave(int ts) { return 62 / (ts / ((ts % 4 == 0) ? 4 : 2)); }
 
 // body of one 256-thread workgroup (4 strips); `block` = the workgroup's index within its level, pointers already at the frame
 template <int TS>
@@ -528,61 +507,92 @@ __device__ __forceinline__ void keyframe_rows_body(const uint8_t* __restrict__ i
                                                    float* __restrict__ jy, int strips_x, int block, unsigned (*s_key)[64][2], bool aos) {
     constexpr int GW = (TS % 4 == 0) ? 4 : 2;    // columns per lane
     constexpr int LPT = TS / GW;                 // lanes per tile
-    constexpr int TPW = 64 / LPT;                // tiles per wave (a strip of TPW tiles along x)
+    constexpr int TPW = keyframe_rows_tiles_per_wave(TS);   // tiles per wave (a strip of TPW tiles along x) + two halo lanes
     ((unsigned*)s_key)[threadIdx.x] = 0u;
     ((unsigned*)s_key)[threadIdx.x + 256] = 0u;
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int strip = block * 4 + wave;          // strip index: tile row tyi, TPW tiles starting at tile column sx0
-    const int tyi = strip / strips_x, sx0 = (strip - tyi * strips_x) * TPW;
-    const int tw = lane / LPT, g = lane - tw * LPT;
+    const int tyi = __builtin_amdgcn_readfirstlane(strip / strips_x);
+    const int sx0 = (strip - tyi * strips_x) * TPW;
+    const int n_live = min(TPW, tx - sx0) * LPT; // lanes 1 .. n_live carry column groups, adjacent in x
+    const bool wave_live = tyi < ty && n_live > 0;            // wave-uniform
+    const int li = lane - 1, tw = max(li, 0) / LPT, g = li - tw * LPT;
     const int txi = sx0 + tw;
-    const bool live = tyi < ty && tw < TPW && txi < tx;
+    const bool live = wave_live && lane >= 1 && lane <= n_live;
     const int bx = txi * TS, by = tyi * TS, cx = g * GW;
-    if (live) {
-        const int x = bx + cx;
-        const int n_live = min(TPW, tx - sx0) * LPT;             // live lanes of this wave: 0 .. n_live-1, adjacent in x
-        const bool first = lane == 0, last = lane == n_live - 1;
-        const int xl = max(x - 1, 0), xr = min(x + GW, w - 1);
-        unsigned prev[GW + 2], cur[GW + 2], nxt[GW + 2];
-        auto row_at = [&](int y) { return fetch_row<GW>(img + (size_t)clampi(y, 0, h - 1) * stride, x, xl, xr, first, last); };
-        position_row<GW>(row_at(by - 1), first, last, prev);
-        position_row<GW>(row_at(by), first, last, cur);
-        // D rows are in flight before the first one is needed and every step refills the slot it consumed (3 registers per
-        // row).  The loop stays rolled: fully unrolled, the compiler hoists all TS + 2 row loads and the kernel drops to
-        // 2 waves / SIMD.
-        // (deeper rings measured slower: D = 10 at TS = 20 takes 0.182 ms per 120 x 1080p keyframes x 3 levels against 0.141)
-        constexpr int D = (TS % 4 == 0) ? 4 : 2;
-        RowFetch ring[D];
-#pragma unroll
-        for (int j = 0; j < D; j++) ring[j] = row_at(by + 1 + j);
+    if (wave_live) {
+        const int x_first = sx0 * TS, x = x_first + li * GW;
+        const int off_lo = max(x_first - GW, 0), off_hi = min(x_first + n_live * GW, w - GW);     // the two halo words
+        const int off = lane == 0 ? off_lo : (lane <= n_live ? x : off_hi);
+        const int off_left = lane <= 1 ? off_lo : x - GW, off_right = lane >= n_live ? off_hi : x + GW;
+        // v_perm selectors {0, byte, 0, 0}: in(x - 1) out of the left neighbour's word, in(x + GW) out of the right one's
+        const unsigned sel_l = 0x0c000c0cu | ((unsigned)((max(x - 1, 0) - off_left) & 3) << 16);
+        const unsigned sel_r = 0x0c000c0cu | ((unsigned)((min(x + GW, w - 1) - off_right) & 3) << 16);
+        auto row_at = [&](int j) -> uint32_t {                     // row by + j (clamped): scalar pointer + lane offset
+            int y;                                                  // clampi(by + j, 0, h - 1), kept on the scalar unit
+            asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, %2" : "=&s"(y) : "s"(__builtin_amdgcn_readfirstlane(by + j)), "s"(__builtin_amdgcn_readfirstlane(h - 1)) : "scc");
+            const uint8_t* rp = img + ((uint32_t)(y * stride) + (uint32_t)off);      // (a level is far below 4 GB)
+            if (GW == 4) { uint32_t v; __builtin_memcpy(&v, rp, 4); return v; }
+            uint16_t t; __builtin_memcpy(&t, rp, 2); return t;
+        };
         unsigned mx = 0, my = 0;
-        unsigned base = 0xffffu - (unsigned)(cx + GW - 1);       // row 0; + (GW-1-k) = 0xffff - (ry*TS + cx + k)
-#pragma unroll 1
-        for (int ry0 = 0; ry0 < TS; ry0 += D) {
-#pragma unroll
-            for (int j = 0; j < D; j++) {
-                position_row<GW>(ring[j], first, last, nxt);
-                ring[j] = row_at(by + ry0 + j + 1 + D);
-                unsigned gxm, gym;
-                if (GW == 4) {
-                    gxm = max(max(sad_u32_imm<3>(cur[2], cur[0]), sad_u32_imm<2>(cur[3], cur[1])),
-                              max(sad_u32_imm<1>(cur[4], cur[2]), sad_u32_imm<0>(cur[5], cur[3])));
-                    gym = max(max(sad_u32_imm<3>(nxt[1], prev[1]), sad_u32_imm<2>(nxt[2], prev[2])),
-                              max(sad_u32_imm<1>(nxt[3], prev[3]), sad_u32_imm<0>(nxt[4], prev[4])));
-                } else {
-                    gxm = max(sad_u32_imm<1>(cur[2], cur[0]), sad_u32_imm<0>(cur[3], cur[1]));
-                    gym = max(sad_u32_imm<1>(nxt[1], prev[1]), sad_u32_imm<0>(nxt[2], prev[2]));
-                }
-                mx = max(mx, gxm + base);
-                my = max(my, gym + base);
-                base -= (unsigned)TS;
-#pragma unroll
-                for (int k = 0; k < GW + 2; k++) { prev[k] = cur[k]; cur[k] = nxt[k]; }
-            }
+        unsigned r0[GW], r1[GW], r2[GW];         // in(x + k, row) << 16 of the two rows above the arriving one (rotating)
+        // one arriving row: p[k] = in(x - 1 + k, by + j) << 16; gx of row j from p, gy of row j - 1 from p and row j - 2 (= A)
+#define VS_KF_STEP(WORD, J, A, T, DO_GX, DO_GY)                                                                         \
+        {                                                                                                               \
+            const uint32_t own_ = (WORD);                                                                               \
+            const uint32_t left_ = (uint32_t)dpp_mov0<0x138>((int)own_);     /* wave_shr:1 -> lane - 1 */               \
+            const uint32_t right_ = (uint32_t)dpp_mov0<0x130>((int)own_);    /* wave_shl:1 -> lane + 1 */               \
+            unsigned p_[GW + 2];                                                                                        \
+            p_[0] = __builtin_amdgcn_perm(0u, left_, sel_l);                                                            \
+            _Pragma("unroll") for (int k = 0; k < GW; k++) p_[k + 1] = __builtin_amdgcn_perm(0u, own_, 0x0c000c0cu | ((unsigned)k << 16)); \
+            p_[GW + 1] = __builtin_amdgcn_perm(0u, right_, sel_r);                                                      \
+            if (DO_GX) {                                                                                                \
+                const unsigned c_ = 0xffffu - (unsigned)((J) * TS);                                                     \
+                mx = max3u(mx, sad_u32_s(p_[2], p_[0], c_), sad_u32_s(p_[3], p_[1], c_ - 1u));                          \
+                if (GW == 4) mx = max3u(mx, sad_u32_s(p_[GW], p_[GW - 2], c_ - 2u), sad_u32_s(p_[GW + 1], p_[GW - 1], c_ - 3u)); \
+            }                                                                                                           \
+            if (DO_GY) {                                                                                                \
+                const unsigned c_ = 0xffffu - (unsigned)(((J) - 1) * TS);                                               \
+                my = max3u(my, sad_u32_s(p_[1], A[0], c_), sad_u32_s(p_[2], A[1], c_ - 1u));                            \
+                if (GW == 4) my = max3u(my, sad_u32_s(p_[GW - 1], A[GW - 2], c_ - 2u), sad_u32_s(p_[GW], A[GW - 1], c_ - 3u)); \
+            }                                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < GW; k++) T[k] = p_[k + 1];                                            \
         }
-        atomicMax(&s_key[wave][tw][0], mx);
-        atomicMax(&s_key[wave][tw][1], my);
+        // three rows are in flight before the first one is needed and every step refills the slot it consumed.  The loop
+        // stays rolled: fully unrolled, the compiler hoists all TS + 2 row loads and the kernel drops to 2 waves / SIMD.
+        const uint32_t w_m1 = row_at(-1), w_0 = row_at(0);
+        uint32_t ring[3] = {row_at(1), row_at(2), row_at(3)};
+        VS_KF_STEP(w_m1, -1, r0, r0, false, false)
+        VS_KF_STEP(w_0, 0, r0, r1, true, false)
+        constexpr int TRIPLES = (TS - 1) / 3, REM = (TS - 1) % 3;
+        int j = 1;
+#pragma unroll 1
+        for (int t = 0; t < TRIPLES; t++, j += 3) {
+            VS_KF_STEP(ring[0], j, r0, r2, true, true)
+            ring[0] = row_at(j + 3);
+            VS_KF_STEP(ring[1], j + 1, r1, r0, true, true)
+            ring[1] = row_at(j + 4);
+            VS_KF_STEP(ring[2], j + 2, r2, r1, true, true)
+            ring[2] = row_at(j + 5);
+        }
+        // the rows left over (j = TS - REM .. TS - 1) and the row below the tile (j = TS: gy of the last row only)
+        if (REM == 0) {
+            VS_KF_STEP(ring[0], TS, r0, r2, false, true)
+        } else if (REM == 1) {
+            VS_KF_STEP(ring[0], TS - 1, r0, r2, true, true)
+            VS_KF_STEP(ring[1], TS, r1, r0, false, true)
+        } else {
+            VS_KF_STEP(ring[0], TS - 2, r0, r2, true, true)
+            VS_KF_STEP(ring[1], TS - 1, r1, r0, true, true)
+            VS_KF_STEP(ring[2], TS, r2, r1, false, true)
+        }
+#undef VS_KF_STEP
+        if (live) {
+            atomicMax(&s_key[wave][tw][0], mx - (unsigned)cx);     // key = (g << 16) | (0xffff - (ry * TS + cx + k))
+            atomicMax(&s_key[wave][tw][1], my - (unsigned)cx);
+        }
     }
     __syncthreads();
     if (live && g == 0) {
@@ -915,7 +925,7 @@ hipError_t keyframe(const uint8_t* img, int w, int h, int stride, int ts, uint16
     if (tx * ty == 0) return hipSuccess;
 #define VS_ROWS(TS)                                                                                                     \
     case TS: {                                                                                                          \
-        constexpr int tpw = 64 / (TS / ((TS % 4 == 0) ? 4 : 2));                                                        \
+        constexpr int tpw = keyframe_rows_tiles_per_wave(TS);                                                           \
         const int strips_x = cdiv(tx, tpw);                                                                             \
         hipLaunchKernelGGL(vs_k_keyframe_rows<TS>, dim3(cdiv(strips_x * ty, 4), n_frames), dim3(256), 0, s, img, w, h,  \
                            stride, tx, ty, lmx, lmy, jx, jy, img_fs, lm_fs, jac_fs, strips_x, aos);                     \
@@ -941,7 +951,7 @@ hipError_t keyframe_levels(const uint8_t* pyr, uint16_t* lm, float* jac, Keyfram
                            size_t jac_fs, hipStream_t s) {
     int total = 0;
     for (int i = 0; i < L.n; i++) {
-        const int ts = L.lv[i].ts, tpw = 64 / (ts / ((ts % 4 == 0) ? 4 : 2));
+        const int ts = L.lv[i].ts, tpw = keyframe_rows_tiles_per_wave(ts);
         L.lv[i].strips_x = cdiv(L.lv[i].tx, tpw);
         L.lv[i].blocks = cdiv(L.lv[i].strips_x * L.lv[i].ty, 4);
         total += L.lv[i].blocks;
