@@ -71,79 +71,91 @@ __device__ __forceinline__ void pyr_passes(const uint8_t (*tile)[PD_IWP], uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// pyr_down, row-walking form (the layout of vs_k_keyframe_rows): a wave owns a strip of 256 input columns and a band of
-// PR_OUT output rows; a lane owns 4 input columns = 2 output columns and walks down the 2*PR_OUT + 3 input rows of the
-// band.  Per input row: one aligned dword load (the wave reads 256 contiguous bytes), the two pixels to the left and the
-// one to the right from the neighbouring lanes (wave_shr / wave_shl DPP moves; fetched bytewise with clamp-to-edge at the
-// ends of the strip and of the image), five v_perm_b32 that pair the bytes up as {even, odd}-output operands, and the
-// horizontal 1-4-6-4-1 for both outputs at once in packed u16 (<= 4080).  The vertical 1-4-6-4-1 runs on a five-row
-// register window, again packed (<= 65280), every second input row; >> 8 is a byte pick.  No LDS, every input row is
-// read once (+ 3 halo rows per band), D rows in flight.  Integer arithmetic: the same bytes as pyr_passes above (which the
-// fused ingest kernel still runs on its LDS tile).
+// pyr_down, row-walking form (the layout of vs_k_keyframe_rows): a wave owns a strip of 248 input columns and a band of
+// PR_OUT output rows; lanes 1 .. n_live own 4 input columns = 2 output columns each and walk down the 2*PR_OUT + 3 input
+// rows of the band, lane 0 and lane n_live + 1 fetch the words that hold the strip's neighbour columns.  Per input row
+// every lane issues ONE dword load at (scalar row offset + its constant byte offset; words that would cross the right
+// image border start at w - 4 instead), the two pixels to the left and the one to the right come from the neighbouring
+// lanes (wave_shr / wave_shl DPP moves), and five v_perm_b32 pair the bytes up as {even, odd}-output operands -- their
+// selectors are per-lane constants fixed before the loop, which is where clamp-to-edge and the shifted border words are
+// resolved.  The horizontal 1-4-6-4-1 runs for both outputs at once in packed u16 (<= 4080), the vertical one on a
+// five-row register window, again packed (<= 65280), every second input row; >> 8 is a byte pick.  No LDS, every input
+// row is read once (+ 3 halo rows per band), D rows in flight.  Integer arithmetic: the same bytes as pyr_passes above
+// (which the fused ingest kernel still runs on its LDS tile).
 // ------------------------------------------------------------------------------------------------
 namespace {
 #ifndef VS_PR_OUT
 #define VS_PR_OUT 16
 #endif
 constexpr int PR_OUT = VS_PR_OUT;           // output rows per wave (batches); a single frame is cut into bands of 4 rows: 4x the waves, a quarter of the walk
+constexpr int PR_LIVE = 62;                 // lanes of a wave that produce outputs (two each)
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-struct PdRow { uint32_t own, left, right; };   // in(x0..x0+3); in(x0-2), in(x0-1) in bytes 2, 3; in(x0+4) in byte 0
 }
 
-__device__ __forceinline__ PdRow pd_fetch(const uint8_t* __restrict__ row, int x0, int w, bool own_fast, bool need_left, bool need_right) {
-    PdRow f{0, 0, 0};
-    if (own_fast) {
-        __builtin_memcpy(&f.own, row + x0, 4);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) f.own |= (uint32_t)row[min(x0 + k, w - 1)] << (8 * k);
-    }
-    if (need_left) f.left = ((uint32_t)row[max(x0 - 2, 0)] << 16) | ((uint32_t)row[max(x0 - 1, 0)] << 24);
-    if (need_right) f.right = row[min(x0 + 4, w - 1)];
-    return f;
-}
-// horizontal pass of one input row for the lane's two outputs: {h(ox), h(ox + 1)}
-__device__ __forceinline__ us2 pd_hsum(const PdRow f, bool need_left, bool need_right) {
-    uint32_t left = (uint32_t)dpp_mov0<0x138>((int)f.own);     // lane - 1: in(x0-4 .. x0-1)
-    uint32_t right = (uint32_t)dpp_mov0<0x130>((int)f.own);    // lane + 1: in(x0+4 .. x0+7)
-    if (need_left) left = f.left;
-    if (need_right) right = f.right;
-    // operand pairs {for output ox, for output ox+1} as two u16: taps -2..+2 around x0 and around x0+2
-    const us2 a = __builtin_bit_cast(us2, __builtin_amdgcn_perm(f.own, left, 0x0c040c02u));    // {in(x0-2), in(x0)}
-    const us2 b = __builtin_bit_cast(us2, __builtin_amdgcn_perm(f.own, left, 0x0c050c03u));    // {in(x0-1), in(x0+1)}
-    const us2 c = __builtin_bit_cast(us2, __builtin_amdgcn_perm(f.own, f.own, 0x0c020c00u));   // {in(x0),   in(x0+2)}
-    const us2 d = __builtin_bit_cast(us2, __builtin_amdgcn_perm(f.own, f.own, 0x0c030c01u));   // {in(x0+1), in(x0+3)}
-    const us2 e = __builtin_bit_cast(us2, __builtin_amdgcn_perm(right, f.own, 0x0c040c02u));   // {in(x0+2), in(x0+4)}
-    return (a + e) + (b + d) * (unsigned short)4 + c * (unsigned short)6;
-}
-
-template <int PR_OUT>
+template <int PR_OUT, bool NARROW>
 __global__ __launch_bounds__(256) void vs_k_pyr_down_rows(const uint8_t* __restrict__ in, int w, int h, int in_stride,
                                                           uint8_t* __restrict__ out, int ow, int oh, int out_stride,
                                                           size_t in_frame_stride, size_t out_frame_stride, int strips_x, int bands) {
     in += blockIdx.y * in_frame_stride;
     out += blockIdx.y * out_frame_stride;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int job = blockIdx.x * 4 + wave;
     if (job >= strips_x * bands) return;                     // whole wave
-    const int band = job / strips_x, strip = job - band * strips_x;
-    const int x0 = (strip * 64 + lane) * 4;                  // first input column of the lane = 2 * its first output column
-    const int ox = x0 >> 1, oy0 = band * PR_OUT;
-    if (ox >= ow) return;                                    // lanes right of the output (their data is not needed: the
-                                                             // last live lane fetches its right neighbour itself)
-    const int n_live = min(64, (ow - strip * 128 + 1) >> 1); // live lanes of this wave: outputs strip*128 .. ow-1, two per lane
-    const bool own_fast = x0 + 3 < w;
-    const bool need_left = lane == 0, need_right = lane == n_live - 1 || x0 + 4 >= w;
-    auto row_at = [&](int y) { return pd_fetch(in + (size_t)clampi(y, 0, h - 1) * in_stride, x0, w, own_fast, need_left, need_right); };
-    auto hsum_at = [&](const PdRow& f) { return pd_hsum(f, need_left, need_right); };
+    const int band = __builtin_amdgcn_readfirstlane(job / strips_x), strip = job - band * strips_x;
+    const int x_first = strip * (PR_LIVE * 4);               // first input column of the strip = 2 * its first output column
+    const int n_live = min(PR_LIVE, (ow - strip * (PR_LIVE * 2) + 1) >> 1);      // lanes 1 .. n_live: two outputs each
+    const int x0 = x_first + (lane - 1) * 4, ox = x0 >> 1, oy0 = band * PR_OUT;
+    const bool live = lane >= 1 && lane <= n_live;
+    // Words are dwords inside the row; an image narrower than a dword is read bytewise into clamp-extended words instead
+    // (wl: the width the word layout sees).
+    constexpr bool narrow = NARROW;                          // w < 4
+    const int wl = narrow ? (1 << 30) : w;
+    auto word_off = [&](int l) { return l <= 0 ? max(x_first - 4, 0) : min(x_first + (min(l, n_live + 1) - 1) * 4, wl - 4); };
+    const int off_o = word_off(lane), off_l = word_off(lane - 1), off_r = word_off(lane + 1);
+    // v_perm byte selector of clamped column c: out of the second operand (bytes 0..3, word at lo) if it lies there, else out
+    // of the first one (bytes 4..7, word at hi)
+    auto sel = [&](int c, int hi, int lo) -> unsigned {
+        c = min(max(c, 0), wl - 1);
+        const unsigned d = (unsigned)(c - lo);
+        return d < 4u ? d : 4u + ((unsigned)(c - hi) & 3u);
+    };
+    // operand pairs {for output ox, for output ox + 1} as two u16: taps -2 .. +2 around x0 and around x0 + 2
+    const unsigned sel_a = 0x0c000c00u | sel(x0 - 2, off_o, off_l) | (sel(x0, off_o, off_l) << 16);           // perm(own, left)
+    const unsigned sel_b = 0x0c000c00u | sel(x0 - 1, off_o, off_l) | (sel(x0 + 1, off_o, off_l) << 16);       // perm(own, left)
+    const unsigned sel_c = 0x0c000c00u | sel(x0, off_o, off_o) | (sel(x0 + 2, off_o, off_o) << 16);           // perm(own, own)
+    const unsigned sel_d = 0x0c000c00u | sel(x0 + 1, off_o, off_o) | (sel(x0 + 3, off_o, off_o) << 16);       // perm(own, own)
+    const unsigned sel_e = 0x0c000c00u | sel(x0 + 2, off_r, off_o) | (sel(x0 + 4, off_r, off_o) << 16);       // perm(right, own)
+    auto row_at = [&](int y) -> uint32_t {                   // the lane's word of input row y (clamped), y wave-uniform
+        int yc;
+        asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, %2" : "=&s"(yc) : "s"(__builtin_amdgcn_readfirstlane(y)), "s"(__builtin_amdgcn_readfirstlane(h - 1)) : "scc");
+        const uint8_t* rp = in + ((uint32_t)(yc * in_stride) + (uint32_t)off_o);      // (a level is far below 4 GB)
+        uint32_t v;
+        if (!narrow) { __builtin_memcpy(&v, rp, 4); return v; }
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)in[(uint32_t)(yc * in_stride) + (uint32_t)min(off_o + k, w - 1)] << (8 * k);
+        return v;
+    };
+    // horizontal pass of one input row for the lane's two outputs: {h(ox), h(ox + 1)}
+    auto hsum_at = [&](uint32_t own) -> us2 {
+        const uint32_t left = (uint32_t)dpp_mov0<0x138>((int)own);      // lane - 1
+        const uint32_t right = (uint32_t)dpp_mov0<0x130>((int)own);     // lane + 1
+        const us2 a = __builtin_bit_cast(us2, __builtin_amdgcn_perm(own, left, sel_a));     // {in(x0-2), in(x0)}
+        const us2 b = __builtin_bit_cast(us2, __builtin_amdgcn_perm(own, left, sel_b));     // {in(x0-1), in(x0+1)}
+        const us2 c = __builtin_bit_cast(us2, __builtin_amdgcn_perm(own, own, sel_c));      // {in(x0),   in(x0+2)}
+        const us2 d = __builtin_bit_cast(us2, __builtin_amdgcn_perm(own, own, sel_d));      // {in(x0+1), in(x0+3)}
+        const us2 e = __builtin_bit_cast(us2, __builtin_amdgcn_perm(right, own, sel_e));    // {in(x0+2), in(x0+4)}
+        return (a + e) + (b + d) * (unsigned short)4 + c * (unsigned short)6;
+    };
     // window of horizontal sums of input rows 2*oy-2 .. 2*oy+2; two new rows per output row
     const int iy0 = 2 * oy0 - 2;
     us2 h0 = hsum_at(row_at(iy0)), h1 = hsum_at(row_at(iy0 + 1)), h2 = hsum_at(row_at(iy0 + 2));
     constexpr int D = 4;
-    PdRow ring[D];
+    uint32_t ring[D];
 #pragma unroll
     for (int j = 0; j < D; j++) ring[j] = row_at(iy0 + 3 + j);
     const int rows_out = min(PR_OUT, oh - oy0);
+    const bool two = ox + 1 < ow;
 #pragma unroll 1
     for (int r0 = 0; r0 < rows_out; r0 += D / 2) {
 #pragma unroll
@@ -152,12 +164,14 @@ __global__ __launch_bounds__(256) void vs_k_pyr_down_rows(const uint8_t* __restr
             const us2 h3 = hsum_at(ring[2 * j]), h4 = hsum_at(ring[2 * j + 1]);
             ring[2 * j] = row_at(iy0 + 3 + 2 * r + D);
             ring[2 * j + 1] = row_at(iy0 + 4 + 2 * r + D);
-            if (r < rows_out) {
+            if (r < rows_out) {                              // uniform
                 const us2 v = (h0 + h4) + (h1 + h3) * (unsigned short)4 + h2 * (unsigned short)6;
                 const uint32_t packed = __builtin_amdgcn_perm(0u, __builtin_bit_cast(uint32_t, v), 0x0c0c0301u);   // {v.x >> 8, v.y >> 8}
-                uint8_t* dst = out + (size_t)(oy0 + r) * out_stride + ox;
-                if (ox + 1 < ow) { const uint16_t t = (uint16_t)packed; __builtin_memcpy(dst, &t, 2); }
-                else dst[0] = (uint8_t)packed;
+                uint8_t* dst = out + ((uint32_t)((oy0 + r) * out_stride) + (uint32_t)ox);
+                if (live) {
+                    if (two) { const uint16_t t = (uint16_t)packed; __builtin_memcpy(dst, &t, 2); }
+                    else dst[0] = (uint8_t)packed;
+                }
             }
             h0 = h2; h1 = h3; h2 = h4;
         }
@@ -858,16 +872,15 @@ hipError_t pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out
     if (ow <= 0 || oh <= 0 || n_frames <= 0) return hipSuccess;
     // a wave's walk is a chain of dependent row loads: with few frames in flight shorter bands finish sooner (one 960x540
     // frame: 21 -> 9 us), with many the long bands re-read fewer halo rows
-    const int strips_x = cdiv(ow, 128);
-    if (n_frames <= 4) {
-        const int bands = cdiv(oh, 4);
-        hipLaunchKernelGGL(vs_k_pyr_down_rows<4>, dim3(cdiv(strips_x * bands, 4), n_frames), dim3(256), 0, s, in, w, h, in_stride, out, ow,
-                           oh, out_stride, in_fs, out_fs, strips_x, bands);
-    } else {
-        const int bands = cdiv(oh, PR_OUT);
-        hipLaunchKernelGGL(vs_k_pyr_down_rows<PR_OUT>, dim3(cdiv(strips_x * bands, 4), n_frames), dim3(256), 0, s, in, w, h, in_stride, out, ow,
-                           oh, out_stride, in_fs, out_fs, strips_x, bands);
-    }
+    const int strips_x = cdiv(ow, 2 * PR_LIVE);
+    const int bands = cdiv(oh, n_frames <= 4 ? 4 : PR_OUT);
+    const dim3 grid(cdiv(strips_x * bands, 4), n_frames);
+#define VS_PD(ROWS, NARROW)                                                                                             \
+    hipLaunchKernelGGL((vs_k_pyr_down_rows<ROWS, NARROW>), grid, dim3(256), 0, s, in, w, h, in_stride, out, ow, oh, out_stride, in_fs, \
+                       out_fs, strips_x, bands)
+    if (n_frames <= 4) { if (w < 4) VS_PD(4, true); else VS_PD(4, false); }
+    else { if (w < 4) VS_PD(PR_OUT, true); else VS_PD(PR_OUT, false); }
+#undef VS_PD
     return hipGetLastError();
 }
 
