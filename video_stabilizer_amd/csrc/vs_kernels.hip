@@ -253,49 +253,34 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
     constexpr uint32_t kWHi = (3735u >> 8) | ((19235u >> 8) << 8) | ((9798u >> 8) << 16);
     const bool frame_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * sizeof(T))) & 3u) == 0;   // uniform
     const bool g0_aligned = ((((uintptr_t)g0) | (uintptr_t)w) & 3u) == 0;
-    for (int i = threadIdx.x; i < PD_IH * (PD_IW / 4); i += 256) {
-        const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
-        const int gy = clampi(iy0 + r, 0, h - 1), gx = ix0 + c4;
-        const T* row = src + (size_t)gy * src_stride;
-        uint32_t v;
-        if (frame_aligned && gx >= 0 && gx + 3 < w) {       // gx is a multiple of 4 pixels: 12 / 24 bytes, dword aligned
-            uint32_t g[4];
-            if (sizeof(T) == 1) {
-                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-                const u32x3 q = *(const u32x3*)((const uint8_t*)row + gx * 3);   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-                const uint32_t px[4] = {q.x, __builtin_amdgcn_alignbyte(q.y, q.x, 3), __builtin_amdgcn_alignbyte(q.z, q.y, 2), q.z >> 8};
+    // gray of the four pixels of one 12- / 24-byte group (dword aligned)
+    auto gray4 = [&](const uint32_t* q, uint32_t (&g)[4]) {
+        if (sizeof(T) == 1) {                                 // q: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            const uint32_t px[4] = {q[0], __builtin_amdgcn_alignbyte(q[1], q[0], 3), __builtin_amdgcn_alignbyte(q[2], q[1], 2), q[2] >> 8};
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t hi = __builtin_amdgcn_udot4(px[k], kWHi, 0u, false);
-                    const uint32_t lo = __builtin_amdgcn_udot4(px[k], kWLo, 16384u, false);
-                    g[k] = ((hi << 8) + lo) >> 15;            // <= 255 for 8-bit input: no clamp
-                    g[k] >>= shift_to_8;
-                }
-            } else {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 qa = *(const u32x4*)((const uint16_t*)row + gx * 3);          // B0G0 R0B1 G1R1 B2G2
-                const u32x2 qb = *(const u32x2*)((const uint16_t*)row + gx * 3 + 8);      // R2B3 G3R3
-                const uint32_t bg[4] = {qa.x, __builtin_amdgcn_alignbyte(qa.z, qa.y, 2), qa.w, __builtin_amdgcn_alignbyte(qb.y, qb.x, 2)};
-                const uint32_t rr[4] = {qa.y & 0xffffu, qa.z >> 16, qb.x & 0xffffu, qb.y >> 16};
-                constexpr uint32_t kWBG = 3735u | (19235u << 16);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                    const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bg[k]), __builtin_bit_cast(us2, kWBG), 16384u, false);
-                    g[k] = (t + rr[k] * 9798u) >> 15;
-                    g[k] >>= shift_to_8;
-                    g[k] = g[k] > 255u ? 255u : g[k];
-                }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t hi = __builtin_amdgcn_udot4(px[k], kWHi, 0u, false);
+                const uint32_t lo = __builtin_amdgcn_udot4(px[k], kWLo, 16384u, false);
+                g[k] = ((hi << 8) + lo) >> 15;                // <= 255 for 8-bit input: no clamp
+                g[k] >>= shift_to_8;
             }
-            v = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-        } else {
-            v = 0;
+        } else {                                              // q: B0G0 R0B1 G1R1 B2G2 | R2B3 G3R3
+            const uint32_t bg[4] = {q[0], __builtin_amdgcn_alignbyte(q[2], q[1], 2), q[3], __builtin_amdgcn_alignbyte(q[5], q[4], 2)};
+            const uint32_t rr[4] = {q[1] & 0xffffu, q[2] >> 16, q[4] & 0xffffu, q[5] >> 16};
+            constexpr uint32_t kWBG = 3735u | (19235u << 16);
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= gray_of(row + (size_t)clampi(gx + k, 0, w - 1) * 3, shift_to_8) << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const uint32_t t = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bg[k]), __builtin_bit_cast(us2, kWBG), 16384u, false);
+                g[k] = (t + rr[k] * 9798u) >> 15;
+                g[k] >>= shift_to_8;
+                g[k] = g[k] > 255u ? 255u : g[k];
+            }
         }
+    };
+    // level 0: the part of the staged tile that is this workgroup's own 128 x 32 block (rows 2..33, columns 4..131)
+    auto stage = [&](int r, int c4, int gx, uint32_t v) {
         *(uint32_t*)&tile[r][c4] = v;
-        // level 0: the part of the staged tile that is this workgroup's own 128 x 32 block (rows 2..33, columns 4..131)
         if (r >= 2 && r < 34 && c4 >= 4 && c4 < 132) {
             const int oy = iy0 + r, ox = gx;                  // = 2*y0 + (r-2), 2*x0 + (c4-4): never negative here
             if (oy < h && ox < w) {
@@ -306,6 +291,59 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
                     for (int k = 0; k < 4 && ox + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
                 }
             }
+        }
+    };
+    constexpr int N_ITEMS = PD_IH * (PD_IW / 4), N_IT = (N_ITEMS + 255) / 256, QW = sizeof(T) == 1 ? 3 : 6;
+    if (frame_aligned && w >= 4) {
+        // Every group of the footprint is ONE load of 12 / 24 bytes at a column clamped into the row (a group that hangs over
+        // the left / right image border reads the nearest full group instead and picks its clamped pixels afterwards), and
+        // all of a thread's loads are issued before the first conversion: five requests in flight per thread instead of one.
+        uint32_t q[N_IT][QW];
+#pragma unroll
+        for (int it = 0; it < N_IT; it++) {
+            const int i = min((int)threadIdx.x + it * 256, N_ITEMS - 1);
+            const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
+            const int gy = clampi(iy0 + r, 0, h - 1), gxc = clampi(ix0 + c4, 0, w - 4);
+            const uint32_t* gp = (const uint32_t*)(src + (size_t)gy * src_stride + (size_t)gxc * 3);
+            if (sizeof(T) == 1) {
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+                const u32x3 t = *(const u32x3*)gp;
+                q[it][0] = t.x; q[it][1] = t.y; q[it][2] = t.z;
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 ta = *(const u32x4*)gp;
+                const u32x2 tb = *(const u32x2*)(gp + 4);
+                q[it][0] = ta.x; q[it][1] = ta.y; q[it][2] = ta.z; q[it][3] = ta.w; q[it][QW - 2] = tb.x; q[it][QW - 1] = tb.y;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < N_IT; it++) {
+            const int i = (int)threadIdx.x + it * 256;
+            if (i < N_ITEMS) {
+                const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
+                const int gx = ix0 + c4, gxc = clampi(gx, 0, w - 4);
+                uint32_t g[4];
+                gray4(q[it], g);
+                uint32_t v = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+                if (gx != gxc) {                               // border group: pixel k = clamp(gx + k) of the row = byte clamp(gx + k) - gxc of v
+                    uint32_t sel = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sel |= (uint32_t)(clampi(gx + k, 0, w - 1) - gxc) << (8 * k);
+                    v = __builtin_amdgcn_perm(0u, v, sel);
+                }
+                stage(r, c4, gx, v);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < N_ITEMS; i += 256) {
+            const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
+            const int gy = clampi(iy0 + r, 0, h - 1), gx = ix0 + c4;
+            const T* row = src + (size_t)gy * src_stride;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= gray_of(row + (size_t)clampi(gx + k, 0, w - 1) * 3, shift_to_8) << (8 * k);
+            stage(r, c4, gx, v);
         }
     }
     __syncthreads();
