@@ -9,9 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from video_stabilizer_amd import capi, synth
 W, H, n = 1920, 1080, 6
-frames, _ = synth.make_clip_torch(W, H, n, seed=5, device=torch.device("cuda", 0))
+batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 0     # --batch 240: pair 0 of a full launch
+frames, _ = synth.make_clip_torch(W, H, max(n, batch), seed=5, device=torch.device("cuda", 0))
 torch.cuda.synchronize()
 al = capi.Aligner(device=0, pyramid_min_width=256)
+if batch:
+    for r in range(2):
+        sys.stderr.write(f"--- batch of {batch}, pass {r}\n"); sys.stderr.flush()
+        al.reset()
+        al.align_batch_device(frames.data_ptr(), batch, W, H, capi.FMT_BGR8)
+    sys.exit(0)
 for i in range(n):
     sys.stderr.write(f"--- frame {i}\n"); sys.stderr.flush()
     al.align_batch_device(frames[i].data_ptr(), 1, W, H, capi.FMT_BGR8)

@@ -293,47 +293,85 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
             }
         }
     };
-    constexpr int N_ITEMS = PD_IH * (PD_IW / 4), N_IT = (N_ITEMS + 255) / 256, QW = sizeof(T) == 1 ? 3 : 6;
+    constexpr int N_ITEMS = PD_IH * (PD_IW / 4), QW = sizeof(T) == 1 ? 3 : 6;
+    static_assert(PD_TW == 64 && PD_TH == 16, "the item layout below is written for a 35 x 34-group footprint around a 32 x 32-group block");
     if (frame_aligned && w >= 4) {
         // Every group of the footprint is ONE load of 12 / 24 bytes at a column clamped into the row (a group that hangs over
         // the left / right image border reads the nearest full group instead and picks its clamped pixels afterwards), and
-        // all of a thread's loads are issued before the first conversion: five requests in flight per thread instead of one.
-        uint32_t q[N_IT][QW];
+        // all of a thread's loads are issued before the first conversion: five requests in flight per thread.
+        // Items: the workgroup's own 32 x 32 groups (staged rows 2..33, groups 1..32) are four per thread -- row
+        // 2 + (tid >> 5) + 8 * it, group 1 + (tid & 31): no index arithmetic, no range tests, level 0 is written from them;
+        // the 166 halo groups (rows 0, 1, 34 and the two side columns) are a fifth item of the first 166 threads.
+        const int tid = (int)threadIdx.x;
+        // packs the grays of four pixels; u8: g = byte 2 of 2 * (B*3735 + G*19235 + R*9798 + 16384) with the weights split as
+        // (w >> 7) * 256 + 2 * (w & 127) -- two v_dot4_u32_u8 and one shift-add per pixel, three v_perm_b32 per group
+        auto gray_word = [&](const uint32_t* q) -> uint32_t {
+            if (sizeof(T) == 1) {
+                constexpr uint32_t kH = (3735u >> 7) | ((19235u >> 7) << 8) | ((9798u >> 7) << 16);
+                constexpr uint32_t kL = (2u * (3735u & 127u)) | ((2u * (19235u & 127u)) << 8) | ((2u * (9798u & 127u)) << 16);
+                const uint32_t px[4] = {q[0], __builtin_amdgcn_alignbyte(q[1], q[0], 3), __builtin_amdgcn_alignbyte(q[2], q[1], 2), q[2] >> 8};
+                uint32_t t[4];
 #pragma unroll
-        for (int it = 0; it < N_IT; it++) {
-            const int i = min((int)threadIdx.x + it * 256, N_ITEMS - 1);
-            const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
-            const int gy = clampi(iy0 + r, 0, h - 1), gxc = clampi(ix0 + c4, 0, w - 4);
-            const uint32_t* gp = (const uint32_t*)(src + (size_t)gy * src_stride + (size_t)gxc * 3);
+                for (int k = 0; k < 4; k++)
+                    t[k] = (__builtin_amdgcn_udot4(px[k], kH, 0u, false) << 8) + __builtin_amdgcn_udot4(px[k], kL, 32768u, false);
+                const uint32_t t01 = __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0602u), t23 = __builtin_amdgcn_perm(t[3], t[2], 0x0c0c0602u);
+                return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+            }
+            uint32_t g[4];
+            gray4(q, g);
+            return g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+        };
+        auto load_group = [&](uint32_t (&q)[QW], int gy, int gxc) {
+            const uint32_t* gp = (const uint32_t*)((const uint8_t*)src + (uint32_t)((gy * src_stride + gxc * 3) * (int)sizeof(T)));   // (a frame is below 4 GB)
             if (sizeof(T) == 1) {
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 const u32x3 t = *(const u32x3*)gp;
-                q[it][0] = t.x; q[it][1] = t.y; q[it][2] = t.z;
+                q[0] = t.x; q[1] = t.y; q[2] = t.z;
             } else {
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 ta = *(const u32x4*)gp;
                 const u32x2 tb = *(const u32x2*)(gp + 4);
-                q[it][0] = ta.x; q[it][1] = ta.y; q[it][2] = ta.z; q[it][3] = ta.w; q[it][QW - 2] = tb.x; q[it][QW - 1] = tb.y;
+                q[0] = ta.x; q[1] = ta.y; q[2] = ta.z; q[3] = ta.w; q[QW - 2] = tb.x; q[QW - 1] = tb.y;
+            }
+        };
+        // border group: pixel k = clamp(gx + k) of the row = byte clamp(gx + k) - gxc of the packed word
+        auto border_sel = [&](int gx, int gxc) {
+            uint32_t sel = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sel |= (uint32_t)(clampi(gx + k, 0, w - 1) - gxc) << (8 * k);
+            return sel;
+        };
+        const int r_own = 2 + (tid >> 5), c_own = 1 + (tid & 31);
+        const int gx_own = ix0 + 4 * c_own, gxc_own = min(gx_own, w - 4);                 // gx_own = 2 * x0 + 4 * (tid & 31) >= 0
+        int r_h, c_h;                                                                     // the halo item
+        if (tid < 3 * 34) { const int k = (tid >= 34) + (tid >= 68); r_h = k == 2 ? PD_IH - 1 : k; c_h = tid - 34 * k; }
+        else { const int t = min(tid - 3 * 34, 63); r_h = 2 + (t >> 1); c_h = (t & 1) * 33; }
+        const bool has_halo = tid < N_ITEMS - 1024;
+        const int gx_h = ix0 + 4 * c_h, gxc_h = clampi(gx_h, 0, w - 4);
+        uint32_t q[5][QW];
+#pragma unroll
+        for (int it = 0; it < 4; it++) load_group(q[it], min(iy0 + r_own + 8 * it, h - 1), gxc_own);
+        load_group(q[4], clampi(iy0 + r_h, 0, h - 1), gxc_h);
+        const bool own_border = gx_own != gxc_own, own_dword = g0_aligned && gx_own + 3 < w;
+        const uint32_t own_sel = border_sel(gx_own, gxc_own);
+        uint32_t* const tile_w = (uint32_t*)&tile[0][0];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            uint32_t v = gray_word(q[it]);
+            if (own_border) v = __builtin_amdgcn_perm(0u, v, own_sel);
+            const int r = r_own + 8 * it, oy = iy0 + r;                                   // level-0 row 2 * y0 + (r - 2)
+            tile_w[r * (PD_IWP / 4) + c_own] = v;
+            if (oy < h && gx_own < w) {
+                uint8_t* dst = g0 + (uint32_t)(oy * w + gx_own);
+                if (own_dword) *(uint32_t*)dst = v;
+                else for (int k = 0; k < 4 && gx_own + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
             }
         }
-#pragma unroll
-        for (int it = 0; it < N_IT; it++) {
-            const int i = (int)threadIdx.x + it * 256;
-            if (i < N_ITEMS) {
-                const int r = i / (PD_IW / 4), c4 = (i - r * (PD_IW / 4)) * 4;
-                const int gx = ix0 + c4, gxc = clampi(gx, 0, w - 4);
-                uint32_t g[4];
-                gray4(q[it], g);
-                uint32_t v = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-                if (gx != gxc) {                               // border group: pixel k = clamp(gx + k) of the row = byte clamp(gx + k) - gxc of v
-                    uint32_t sel = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) sel |= (uint32_t)(clampi(gx + k, 0, w - 1) - gxc) << (8 * k);
-                    v = __builtin_amdgcn_perm(0u, v, sel);
-                }
-                stage(r, c4, gx, v);
-            }
+        if (has_halo) {
+            uint32_t v = gray_word(q[4]);
+            if (gx_h != gxc_h) v = __builtin_amdgcn_perm(0u, v, border_sel(gx_h, gxc_h));
+            tile_w[r_h * (PD_IWP / 4) + c_h] = v;
         }
     } else {
         for (int i = threadIdx.x; i < N_ITEMS; i += 256) {
