@@ -410,7 +410,7 @@ def test_stabilizer_process_clips_equals_fresh_stabilizers(gpu_vs):
 
 
 @pytest.mark.parametrize("bits", [8, 10])
-@pytest.mark.parametrize("w,h", [(323, 247), (258, 130), (1283, 99), (256, 96), (131, 129)])
+@pytest.mark.parametrize("w,h", [(323, 247), (258, 130), (1283, 99), (256, 96), (131, 129), (128, 96), (129, 97), (127, 95), (260, 96), (385, 99)])
 def test_ingest_pyramid_bit_exact_on_awkward_sizes(gpu_vs, oracle, w, h, bits):
     """the fused BGR -> gray level 0 + level 1 kernel and the row-walking pyr_down behind it: every pyramid level of a frame
     equals the oracle's, for widths that are not multiples of 4 / 128 / 256, odd heights, and both frame depths (the 16-bit

@@ -29,10 +29,13 @@ def test_pyr_down_bit_exact(gpu_vs, oracle, w, h):
 
 
 @pytest.mark.parametrize("w,h", [(2, 2), (3, 2), (4, 4), (5, 7), (7, 5), (8, 3), (9, 9), (254, 17), (255, 18), (256, 19), (257, 33), (258, 34), (259, 35),
-                                 (511, 64), (513, 66), (1027, 5), (130, 257)])
+                                 (511, 64), (513, 66), (1027, 5), (130, 257),
+                                 (245, 9), (246, 9), (247, 9), (248, 9), (249, 9), (250, 9), (251, 9), (252, 10), (253, 11), (495, 5), (496, 5), (497, 5),
+                                 (499, 7), (743, 6), (744, 6), (745, 6), (6, 40), (4, 33)])
 def test_pyr_down_strip_and_band_boundaries(gpu_vs, oracle, w, h):
-    """the row-walking kernel's seams: strips of 256 input columns, bands of 16 output rows, widths that are not a multiple
-    of 4 (byte-assembled last group), 1- and 2-lane strips, images smaller than the 5x5 window"""
+    """the row-walking kernel's seams: strips of 248 input columns (62 lanes of 4 + two halo lanes; 256 until round 2), bands
+    of 16 output rows, widths that are not a multiple of 4 (the last words start at w - 4 and the per-lane byte selectors pick
+    the clamped columns), 1- and 2-lane strips, images narrower than a dword (bytewise variant) or smaller than the 5x5 window"""
     img = _noise(w, h, w * 131 + h)
     assert np.array_equal(gpu_vs.pyr_down(img), oracle.pyr_down(img))
 
@@ -109,10 +112,11 @@ def test_keyframe_fused_equals_three_stage_oracle(gpu_vs, oracle, w, h):
 
 
 @pytest.mark.parametrize("ts", [2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 3, 7, 21, 24, 64])
-@pytest.mark.parametrize("w,h", [(324, 250), (257, 131), (1283, 97)])
+@pytest.mark.parametrize("w,h", [(324, 250), (257, 131), (1283, 97), (240, 64), (243, 61), (249, 40), (483, 23), (124, 21), (127, 22)])
 def test_keyframe_fused_every_tile_size(gpu_vs, oracle, ts, w, h):
     """the ten strip kernels (the reference's tile sizes, CMakeLists.txt:212-253) and the generic kernel (any other size),
-    on widths that leave partial strips, unaligned rows and remainder columns; tie-heavy content (values 0..7)"""
+    on widths that leave partial strips, unaligned rows and remainder columns, and on widths at the strips' seams (a wave carries
+    62 / (ts / 4 or 2) tiles: 240 or 248 columns for most sizes, 124 for ts = 2); tie-heavy content (values 0..7)"""
     if ts > min(w, h):
         pytest.skip("tile larger than the image")
     rng = np.random.default_rng(ts * 1000 + w)
