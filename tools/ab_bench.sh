@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/scratch/ab.sh <variant.so> [rounds]   -- alternates the default library and a variant in one run
+# (A/B of two builds of the library on ONE box: devices differ by several percent, so every comparison alternates the two)
+# usage: tools/ab_bench.sh <variant.so> [rounds]   -- alternates the default library and a variant in one run
 V="$1"; R="${2:-2}"
 run() { python bench.py --no-cpu-baseline --no-roofline-4k --no-host-fed --steps 10 --warmup 3 2>/dev/null | python -c "
 import sys, json
