@@ -77,6 +77,14 @@ def test_sixteen_pairs_in_one_launch_equal_the_plain_launch():
     assert _run(1920, 1080, 17, True) == plain
 
 
+def test_mid_size_launch_shares_the_idle_cus():
+    # 17 .. 128 pairs: as many workgroups per pair as keep the launch within one per CU (40 pairs -> 6 per pair), descriptors
+    # and states through device memory (the direct form stops at 16 pairs)
+    plain = _run(1920, 1080, 41, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
+    assert sum(r[0] for r in plain) == 40
+    assert _run(1920, 1080, 41, True) == plain
+
+
 def test_polled_and_synchronised_completion_agree():
     assert _run(1920, 1080, 4, False, VS_GN_POLL=0) == _run(1920, 1080, 4, False)
 

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void vs_k_gather_selected(const PairState* __r
 constexpr int kMaxDevices = 64;              // devices the per-device launch caches index; beyond that they are bypassed
 constexpr int kCoopGroup = 16;         // workgroups per pair in latency mode (1080p: 8 and 16 alike; 4K: 16 is 3 % faster)
 constexpr int kCoopMaxGroup = 16;
-constexpr int kCoopMaxPairs = 16;      // latency mode for launches of at most this many pairs
+constexpr int kCoopMaxPairs = 128;     // helpers for launches of at most this many pairs (16 per pair up to 16 pairs, then as many as keep the launch within one workgroup per CU)
+constexpr int kChipCUs = 256;
 constexpr int kCoopMinTiles = 4096;    // levels with at least this many tiles are shared
 struct CoopLevel {
     int t_ready, nslices, pad[2];
@@ -494,8 +495,8 @@ int vs_aligner::ensure_capacity(int n) {
     VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
     VS_HIP(hipMalloc((void**)&wv, (size_t)newcap * 2 * nt_max * sizeof(float) * 2));   // samples of all pairs, then template pixels
     VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 28));
-    VS_HIP(hipMalloc((void**)&coop, kCoopMaxPairs * coop_pair_bytes(nt_max)));
-    VS_HIP(hipMemset(coop, 0, kCoopMaxPairs * coop_pair_bytes(nt_max)));
+    VS_HIP(hipMalloc((void**)&coop, std::min(newcap, kCoopMaxPairs) * coop_pair_bytes(nt_max)));
+    VS_HIP(hipMemset(coop, 0, std::min(newcap, kCoopMaxPairs) * coop_pair_bytes(nt_max)));
     coop_epoch = 0;
     VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
     VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
@@ -751,7 +752,8 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
             static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
             int group = 1;
-            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles) group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : kCoopGroup;
+            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles)
+                group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : std::max(1, std::min(kCoopGroup, kChipCUs / n_pairs));
             const int epoch = ++coop_epoch;
             PairDescPack dpack{};
             if (direct) for (int q = 0; q < n_pairs; q++) dpack.d[q] = hd[q];
