@@ -40,6 +40,44 @@ def test_pyr_down_strip_and_band_boundaries(gpu_vs, oracle, w, h):
     assert np.array_equal(gpu_vs.pyr_down(img), oracle.pyr_down(img))
 
 
+@pytest.mark.parametrize("w,h,pad_in,pad_out", [(250, 37, 3, 5), (124, 20, 1, 0), (1283, 21, 13, 7), (3, 9, 2, 1)])
+def test_pyr_down_and_keyframe_through_padded_rows(gpu_vs, oracle, w, h, pad_in, pad_out):
+    """the operator entry points take row strides (imgproc.hpp's buffers may be crops of larger images): rows that start at odd
+    addresses, outputs with a pitch of their own; the padding bytes must neither be read into the result nor written"""
+    import ctypes
+    rng = np.random.default_rng(w * 17 + h)
+    big = rng.integers(0, 256, (h, w + pad_in), dtype=np.uint8)
+    img = np.ascontiguousarray(big[:, :w])
+    ow, oh = w // 2, h // 2
+    out = np.full((oh, ow + pad_out), 0xA5, np.uint8)
+    lib = gpu_vs.lib()
+    assert lib.vs_pyr_down(big.ctypes.data_as(ctypes.c_void_p), w, h, w + pad_in, out.ctypes.data_as(ctypes.c_void_p), ow, oh,
+                           ow + pad_out, gpu_vs.MEM_HOST, None) == 0
+    assert np.array_equal(out[:, :ow], oracle.pyr_down(img))
+    assert (out[:, ow:] == 0xA5).all()
+    if w >= 8:
+        ts = gpu_vs.tile_size(w, h)
+        tx, ty = w // ts, h // ts
+        lmx, lmy = np.empty((2, ty, tx), np.uint16), np.empty((2, ty, tx), np.uint16)
+        jx, jy = np.empty((4, ty, tx), np.float32), np.empty((4, ty, tx), np.float32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.vs_keyframe_fused(P(big), w, h, w + pad_in, ts, P(lmx), P(lmy), P(jx), P(jy), gpu_vs.MEM_HOST, None) == 0
+        _, wlx, wly, wjx, wjy = gpu_vs.keyframe_fused(img)
+        assert np.array_equal(lmx, wlx) and np.array_equal(lmy, wly) and np.array_equal(jx, wjx) and np.array_equal(jy, wjy)
+        # bgr_image_warp and bgr_to_gray into a crop of a larger host image: the pixels right of every row stay untouched
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        t = gpu_vs.Transform.of(0.004, -0.003, 1.25, -0.75)
+        for mode in (gpu_vs.WARP_LANCZOS2, gpu_vs.WARP_BILINEAR):
+            dst = np.full((h, (w + pad_out) * 3), 0x5A, np.uint8)
+            assert lib.vs_bgr_image_warp(P(bgr), w, h, 3 * w, 3, 8, ctypes.byref(t), mode, gpu_vs.BORDER_CLAMP, 255, P(dst), 3 * (w + pad_out),
+                                         gpu_vs.MEM_HOST, None) == 0
+            assert np.array_equal(dst[:, :3 * w].reshape(h, w, 3), gpu_vs.bgr_image_warp(bgr, t, mode=mode))
+            assert (dst[:, 3 * w:] == 0x5A).all()
+        gray = np.full((h, w + pad_out), 0x5A, np.uint8)
+        assert lib.vs_bgr_to_gray(P(bgr), w, h, 3 * w, 8, 0, P(gray), w + pad_out, gpu_vs.MEM_HOST, None) == 0
+        assert np.array_equal(gray[:, :w], gpu_vs.bgr_to_gray(bgr)) and (gray[:, w:] == 0x5A).all()
+
+
 def test_pyr_down_known_answers(gpu_vs):
     # SURVEY 8c-1: impulse responses of the integer form (sum w_i w_j in) >> 8
     img = np.zeros((32, 32), np.uint8)

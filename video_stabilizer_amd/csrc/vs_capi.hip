@@ -41,8 +41,19 @@ int Staged::out(void* ptr, size_t n, int mem) {
     dev = buf.p;
     return VS_OK;
 }
+int Staged::out_image(void* ptr, size_t row_bytes_, size_t rows_, size_t pitch_, size_t frames_, size_t frame_pitch_, int mem) {
+    const size_t n = frames_ == 0 || rows_ == 0 ? 0 : (frames_ - 1) * frame_pitch_ + (rows_ - 1) * pitch_ + row_bytes_;
+    const int r = out(ptr, n, mem);
+    const bool dense = pitch_ == row_bytes_ && (frames_ <= 1 || frame_pitch_ == rows_ * pitch_);
+    if (r == VS_OK && staged && !dense) { row_bytes = row_bytes_; rows = rows_; pitch = pitch_; frames = frames_; frame_pitch = frame_pitch_; }
+    return r;
+}
 int Staged::finish(hipStream_t s) {
-    if (staged && is_out && bytes) VS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    if (!(staged && is_out && bytes)) return VS_OK;
+    if (rows == 0) { VS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s)); return VS_OK; }
+    for (size_t f = 0; f < frames; f++)           // pitched: the bytes between the rows stay as the caller had them
+        VS_HIP(hipMemcpy2DAsync((char*)host + f * frame_pitch, pitch, (const char*)dev + f * frame_pitch, pitch, row_bytes, rows,
+                                hipMemcpyDeviceToHost, s));
     return VS_OK;
 }
 
@@ -156,7 +167,7 @@ int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, in
     hipStream_t s = (hipStream_t)stream;
     Staged a, b;
     VS_TRY(a.in(in, img_span(w, h, in_stride, 1), mem, s));
-    VS_TRY(b.out(out, img_span(ow, oh, out_stride, 1), mem));
+    VS_TRY(b.out_image(out, (size_t)ow, (size_t)oh, (size_t)out_stride, 1, 0, mem));
     VS_HIP(vsk::pyr_down(a.as<uint8_t>(), w, h, in_stride, b.as<uint8_t>(), ow, oh, out_stride, 1, 0, 0, s));
     VS_TRY(b.finish(s));
     return finish_host(mem, s);
@@ -342,9 +353,8 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     VS_TRY(ring->upload(P.data(), (size_t)n_frames, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
-    const size_t out_bytes = ((size_t)(n_frames - 1) * dst_fs + img_span(roi.w, roi.h, dst_stride, channels)) * osz;
     VS_TRY(a.in(src, in_bytes, mem, s));
-    VS_TRY(o.out(dst, out_bytes, mem));
+    VS_TRY(o.out_image(dst, (size_t)roi.w * channels * osz, (size_t)roi.h, (size_t)dst_stride * osz, (size_t)n_frames, dst_fs * osz, mem));
     hipError_t e = hipErrorNotSupported;
     if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
         e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
@@ -393,7 +403,7 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
     hipStream_t s = (hipStream_t)stream;
     Staged a, o;
     VS_TRY(a.in(src, img_span(w, h, src_stride, 3) * (bits / 8), mem, s));
-    VS_TRY(o.out(dst, img_span(w, h, dst_stride, 1), mem));
+    VS_TRY(o.out_image(dst, (size_t)w, (size_t)h, (size_t)dst_stride, 1, 0, mem));
     VS_HIP(vsk::bgr_to_gray(a.dev, w, h, src_stride, bits, shift_to_8, o.as<uint8_t>(), dst_stride, 1, 0, 0, s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);

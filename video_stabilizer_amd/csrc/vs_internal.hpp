@@ -49,7 +49,11 @@ struct Staged {
     bool is_out = false, staged = false;
     int in(const void* ptr, size_t n, int mem, hipStream_t s);
     int out(void* ptr, size_t n, int mem);
+    // an image output: `frames` images of `rows` rows of `row_bytes` bytes, `pitch` bytes from row to row and `frame_pitch` from
+    // image to image.  Only the rows' own bytes travel back: the padding between them may be the caller's neighbouring pixels.
+    int out_image(void* ptr, size_t row_bytes, size_t rows, size_t pitch, size_t frames, size_t frame_pitch, int mem);
     int finish(hipStream_t s);   // D2H for staged outputs (async; caller syncs)
+    size_t row_bytes = 0, rows = 0, pitch = 0, frames = 0, frame_pitch = 0;   // set by out_image (pitch != row_bytes or gaps between frames)
     template <typename T> T* as() const { return (T*)dev; }
 };
 
