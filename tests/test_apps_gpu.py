@@ -232,3 +232,13 @@ def test_video_test_10bit_y4m(gpu_vs, tmp_path):
         got_y = np.frombuffer(raw, "<u2", w * h, pos + 6).reshape(h, w)
         assert np.array_equal(got_y, wy[k]), k
         pos += 6 + fsz
+
+
+def test_latency_harness_aligns_every_frame_of_its_clip(gpu_vs, clip):
+    """apps/vs_latency: the reference's one-frame-per-call pattern from C++ (what profiles/r02_latency_cpp.txt is measured with);
+    here only that it runs, aligns its seeded clip and reports a sane iteration count"""
+    import json
+    for args in ((640, 360, 8, 128), (1920, 1080, 4, 256)):
+        out = json.loads(run("vs_latency", *args).strip().splitlines()[-1])
+        assert out["w"] == args[0] and out["frames"] == args[2] and out["aligned"] == args[2] - 1
+        assert 3 <= out["gn_iterations_per_frame"] <= 60 and out["ms_per_call"] > 0
