@@ -5,7 +5,8 @@ import csv
 import glob
 import sys
 
-for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+import os
+for f in sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:   # the newest pass only
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):

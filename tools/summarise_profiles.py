@@ -18,7 +18,9 @@ N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 def counters(d, kernel="warp_c3"):
     agg, ids = collections.defaultdict(float), set()
-    for f in glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True):
+    # (gpurun merges every call's output into the local scratch directory: only the newest pass of a directory counts)
+    files = sorted(glob.glob(os.path.join(SRC, d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -28,7 +30,7 @@ def counters(d, kernel="warp_c3"):
 
 
 for wl in ("c2", "c3"):
-    f = glob.glob(os.path.join(SRC, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True)[0]
+    f = sorted(glob.glob(os.path.join(SRC, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "vs_k_" in r[0] or "vsp" in r[0]]     # the library's kernels (torch's generator kernels dropped)
     with open(os.path.join(DST, "r02_bench_%s_kernel_stats.csv" % wl), "w", newline="") as o:
