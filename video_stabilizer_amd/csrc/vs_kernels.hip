@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void vs_k_keyframe(const uint8_t* __restrict__
 // v_perm_b32 and each arg-max key (|a - b| << 16) | (0xffff - (ry * TS + k)) is ONE v_sad_u32 whose addend is a scalar
 // register (the row term is wave-uniform); a lane's column offset is subtracted once after the loop, which gives the
 // tile-scan key of the generic kernel.  The TS / GW lanes of a tile meet in an LDS atomic max.
-// Round 2: 43 -> 21 vector instructions per row and lane (the border loads, their branches and the 64-bit address
+// Round 2: 43 -> 23 vector instructions per row and lane (the border loads, their branches and the 64-bit address
 // arithmetic went away).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned sad_u32_s(unsigned a, unsigned b, unsigned c) {      // |a - b| + c, c wave-uniform
