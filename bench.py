@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     ap.add_argument("--no-roofline-4k", action="store_true", help="skip the isolated 32 x 4K bgr_image_warp measurement")
+    ap.add_argument("--exclusive-solver", action="store_true", help="keep the solver kernel in VS_BATCH_EXCLUSIVE mode inside the overlapped step")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-resident (PCIe-inclusive) alignment measurement")
     args = ap.parse_args()
 
@@ -296,6 +297,10 @@ def main():
                                select_mode=capi.SELECT_DEVICE if args.select == "device" else capi.SELECT_STL_HOST, **params_kw)
         warped = torch.empty_like(all_frames)
         N = n_clips * n
+        # the timed step overlaps the warp of pass k with the alignment of pass k+1 (two streams): full batches go through the
+        # small-footprint build of the solver kernel, which shares CUs with the warp grid (bit-identical results)
+        if not args.no_warp and not args.exclusive_solver:
+            aligner.set_batch_mode(capi.BATCH_SHARED)
 
         def step(timed, warp_mode=None):
             # all clips of the rank in one call (vs_aligner_align_clips): every stage is one launch over all clips
@@ -341,12 +346,15 @@ def main():
         # second, separately reported figure: the alignment stages alone (BASELINE configs[1] read literally)
         def fn():
             aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
+        aligner.set_batch_mode(capi.BATCH_EXCLUSIVE)          # nothing else runs: one 512-thread workgroup per pair
         aligner.enable_timing(True)
         dt_a, _ = timed_loop(fn, args.steps)
         dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=red_dev)
         align_only = (dt_a, frames_a, aligner.timings())
 
     fast_warp = None
+    if aligner and not args.no_warp and not args.exclusive_solver:
+        aligner.set_batch_mode(capi.BATCH_SHARED)
     if aligner and not args.no_warp and args.warp_mode == "exact":
         # third figure: the same step with the tolerance-gated warp arithmetic (VS_WARP_LANCZOS2_FAST: within the north star's
         # "1 ULP of the Lanczos path", tests/test_warp_fast_gpu.py) -- reported beside `value`, never as `value`

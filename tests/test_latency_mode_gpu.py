@@ -7,6 +7,8 @@ a process of its own; the frames come from the same seeded generator.
   default  (unset)                             pipelined loop + 16 workgroups per pair for <= 16 pairs
   few      VS_GN_HELPERS=2 / 3                 few, large slices: several staging passes per helper
   sync     VS_GN_POLL=0                        completion through hipStreamSynchronize instead of the polled result block
+  cores    VS_GN_CORESIDENT=1 / 0              the small-footprint build of the fused kernel (256 hardware threads standing in for
+                                               the 512 of the plain build: virtual threads) / the plain build for a full batch
 """
 import json
 import os
@@ -27,7 +29,8 @@ torch.cuda.init()
 from video_stabilizer_amd import capi, synth
 w, h, n, batch = (int(a) for a in sys.argv[2:6])
 frames, _ = synth.make_clip(w, h, n, seed=77, channels=3)
-al = capi.Aligner(device=0, pyramid_min_width=256)
+al = capi.Aligner(device=0, pyramid_min_width=int(sys.argv[6]) if len(sys.argv) > 6 else 256)
+if len(sys.argv) > 7 and int(sys.argv[7]): al.set_batch_mode(capi.BATCH_SHARED)
 out = []
 def rec(i, st, t):
     inf = al.info(i)
@@ -44,12 +47,12 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(w, h, n, batch, **env):
+def _run(w, h, n, batch, pmw=256, shared=0, **env):
     e = dict(os.environ)
-    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS", "VS_GN_POLL"):
+    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS", "VS_GN_POLL", "VS_GN_CORESIDENT"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
-    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch))], env=e, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch)), str(pmw), str(int(shared))], env=e, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -104,3 +107,29 @@ def test_a_helper_that_never_reports_back_costs_a_timeout_not_a_hang():
     plain = _run(1920, 1080, 3, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1)
     stalled = _run(1920, 1080, 3, False, VS_GN_STALL_HELPERS=1)
     assert stalled == plain
+
+
+def test_coresident_build_equals_the_plain_launch_bit_for_bit():
+    # the 256-thread build walks the virtual threads / waves of the 512-thread build: same additions, same order, same bits --
+    # transforms, iteration counts, condition numbers, failure codes
+    plain = _run(1920, 1080, 5, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    assert sum(r[0] for r in plain) == 4
+    assert _run(1920, 1080, 5, True, VS_GN_CORESIDENT=1) == plain
+    # one frame at a time through the small build too (direct descriptors, polled result block)
+    assert _run(1920, 1080, 5, False, VS_GN_CORESIDENT=1) == _run(1920, 1080, 5, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+
+
+def test_shared_mode_full_batch_equals_the_plain_launch():
+    # vs_aligner_set_batch_mode(VS_BATCH_SHARED), more than 128 pairs: the small-footprint build; 640x480 with the reference's default pyramid keeps the
+    # clip small (5 levels of 1200 / 300 tiles per set)
+    plain = _run(640, 480, 140, True, pmw=20, VS_GN_CORESIDENT=0)
+    assert sum(r[0] for r in plain) >= 130
+    assert _run(640, 480, 140, True, pmw=20, shared=1) == plain
+    assert _run(640, 480, 140, True, pmw=20, VS_GN_CORESIDENT=1) == plain
+
+
+def test_coresident_build_on_odd_sizes_and_default_pyramid():
+    # 1280x720 with pyramid_min_width 256: 3 levels, tile sizes 20 / 14 / 6 with remainder pixels, 2304 / 1125 / 1590 tiles per
+    # set -- every level selects both sets side by side, 128 hardware threads each
+    plain = _run(1280, 720, 6, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    assert _run(1280, 720, 6, True, VS_GN_CORESIDENT=1) == plain

@@ -20,6 +20,7 @@ FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the s
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE = 0, 1
+BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1
 
 
 class Transform(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "vs_aligner_create": (_vp, [C.POINTER(AlignerParams), _i32]),
     "vs_aligner_destroy": (None, [_vp]),
     "vs_aligner_set_select_mode": (_i32, [_vp, _i32]),
+    "vs_aligner_set_batch_mode": (_i32, [_vp, _i32]),
     "vs_aligner_reset": (_i32, [_vp]),
     "vs_aligner_align_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP]),
     "vs_aligner_align_batch": (_i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP, C.POINTER(C.c_int32)]),
@@ -479,6 +481,11 @@ class Aligner:
         if not self.h:
             raise VsError("vs_aligner_create failed: %s" % lib().vs_last_error().decode())
         _check(lib().vs_aligner_set_select_mode(self.h, select_mode))
+
+    def set_batch_mode(self, mode):
+        """BATCH_SHARED: full batches run through the small-footprint solver kernel (same bits; for callers that overlap
+        other GPU work, e.g. the previous clip's warp)"""
+        _check(lib().vs_aligner_set_batch_mode(self.h, mode))
 
     def align_next(self, frame, fmt=None):
         """frame: numpy (h,w) u8 gray, (h,w,3) u8/u16 BGR (u16 = 10-bit unless fmt says FMT_BGR12 / FMT_BGR16_FULL).

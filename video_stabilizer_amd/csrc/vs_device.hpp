@@ -351,6 +351,17 @@ __device__ __forceinline__ void wave_partials(const double v[K], LP lds) {
     }
 }
 
+// the same with the slot given by the caller (a hardware wave standing in for virtual wave `slot`, vs_align_kernels.inc)
+template <int K, typename LP = double*>
+__device__ __forceinline__ void wave_partials_at(const double v[K], LP lds, int slot) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) lds[slot * K + k] = s;
+    }
+}
+
 // Eight sums over the wave at once: a butterfly that halves the number of values a lane carries at each of the first three
 // steps (lane pairs at distance 1, 2, 4 exchange the half the partner keeps), then three steps on the one value that is
 // left -- 10 fp64 additions per lane instead of the 48 of eight separate wave_sum trees.  Lanes 0..7 end up holding the

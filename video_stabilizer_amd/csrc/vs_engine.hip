@@ -244,16 +244,38 @@ struct FusedLevels {
 // slower with half the threads) and is the default for every level size; VS_SMALL_WG_TILES (build time) sends larger levels
 // to the 1024-thread build.
 namespace nt1024 {
-constexpr int kGnThreads = 1024;
+constexpr int kGnThreads = 1024, kGnVirt = 1024;
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(kGnThreads)
 #include "vs_align_kernels.inc"
+#undef VS_GN_FUSED_BOUNDS
 }  // namespace nt1024
 #ifndef VS_NT_SMALL
 #define VS_NT_SMALL 512
 #endif
 namespace nt512 {
-constexpr int kGnThreads = VS_NT_SMALL;
+constexpr int kGnThreads = VS_NT_SMALL, kGnVirt = VS_NT_SMALL;
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(kGnThreads)
 #include "vs_align_kernels.inc"
+#undef VS_GN_FUSED_BOUNDS
 }  // namespace nt512
+// Small-footprint build of the fused kernel for full batches (DESIGN.md "co-residency"): 256 hardware threads stand in for the
+// 512 of nt512 (virtual threads: bit-identical sums), at most 128 VGPRs (4 waves per SIMD) and ~33 KB of LDS (selection arrays
+// of one point set; no staged image) -- the footprint of ONE bgr_image_warp workgroup, so a pair's workgroup moves into a CU as
+// soon as one warp workgroup leaves it and the alignment of clip k+1 runs under the warp launch of clip k instead of waiting
+// for whole CUs to drain.  Levels of up to 64 * 256 tiles (1080p: 5184; a 4K level 0 has 20736 and stays with nt512).
+#if VS_NT_SMALL == 512
+namespace nt256v {
+constexpr int kGnThreads = 256, kGnVirt = 512;
+#ifndef VS_NT256_MINWAVES
+#define VS_NT256_MINWAVES 4
+#endif
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(256, VS_NT256_MINWAVES)
+#include "vs_align_kernels.inc"
+#undef VS_GN_FUSED_BOUNDS
+}  // namespace nt256v
+#define VS_HAVE_NT256V 1
+#endif
+constexpr int kCoResidentMaxTiles = 64 * 256;
 #ifndef VS_SMALL_WG_TILES
 #define VS_SMALL_WG_TILES 26000
 #endif
@@ -292,6 +314,7 @@ struct vs_aligner {
     hipStream_t stream = nullptr;
     vs_aligner_params params;
     int select_mode = VS_SELECT_DEVICE;   // same survivors in the same order as the host path (tests/test_select_gpu.py)
+    int batch_mode = VS_BATCH_EXCLUSIVE;  // VS_BATCH_SHARED: full batches through the small-footprint solver kernel
 
     // sequence state (alignment.hpp:61-70)
     int W = -1, H = -1, fmt = -1;
@@ -736,28 +759,47 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 if (both <= 150 * 1024) dyn = std::max(dyn, (both + 15) & ~(size_t)15);
             }
             const bool small_wg = nt_max <= kSmallWgTiles;
+            // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
+            static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
+            int group = 1;
+            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles)
+                group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : std::max(1, std::min(kCoopGroup, kChipCUs / n_pairs));
+            // full batches of a handle in VS_BATCH_SHARED mode: the small-footprint build (shares CUs with whatever else is
+            // running, e.g. the previous clip's warp launch); VS_GN_CORESIDENT=0 / 1 overrides the rule (1: every launch, helpers off)
+            bool cores = false;
+#ifdef VS_HAVE_NT256V
+            static const int cores_env = []() { const char* e = getenv("VS_GN_CORESIDENT"); return e ? atoi(e) : -1; }();
+            cores = small_wg && nt_max <= kCoResidentMaxTiles &&
+                    (cores_env >= 0 ? cores_env != 0 : (batch_mode == VS_BATCH_SHARED && n_pairs > kCoopMaxPairs));
+            if (cores) {
+                group = 1;
+                dyn = 0;
+                for (int l = 0; l < levels; l++) {
+                    const size_t nt = (size_t)L[l].nt;
+                    dyn = std::max(dyn, ((nt <= 32 * (nt256v::kGnThreads / 2) ? nt * 12 : nt * 6) + 15) & ~(size_t)15);
+                }
+            }
+            const auto kernel = cores ? nt256v::vs_k_align_pairs : (small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs);
+#else
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
+#endif
+            const int kthreads = cores ? 256 : (small_wg ? nt512::kGnThreads : nt1024::kGnThreads);
             {   // The limit belongs to (kernel, device) and is shared by every handle of the process: it is only ever raised,
                 // and only when a launch needs more than was granted before (the call costs microseconds of host time).
                 static std::mutex dyn_mu;
-                static size_t dyn_set[2][kMaxDevices];
+                static size_t dyn_set[3][kMaxDevices];
                 std::lock_guard<std::mutex> g(dyn_mu);
-                size_t& granted = dyn_set[small_wg ? 0 : 1][std::min(std::max(device, 0), kMaxDevices - 1)];
+                size_t& granted = dyn_set[cores ? 2 : (small_wg ? 0 : 1)][std::min(std::max(device, 0), kMaxDevices - 1)];
                 if (granted < dyn || device >= kMaxDevices) {
                     VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(dyn, granted)));
                     granted = std::max(dyn, granted);
                 }
             }
             t_begin(VS_STAGE_GN);
-            // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
-            static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
-            int group = 1;
-            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles)
-                group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : std::max(1, std::min(kCoopGroup, kChipCUs / n_pairs));
             const int epoch = ++coop_epoch;
             PairDescPack dpack{};
             if (direct) for (int q = 0; q < n_pairs; q++) dpack.d[q] = hd[q];
-            hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s,
+            hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(kthreads), dyn, s,
                                direct ? h_states : states, descs, pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn,
                                fl, gp, group, coop, epoch, wv, dpack, direct ? 1 : 0);
             VS_HIP(hipGetLastError());
@@ -918,6 +960,12 @@ void vs_aligner_destroy(vs_aligner* a) {
 int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
     VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE));
     a->select_mode = mode;
+    return VS_OK;
+}
+
+int vs_aligner_set_batch_mode(vs_aligner* a, int mode) {
+    VS_ARG(a && (mode == VS_BATCH_EXCLUSIVE || mode == VS_BATCH_SHARED));
+    a->batch_mode = mode;
     return VS_OK;
 }
 

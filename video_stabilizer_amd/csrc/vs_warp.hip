@@ -321,6 +321,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi) {
     __shared__ f4 tile[WS_H * WS_RS];                      // {B,G,R,1} per staged source pixel
+#ifdef VS_WARP_LDS_PAD
+    __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
+    if (w < 0) lds_pad[threadIdx.x] = 0;
+#endif
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id order and
     // gridDim.x is a multiple of 8, so workgroup b of a frame works on its tile (b % 8) * chunk + b / 8: every XCD walks
     // one contiguous run of tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
