@@ -213,6 +213,11 @@ typedef struct vs_align_info {
     int32_t iterations[16];
     double  condition[16];
     double  phase_dx, phase_dy, phase_response;   /* cv::phaseCorrelate result of the pair (phase_correlate only, else 0) */
+    /* the custom metrics of the reference's PerformanceMetrics (alignment.cpp:489-490 "SelectedPointsX_/Y_<level>") and the
+     * estimate each level ended on (centre-based, that level's pixels, before the x2 of TX,TY at :683-687): set for every
+     * level the pair reached; a level that ran out of iterations (fail_reason 2) leaves its transform 0 */
+    int32_t selected_x[16], selected_y[16];
+    vs_transform level_transform[16];
 } vs_align_info;
 
 vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);

@@ -51,7 +51,7 @@ class AlignDebug(C.Structure):
                 ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
 
 
-WARP_LANCZOS2, WARP_BILINEAR = 0, 1
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4
@@ -98,6 +98,8 @@ def lib():
         "vso_transform_warp_center": (Point, [TP, Point, f64, f64]),
         "vso_transform_max_corner_displacement": (f64, [TP, f64, f64]),
         "vso_select_smallest": (i32, [vp, i32, i32, f32, vp]),
+        "vso_nth_element_killer": (i32, [i32, i32, f32, vp]),
+        "vso_nth_element_hits_depth_limit": (i32, [vp, i32, f32]),
         "vso_hessian": (None, [vp, i32, vp, i32, vp]),
         "vso_condition_and_invert": (f64, [vp, vp]),
         "vso_optimal_dft_size": (i32, [i32]),
@@ -337,6 +339,20 @@ def select_smallest(warpdiff, fraction=0.8):
     idx = np.empty(tx * ty, np.int32)
     n = lib().vso_select_smallest(_p(wd), tx, ty, fraction, _p(idx))
     return idx[:n].copy()
+
+
+def nth_element_killer(tx, ty, fraction=0.8):
+    """(ty, tx) uint16 table on which std::nth_element(begin, begin + n*fraction, end) runs out of its depth budget"""
+    out = np.empty((ty, tx), np.uint16)
+    r = lib().vso_nth_element_killer(tx, ty, fraction, _p(out))
+    if r < 0:
+        raise ValueError("table does not fit 16 bits")
+    return out
+
+
+def nth_element_hits_depth_limit(warpdiff, fraction=0.8):
+    wd = _c(warpdiff, np.uint16)
+    return bool(lib().vso_nth_element_hits_depth_limit(_p(wd), wd.size, fraction))
 
 
 def optimal_dft_size(n):

@@ -93,6 +93,52 @@ inline float lanczos_sample(const ImageRef<T>& img, float Wx, float Wy, int c) {
     return sum_num / sum_den;
 }
 
+/* VSO_WARP_LANCZOS2_CONTRACTED -- the same sampler as the reference's own build target would round it.  The reference
+ * compiles its generators for "x86-64-...-fma-..." (CMakeLists.txt:151) and never asks for strict_float (no occurrence in
+ * the tree), so LLVM is free to contract a multiply into the add that consumes it (Halide emits its float arithmetic with
+ * the contract flag unless strict_float is requested; Halide's source is not in this container, so this is stated from its
+ * published behaviour, not from a file here).  Applied to the expression trees as written:
+ *   lanczos2 (generators.cpp:38-44)   "c + val * x2"  ->  fma(val, x2, c), six times; x2 = x * x and the select unchanged
+ *   sum_num  (generators.cpp:694)     "+= w_2d * val" ->  fma(w_2d, val, sum_num), w_2d = wx * wy a rounded product (:687)
+ *   sum_den  (generators.cpp:695)     "+= w_2d"       ->  sum_den + w_2d (no multiply of its own to fuse)
+ *   sum_num / sum_den                 one IEEE divide (:697)
+ * Same tap order (rxy.x inner, rxy.y outer), same accumulators from 0, same sampling position as the un-contracted form:
+ * the two modes differ only in where the sampler rounds.  std::fmaf is exact-then-round-once by definition, so this
+ * function means the same on every machine. */
+inline float lanczos2_contracted(float x) {
+    float x2 = x * x;
+    float val = 0.000858519f;
+    val = std::fmaf(val, x2, -0.0158853f);
+    val = std::fmaf(val, x2, 0.128693f);
+    val = std::fmaf(val, x2, -0.583468f);
+    val = std::fmaf(val, x2, 1.52229f);
+    val = std::fmaf(val, x2, -2.05238f);
+    val = std::fmaf(val, x2, 0.999861f);
+    return std::fabs(x) >= 2.0f ? 0.0f : val;
+}
+template <typename T, bool CONSTANT_BORDER>
+inline float lanczos_sample_contracted(const ImageRef<T>& img, float Wx, float Wy, int c) {
+    float floorWx = std::floor(Wx), floorWy = std::floor(Wy);
+    float fracWx = Wx - floorWx, fracWy = Wy - floorWy;
+    float wx[5], wy[5];
+    for (int u = 0; u < 5; u++) {
+        wx[u] = lanczos2_contracted((float)(u - 2) - fracWx);
+        wy[u] = lanczos2_contracted((float)(u - 2) - fracWy);
+    }
+    int ix = (int)floorWx, iy = (int)floorWy;
+    float sum_num = 0.0f, sum_den = 0.0f;
+    for (int ry = 0; ry < 5; ry++) {
+        for (int rx = 0; rx < 5; rx++) {
+            float w2d = wx[rx] * wy[ry];
+            float val = CONSTANT_BORDER ? img.constant0(ix + rx - 2, iy + ry - 2, c)
+                                        : img.clamped(ix + rx - 2, iy + ry - 2, c);
+            sum_num = std::fmaf(w2d, val, sum_num);
+            sum_den = sum_den + w2d;
+        }
+    }
+    return sum_num / sum_den;
+}
+
 /* image_warp's bilinear sampler (generators.cpp:148-163).  Halide float lerp(a,b,t) is
  * a*(1-t) + b*t. */
 inline float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
@@ -133,6 +179,9 @@ void bgr_warp_impl(const T* src, int w, int h, int src_stride, int channels,
                 if (mode == VSO_WARP_LANCZOS2)
                     v = border == VSO_BORDER_CONSTANT ? lanczos_sample<T, true>(img, Wx, Wy, c)
                                                       : lanczos_sample<T, false>(img, Wx, Wy, c);
+                else if (mode == VSO_WARP_LANCZOS2_CONTRACTED)
+                    v = border == VSO_BORDER_CONSTANT ? lanczos_sample_contracted<T, true>(img, Wx, Wy, c)
+                                                      : lanczos_sample_contracted<T, false>(img, Wx, Wy, c);
                 else
                     v = border == VSO_BORDER_CONSTANT ? bilinear_sample<T, true>(img, Wx, Wy, c)
                                                       : bilinear_sample<T, false>(img, Wx, Wy, c);
@@ -478,6 +527,70 @@ int vso_select_smallest(const uint16_t* warpdiff, int tx, int ty, float fraction
     v.resize(selected_count);
     for (size_t i = 0; i < v.size(); i++) out_idx[i] = (int32_t)v[i].tile_y * tx + v[i].tile_x;
     return (int)selected_count;
+}
+
+/* Test-input generator: a warpdiff table on which std::nth_element(begin, begin + n*fraction, end) -- this libstdc++'s, the
+ * call above -- runs out of its introselect depth budget (2 * lg n partitions) and falls back to heap-select.  McIlroy's
+ * adversary ("A Killer Adversary for Quicksort", 1999): the algorithm runs on item ids whose values are decided lazily --
+ * unfrozen items count as larger than every frozen one, and when two unfrozen items meet, the one last seen as a pivot
+ * candidate is frozen at the next smallest value -- so every median-of-3 pivot ends up among the smallest of its range and a
+ * partition peels off a constant number of elements.  The frozen values, replayed as data, make the same comparisons come out
+ * the same way.  Returns the number of distinct values used (the rest share the value `n_solid`), or -1 if the table would not fit
+ * 16 bits.  The product's on-device replica must flag exactly these inputs (tests/test_select_gpu.py). */
+int vso_nth_element_killer(int tx, int ty, float fraction, uint16_t* out) {
+    const int n = tx * ty;
+    if (n < 1 || n > 65535) return -1;
+    const int gas = n + 1;
+    std::vector<int> val((size_t)n, gas), item((size_t)n);
+    for (int i = 0; i < n; i++) item[i] = i;
+    int nsolid = 0, candidate = 0;
+    auto cmp = [&](int x, int y) {
+        if (val[x] == gas && val[y] == gas) { if (x == candidate) val[x] = nsolid++; else val[y] = nsolid++; }
+        if (val[x] == gas) candidate = x; else if (val[y] == gas) candidate = y;
+        return val[x] < val[y];
+    };
+    const size_t selected_count = static_cast<size_t>((size_t)n * fraction);
+    std::nth_element(item.begin(), item.begin() + selected_count, item.end(), cmp);
+    for (int i = 0; i < n; i++) out[i] = (uint16_t)(val[i] == gas ? nsolid : val[i]);
+    return nsolid;
+}
+
+/* How many partition rounds libstdc++'s introselect spends on a table before it stops (range <= 3) or gives up: counted by
+ * running the same call with a comparator that watches for the median-of-3 pattern is fragile, so this restates the control
+ * flow of bits/stl_algo.h __introselect literally (depth budget 2 * lg n, __unguarded_partition_pivot = median of first+1 /
+ * mid / last-1 to first, Hoare partition of [first+1, last)) on a copy of the keys and reports 1 when the budget reaches 0
+ * with more than 3 elements left -- the condition under which std::nth_element calls __heap_select. */
+int vso_nth_element_hits_depth_limit(const uint16_t* warpdiff, int n, float fraction) {
+    std::vector<uint16_t> a(warpdiff, warpdiff + n);
+    const long nth = (long)static_cast<size_t>((size_t)n * fraction);
+    if (n == 0 || nth == n) return 0;
+    long first = 0, last = n;
+    int depth = 0;
+    for (long m = n; m > 1; m >>= 1) depth++;
+    depth *= 2;
+    while (last - first > 3) {
+        if (depth == 0) return 1;
+        --depth;
+        const long mid = first + (last - first) / 2, ia = first + 1, ib = mid, ic = last - 1;
+        long m;
+        if (a[ia] < a[ib]) m = (a[ib] < a[ic]) ? ib : ((a[ia] < a[ic]) ? ic : ia);
+        else if (a[ia] < a[ic]) m = ia;
+        else if (a[ib] < a[ic]) m = ic;
+        else m = ib;
+        std::swap(a[first], a[m]);
+        long i = first + 1, j = last;
+        const uint16_t pv = a[first];
+        for (;;) {
+            while (a[i] < pv) ++i;
+            --j;
+            while (pv < a[j]) --j;
+            if (!(i < j)) break;
+            std::swap(a[i], a[j]);
+            ++i;
+        }
+        if (i <= nth) first = i; else last = i;
+    }
+    return 0;
 }
 
 /* alignment.cpp:278-332.  jac planar (n,4): element (i,c) at c*n+i */

@@ -57,7 +57,9 @@ typedef struct vso_stabilizer_params {
     int    warp_border;  /* VSO_BORDER_* */
 } vso_stabilizer_params;
 
-enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1 };
+/* VSO_WARP_LANCZOS2_CONTRACTED: the Lanczos2 sampler with the multiply-adds fused where the reference's own target
+ * (CMakeLists.txt:151 "fma", no strict_float) lets LLVM fuse them -- the twin of the product's VS_WARP_LANCZOS2_FAST */
+enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1, VSO_WARP_LANCZOS2_CONTRACTED = 2 };
 enum { VSO_BORDER_CLAMP = 0, VSO_BORDER_CONSTANT = 1 };
 enum { VSO_FMT_GRAY8 = 0, VSO_FMT_BGR8 = 1, VSO_FMT_BGR10 = 2, VSO_FMT_BGR16 = 2, VSO_FMT_BGR12 = 3, VSO_FMT_BGR16_FULL = 4 };
 /* worker threads for the row-parallel loops of the image-sized stages (CPU-baseline timing only; results do not depend on it) */
@@ -122,6 +124,11 @@ double        vso_transform_max_corner_displacement(const vso_transform* t, doub
 /* std::nth_element on {abs_delta,tile_x,tile_y} exactly as alignment.cpp:438-486 (libstdc++).
  * Writes the kept tile indices (tile_y*tx+tile_x) in the post-nth_element order. Returns count. */
 int  vso_select_smallest(const uint16_t* warpdiff, int tx, int ty, float fraction, int32_t* out_idx);
+/* test inputs for the selection: a table on which this libstdc++'s std::nth_element exhausts its introselect depth budget
+ * (McIlroy's adversary run against the very call above), and a literal restatement of __introselect's control flow that says
+ * whether a table does so */
+int  vso_nth_element_killer(int tx, int ty, float fraction, uint16_t* out);
+int  vso_nth_element_hits_depth_limit(const uint16_t* warpdiff, int n, float fraction);
 void vso_hessian(const float* jacx, int nx, const float* jacy, int ny, double H[16]); /* :278-332 */
 /* cond / Tikhonov / pseudo-inverse (:555-583).  OpenCV SVD is replaced by a cyclic Jacobi
  * eigen-solver (H is symmetric PSD).  Returns the condition number. */

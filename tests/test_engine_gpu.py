@@ -38,6 +38,9 @@ def _check_seq(res):
             for l in range(dbg.levels):
                 if dbg.iterations[l]:
                     assert abs(inf.condition[l] - dbg.condition[l]) <= 1e-9 * dbg.condition[l]
+                # the reference's PerformanceMetrics custom metrics (alignment.cpp:489-490) and the estimate each level ended on
+                assert (inf.selected_x[l], inf.selected_y[l]) == (dbg.selected_x[l], dbg.selected_y[l]), (i, l)
+                assert _cmp_transform(inf.level_transform[l], dbg.level_transform[l]) < TOL, (i, l, inf.level_transform[l].tup(), dbg.level_transform[l].tup())
 
 
 def test_c1_gray_pair_640x480(gpu_vs, oracle):

@@ -35,7 +35,8 @@ out = []
 def rec(i, st, t):
     inf = al.info(i)
     out.append([int(st), [float(x).hex() for x in t.tup()], int(inf.fail_reason), [int(x) for x in inf.iterations[:inf.levels]],
-                [float(c).hex() for c in inf.condition[:inf.levels]]])
+                [float(c).hex() for c in inf.condition[:inf.levels]],
+                [[float(x).hex() for x in inf.level_transform[l].tup()] for l in range(inf.levels)], list(inf.selected_x[:inf.levels])])
 if batch:
     st, ts = al.align_batch(frames)
     for i in range(n): rec(i, st[i], ts[i])
@@ -49,7 +50,7 @@ print("RESULT " + json.dumps(out))
 
 def _run(w, h, n, batch, pmw=256, shared=0, **env):
     e = dict(os.environ)
-    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS", "VS_GN_POLL", "VS_GN_CORESIDENT"):
+    for k in ("VS_GN_PIPELINE", "VS_GN_HELPERS", "VS_GN_STALL_HELPERS", "VS_GN_POLL", "VS_GN_CORESIDENT", "VS_GN_SELECT_DEPTH"):
         e.pop(k, None)
     e.update({k: str(v) for k, v in env.items()})
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(w), str(h), str(n), str(int(batch)), str(pmw), str(int(shared))], env=e, capture_output=True, text=True,
@@ -133,3 +134,16 @@ def test_coresident_build_on_odd_sizes_and_default_pyramid():
     # set -- every level selects both sets side by side, 128 hardware threads each
     plain = _run(1280, 720, 6, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
     assert _run(1280, 720, 6, True, VS_GN_CORESIDENT=1) == plain
+
+
+def test_depth_limit_exit_is_redone_on_the_host_with_the_same_result():
+    # fail_reason 100 ("libstdc++ would have heap-selected": tests/test_select_gpu.py shows real tables that do it) sends the
+    # whole chunk through the per-level path with the host's std::nth_element.  With the on-device budget cut to 3 rounds (test
+    # hook) every ordinary pair takes that exit; transforms, iteration counts, condition numbers, per-level transforms must
+    # equal the plain run -- one pair at a time, a small batch, a full batch (both kernel builds)
+    plain = _run(1920, 1080, 5, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    assert _run(1920, 1080, 5, True, VS_GN_SELECT_DEPTH=3) == plain
+    assert _run(1920, 1080, 5, False, VS_GN_SELECT_DEPTH=3) == _run(1920, 1080, 5, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    assert _run(1920, 1080, 5, True, VS_GN_SELECT_DEPTH=3, VS_GN_CORESIDENT=1) == plain
+    big = _run(640, 480, 140, True, pmw=20, VS_GN_CORESIDENT=0)
+    assert _run(640, 480, 140, True, pmw=20, VS_GN_SELECT_DEPTH=2) == big

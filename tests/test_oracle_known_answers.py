@@ -319,6 +319,101 @@ def test_bgr_warp_lanczos_equals_sparse_sampler(oracle):
         assert np.array_equal(np.floor(np.abs(f[ys, xs])).astype(np.uint16), wd)
 
 
+def _round_f32(q):
+    """a Fraction rounded to the nearest float32, ties to even -- exact integer arithmetic, no intermediate double"""
+    from fractions import Fraction
+    if q == 0:
+        return np.float32(0.0)
+    sign = -1 if q < 0 else 1
+    q = abs(q)
+    e = q.numerator.bit_length() - q.denominator.bit_length()          # 2^(e-1) < q < 2^(e+1)
+    if Fraction(2) ** e > q:
+        e -= 1                                                             # now 2^e <= q < 2^(e+1)
+    e = max(e, -126)                                                       # subnormals share the exponent of the smallest normal
+    scaled = q / Fraction(2) ** (e - 23)                                   # the significand as a rational in [2^23, 2^24)
+    n, rem = divmod(scaled.numerator, scaled.denominator)
+    twice = 2 * rem
+    if twice > scaled.denominator or (twice == scaled.denominator and (n & 1)):
+        n += 1
+    return np.float32(sign * float(Fraction(n) * Fraction(2) ** (e - 23)))    # n * 2^(e-23) is a float32 value: exact in a double
+
+
+def test_contracted_lanczos2_twin_equals_a_literal_restatement_with_exact_fma(oracle):
+    # VSO_WARP_LANCZOS2_CONTRACTED = generators.cpp:31-47 + :684-697 with the multiply-adds fused where LLVM may fuse them on the
+    # reference's target (CMakeLists.txt:151: "fma", no strict_float anywhere): c + val*x2 -> fma(val, x2, c); sum_num += w2d*val
+    # -> fma(w2d, val, sum_num); w2d = wx*wy, sum_den += w2d and the divide as written.  Restated here with an fma that is
+    # exact by construction (rationals, one rounding), independent of std::fmaf and of the machine.
+    from fractions import Fraction as F
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return _round_f32(F(float(a)) * F(float(b)) + F(float(c)))
+
+    def lz(x):
+        x = f32(x)
+        x2 = f32(x * x)
+        v = f32(0.000858519)
+        for c in (-0.0158853, 0.128693, -0.583468, 1.52229, -2.05238, 0.999861):
+            v = fma(v, x2, f32(c))
+        return f32(0.0) if abs(x) >= 2.0 else v
+
+    rng = np.random.default_rng(11)
+    h, w = 7, 9
+    src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    src[2, 3] = (255, 0, 255)
+    src[3, 3] = (0, 255, 0)
+    for border in (oracle.BORDER_CLAMP, oracle.BORDER_CONSTANT):
+        t = oracle.Transform.of(0.03, -0.02, 0.7, -1.3)
+        got = oracle.bgr_image_warp(src, t, oracle.WARP_LANCZOS2_CONTRACTED, border, f32=True)
+        p = oracle.ul_params_warp(t, w, h)
+        A, B, TX, TY = (f32(v) for v in p)
+        A1 = f32(f32(1.0) + A)
+        for y in range(h):
+            for x in range(w):
+                Wx = f32(f32(f32(A1 * f32(x)) - f32(B * f32(y))) + TX)          # generators.cpp:141 (un-contracted: same positions as VSO_WARP_LANCZOS2)
+                Wy = f32(f32(f32(B * f32(x)) + f32(A1 * f32(y))) + TY)
+                flx, fly = f32(np.floor(Wx)), f32(np.floor(Wy))
+                frx, fry = f32(Wx - flx), f32(Wy - fly)
+                wx = [lz(f32(f32(u - 2) - frx)) for u in range(5)]
+                wy = [lz(f32(f32(u - 2) - fry)) for u in range(5)]
+                for c in range(3):
+                    num, den = f32(0.0), f32(0.0)
+                    for ry in range(5):
+                        for rx in range(5):
+                            sx, sy = int(flx) + rx - 2, int(fly) + ry - 2
+                            if border == oracle.BORDER_CONSTANT and (sx < 0 or sy < 0 or sx >= w or sy >= h):
+                                val = f32(0.0)
+                            else:
+                                val = f32(src[min(max(sy, 0), h - 1), min(max(sx, 0), w - 1), c])
+                            w2d = f32(wx[rx] * wy[ry])
+                            num = fma(w2d, val, num)
+                            den = f32(den + w2d)
+                    assert f32(num / den) == got[y, x, c], (border, y, x, c)
+    # ... and it is a different function from the un-contracted mode (else the twin would test nothing), within one LSB of it
+    big = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    t = oracle.Transform.of(0.01, 0.004, 2.3, -1.6)
+    e = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2, f32=True)
+    k = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2_CONTRACTED, f32=True)
+    assert not np.array_equal(e, k) and np.abs(e - k).max() < 1e-3
+    ei = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2).astype(int)
+    ki = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2_CONTRACTED).astype(int)
+    assert np.abs(ei - ki).max() <= 1
+
+
+def test_round_f32_helper():
+    from fractions import Fraction as F
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        a, b, c = (np.float32(v) for v in rng.normal(size=3) * 10.0 ** rng.integers(-3, 4))
+        exact = F(float(a)) * F(float(b)) + F(float(c))
+        r = _round_f32(exact)
+        lo, hi = np.nextafter(r, np.float32(-np.inf)), np.nextafter(r, np.float32(np.inf))
+        assert abs(F(float(r)) - exact) <= abs(F(float(lo)) - exact) and abs(F(float(r)) - exact) <= abs(F(float(hi)) - exact)
+    assert _round_f32(F(1) + F(1, 2 ** 24)) == np.float32(1.0)                     # tie -> even
+    assert _round_f32(F(1) + F(3, 2 ** 24)) == np.float32(1.0) + np.float32(2.0 ** -22)   # tie -> even (up)
+    assert _round_f32(F(1, 2 ** 149)) == np.float32(2.0 ** -149) and _round_f32(F(1, 2 ** 151)) == np.float32(0.0)
+
+
 def test_bgr_warp_store_rule_round_half_up_saturate(oracle):
     src = np.zeros((8, 8, 1), np.uint8)
     src[:, 4:] = 255

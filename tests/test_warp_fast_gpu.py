@@ -1,128 +1,70 @@
-"""VS_WARP_LANCZOS2_FAST (the tolerance-gated arithmetic of bgr_image_warp) against the oracle and against an fp64
-evaluation of the same sampler.
+"""VS_WARP_LANCZOS2_FAST = the contracted form of the Lanczos2 sampler, against its CPU twin -- bit for bit.
 
-Gate = SURVEY 8(d) / north star "warped pixels within 1 ULP of the Lanczos path":
-  * float output:  |x - value| <= K * eps * (sum|w*v| / |sum w| + max|v| in the window)   (eps = 2^-23, the fp32 ULP of 1.0)
-    SURVEY 8(d) writes the scale as sum|w*v| / |sum w| alone; that form assumes exact weights and is violated by the
-    ORACLE ITSELF by factors of 10^2..10^4 in dark pixels beside bright ones (see sampler_f64), so the window maximum is
-    added.  The reference's own Halide pipeline is not strict-float ("fp32 parity definition"): the CPU
-    oracle's order of roundings is one member of a family defined only up to this bound.  The test therefore checks the
-    fast kernel against the fp64 value of the sampler (same fp32 coordinates; weights and sums in double) with the SAME
-    constant K the oracle itself needs, and against the oracle with 2K.
-  * integer outputs: at most 1 LSB from the exact mode, >= 99.99 % of the values identical (8-bit and 10-bit).
-The float path goes through vs_bgr_image_warp_f32 (generic kernel) and the integer path through the tuned c3 kernels;
-both call the same vs_device.hpp functions for the fast arithmetic.
+The reference compiles its generators for a target with FMA and without strict_float (CMakeLists.txt:151; no `strict_float`
+in the tree), so on the reference's own machine LLVM may fuse a multiply into the add that consumes it.  The oracle's
+VSO_WARP_LANCZOS2_CONTRACTED restates generators.cpp:31-47 / :684-697 with exactly those fusions (std::fmaf) and is pinned by
+a literal restatement with an exact rational fma (tests/test_oracle_known_answers.py).  The product's fast mode computes the
+same sequence of roundings on the GPU: every comparison below is np.array_equal -- float output (generic kernel) and
+integer outputs (tuned c3 kernels, LDS path and global path), 8- and 10-bit, both borders.  No tolerance anywhere.
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-EPS = 2.0 ** -23
-K_TRUTH = 32.0     # measured on MI355X (run with -s): the oracle itself needs 18..24 on these inputs, the fast kernel 12..14
-C6 = [np.float32(c) for c in (0.000858519, -0.0158853, 0.128693, -0.583468, 1.52229, -2.05238, 0.999861)]
-
-
-def lanczos2_f64(x32):
-    """generators.cpp:31-47 in double on fp32 arguments (the |x| >= 2 select is decided on the fp32 argument)."""
-    x = x32.astype(np.float64)
-    x2 = x * x
-    v = np.full_like(x, float(C6[0]))
-    for c in C6[1:]:
-        v = float(c) + v * x2
-    return np.where(np.abs(x32) >= np.float32(2.0), 0.0, v)
-
-
-def sampler_f64(src, A, B, TX, TY, border):
-    """Value of the Lanczos2 sampler per output pixel and channel in fp64, and the error scale
-    sum|w v| / |sum w| + max|v| over the 4x4 window.  Coordinates and fractions follow the oracle's fp32 operations
-    exactly (generators.cpp:141-142).  The second term of the scale: a polynomial weight near one of its zero crossings
-    (|x| ~ 1, |x| -> 2) carries an ABSOLUTE error of a few eps, because the Horner partial sums reach 37 while the weight
-    itself is ~0 -- so in a dark pixel next to a bright one every fp32 evaluation order, the oracle's included, is off by
-    eps x the bright neighbour, not by eps x the dark result."""
-    h, w, c = src.shape
-    f32 = np.float32
-    A1 = f32(1.0) + f32(A)
-    xs = np.arange(w, dtype=np.float32)[None, :]
-    ys = np.arange(h, dtype=np.float32)[:, None]
-    Wx = (A1 * xs - f32(B) * ys) + f32(TX)
-    Wy = (f32(B) * xs + A1 * ys) + f32(TY)
-    flx, fly = np.floor(Wx), np.floor(Wy)
-    frx, fry = (Wx - flx).astype(np.float32), (Wy - fly).astype(np.float32)
-    ix, iy = flx.astype(np.int64), fly.astype(np.int64)
-    wx = [lanczos2_f64((f32(u - 2) - frx).astype(np.float32)) for u in range(1, 5)]
-    wy = [lanczos2_f64((f32(u - 2) - fry).astype(np.float32)) for u in range(1, 5)]
-    num = np.zeros((h, w, c))
-    absnum = np.zeros((h, w, c))
-    vmax = np.zeros((h, w, c))
-    den = np.zeros((h, w))
-    s = src.astype(np.float64)
-    for ry in range(4):
-        sy = iy + ry - 1
-        for rx in range(4):
-            sx = ix + rx - 1
-            w2 = wx[rx] * wy[ry]
-            if border == 0:
-                v = s[np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1)]
-            else:
-                inside = (sy >= 0) & (sy < h) & (sx >= 0) & (sx < w)
-                v = s[np.clip(sy, 0, h - 1), np.clip(sx, 0, w - 1)] * inside[..., None]
-            num += w2[..., None] * v
-            absnum += np.abs(w2)[..., None] * v
-            vmax = np.maximum(vmax, v)
-            den += w2
-    return num / den[..., None], absnum / np.abs(den)[..., None] + vmax
-
-
 TRANSFORMS = [(0.004, -0.003, 2.25, -1.5), (-0.01, 0.02, -7.75, 3.125), (0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 3.0, -2.0), (0.0007, 0.0019, 0.5, 0.5)]
 
 
 @pytest.mark.parametrize("border", [0, 1])
 @pytest.mark.parametrize("bits", [8, 10])
-def test_fast_mode_float_output_within_the_ulp_bound(gpu_vs, oracle, bits, border):
+def test_fast_mode_float_output_equals_the_contracted_twin(gpu_vs, oracle, bits, border):
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(320, 200, 1, seed=11, channels=3, bits=bits)
     src = frames[0]
-    worst = {"fast_vs_truth": 0.0, "oracle_vs_truth": 0.0, "fast_vs_oracle": 0.0}
+    differs = 0
     for tr in TRANSFORMS:
         tg, to = gpu_vs.Transform.of(*tr), oracle.Transform.of(*tr)
         fast = gpu_vs.bgr_image_warp(src, tg, mode=gpu_vs.WARP_LANCZOS2_FAST, border=border, f32=True)
+        twin = oracle.bgr_image_warp(src, to, oracle.WARP_LANCZOS2_CONTRACTED, border=border, f32=True)
+        assert np.array_equal(fast, twin), (tr, float(np.abs(fast - twin).max()))
         exact = gpu_vs.bgr_image_warp(src, tg, mode=gpu_vs.WARP_LANCZOS2, border=border, f32=True)
-        ref = oracle.bgr_image_warp(src, to, border=border, f32=True)
-        assert np.array_equal(exact, ref)                       # the exact mode IS the oracle, bit for bit
-        A, B, TX, TY = oracle.ul_params_warp(to, src.shape[1], src.shape[0])
-        val, bound = sampler_f64(src, A, B, TX, TY, border)
-        tol = EPS * np.maximum(bound, 1e-30)
-        worst["fast_vs_truth"] = max(worst["fast_vs_truth"], float((np.abs(fast - val) / tol).max()))
-        worst["oracle_vs_truth"] = max(worst["oracle_vs_truth"], float((np.abs(ref - val) / tol).max()))
-        worst["fast_vs_oracle"] = max(worst["fast_vs_oracle"], float((np.abs(fast.astype(np.float64) - ref) / tol).max()))
-    print("bits", bits, "border", border, "worst |delta| / (eps * (sum|wv| / |sum w| + max|v|)):", worst)
-    assert worst["oracle_vs_truth"] <= K_TRUTH, worst           # the yardstick itself
-    assert worst["fast_vs_truth"] <= K_TRUTH, worst             # the fast arithmetic is as close to the sampler as the oracle is
-    assert worst["fast_vs_oracle"] <= 2 * K_TRUTH, worst        # hence within twice that of each other
+        assert np.array_equal(exact, oracle.bgr_image_warp(src, to, border=border, f32=True))   # the exact mode IS the un-contracted oracle
+        differs += int(not np.array_equal(exact, fast))
+    assert differs > 0          # the two modes are different functions: the twin tests something
 
 
 @pytest.mark.parametrize("border", [0, 1])
 @pytest.mark.parametrize("dtype,hi,bits", [(np.uint8, 255, 8), (np.uint16, 1023, 10)])
-def test_fast_mode_integer_output_within_one_lsb(gpu_vs, oracle, dtype, hi, bits, border):
-    """Tuned c3 kernels (u8 / u16): <= 1 LSB from the exact mode (= the oracle), >= 99.99 % identical."""
+def test_fast_mode_integer_output_equals_the_contracted_twin(gpu_vs, oracle, dtype, hi, bits, border):
+    """Tuned c3 kernels (u8 / u16): identical to the twin; and never more than 1 LSB from the un-contracted mode."""
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(640, 360, 3, seed=5, channels=3, bits=bits)
     ts = [gpu_vs.Transform.of(*tr) for tr in TRANSFORMS[:3]]
+    fast = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_LANCZOS2_FAST, border=border, max_value=hi)
     exact = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_LANCZOS2, border=border, max_value=hi)
     for i in range(3):
-        assert np.array_equal(exact[i], oracle.bgr_image_warp(frames[i], oracle.Transform.of(*ts[i].tup()), border=border, max_value=hi))
-    fast = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_LANCZOS2_FAST, border=border, max_value=hi)
+        to = oracle.Transform.of(*ts[i].tup())
+        assert np.array_equal(fast[i], oracle.bgr_image_warp(frames[i], to, oracle.WARP_LANCZOS2_CONTRACTED, border=border, max_value=hi))
+        assert np.array_equal(exact[i], oracle.bgr_image_warp(frames[i], to, border=border, max_value=hi))
     d = np.abs(fast.astype(np.int64) - exact.astype(np.int64))
-    same = float((d == 0).mean())
-    print("bits", bits, "border", border, "identical fraction", same, "max diff", int(d.max()))
+    print("bits", bits, "border", border, "identical to the un-contracted mode:", float((d == 0).mean()), "max diff", int(d.max()))
     assert d.max() <= 1
-    assert same >= 0.9999, same
 
 
-def test_fast_mode_other_layouts_use_the_same_arithmetic(gpu_vs):
-    """1-channel frames have no tuned kernel: the generic kernel serves them with the same fast arithmetic, so a gray
-    frame equals the blue plane of a BGR frame whose channels are all that gray frame (c3 kernel) in fast mode too."""
+def test_fast_mode_ragged_sizes_windows_and_unaligned_rows(gpu_vs, oracle):
+    """sizes that are not multiples of the 64x16 tile, of 4 pixels or of 4 bytes per row: border tiles, byte-wise stores"""
+    rng = np.random.default_rng(21)
+    for (h, w) in [(17, 65), (33, 130), (16, 64), (5, 7), (70, 201)]:
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for tr in TRANSFORMS[:2]:
+            for border in (0, 1):
+                got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_LANCZOS2_FAST, border=border)
+                want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_LANCZOS2_CONTRACTED, border=border)
+                assert np.array_equal(got, want), (h, w, tr, border)
+
+
+def test_fast_mode_other_layouts_use_the_same_arithmetic(gpu_vs, oracle):
+    """1-channel frames have no tuned kernel: the generic kernel serves them with the same contracted arithmetic."""
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(256, 160, 1, seed=3, channels=3)
     gray = np.ascontiguousarray(frames[0][..., :1])
@@ -131,15 +73,26 @@ def test_fast_mode_other_layouts_use_the_same_arithmetic(gpu_vs):
     a = gpu_vs.bgr_image_warp(gray, t, mode=gpu_vs.WARP_LANCZOS2_FAST)
     b = gpu_vs.bgr_image_warp(bgr, t, mode=gpu_vs.WARP_LANCZOS2_FAST)
     assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(b[..., 0], b[..., 2])
+    assert np.array_equal(a, oracle.bgr_image_warp(gray, oracle.Transform.of(*t.tup()), oracle.WARP_LANCZOS2_CONTRACTED))
 
 
 def test_fast_mode_large_rotation_takes_the_global_path(gpu_vs, oracle):
-    """Footprints that do not fit the LDS window run the per-pixel path of the same kernel, fast arithmetic included."""
+    """Footprints that do not fit the LDS window run the per-pixel path of the same kernel, same arithmetic."""
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(320, 240, 1, seed=9, channels=3)
     t = gpu_vs.Transform.of(-0.2, 0.6, 4.0, -3.0)
-    exact = gpu_vs.bgr_image_warp(frames[0], t, mode=gpu_vs.WARP_LANCZOS2)
-    assert np.array_equal(exact, oracle.bgr_image_warp(frames[0], oracle.Transform.of(*t.tup())))
     fast = gpu_vs.bgr_image_warp(frames[0], t, mode=gpu_vs.WARP_LANCZOS2_FAST)
-    d = np.abs(fast.astype(np.int64) - exact.astype(np.int64))
-    assert d.max() <= 1 and float((d == 0).mean()) >= 0.9999
+    assert np.array_equal(fast, oracle.bgr_image_warp(frames[0], oracle.Transform.of(*t.tup()), oracle.WARP_LANCZOS2_CONTRACTED))
+
+
+def test_fast_mode_4k_frame_equals_the_contracted_twin(gpu_vs, oracle):
+    """BASELINE configs[2] frame size, one frame (the oracle needs a few seconds for it with its rows in parallel)."""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(3840, 2160, 1, seed=2, channels=3)
+    t = (0.0012, -0.0017, 3.3, -2.7)
+    oracle.set_threads(8)
+    try:
+        want = oracle.bgr_image_warp(frames[0], oracle.Transform.of(*t), oracle.WARP_LANCZOS2_CONTRACTED)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(gpu_vs.bgr_image_warp(frames[0], gpu_vs.Transform.of(*t), mode=gpu_vs.WARP_LANCZOS2_FAST), want)

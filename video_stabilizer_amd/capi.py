@@ -55,7 +55,8 @@ class StabilizerParams(C.Structure):
 class AlignInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("fail_reason", C.c_int32), ("fail_level", C.c_int32),
                 ("levels", C.c_int32), ("iterations", C.c_int32 * 16), ("condition", C.c_double * 16),
-                ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
+                ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double),
+                ("selected_x", C.c_int32 * 16), ("selected_y", C.c_int32 * 16), ("level_transform", Transform * 16)]
 
 
 STAGES = ["ingest", "pyr_down", "keyframe", "warpdiff", "select", "gather", "gn", "phase"]

@@ -39,17 +39,18 @@ __device__ __forceinline__ void lanczos_weights4(float frac, float w[4]) {
     w[3] = lanczos2(2.0f - frac);
 }
 
-// ---- VS_WARP_LANCZOS2_FAST: the tolerance-gated arithmetic of bgr_image_warp -------------------------------------
-// Same sampler (generators.cpp:31-47 polynomial, :672-697 window and normalisation), evaluated with fused
-// multiply-adds and in separable order -- NOT the reference's sequence of roundings:
-//   w(t)   = Horner in t*t with one fma per step (6 roundings instead of 12), same |t| >= 2 select
-//   h[ry]  = fma(wx3,v3, fma(wx2,v2, fma(wx1,v1, wx0*v0)))          horizontal pass, per source row and channel
-//   num    = fma(wy3,h3, fma(wy2,h2, fma(wy1,h1, wy0*h0)))          vertical pass
-//   den    = ((wx0+wx1)+(wx2+wx3)) * ((wy0+wy1)+(wy2+wy3))          == sum of wx*wy up to rounding
-//   out    = num * r,  r = rcp(den) refined by one Newton step
-// 20 multiply-adds per channel instead of 16 products + 32 separately rounded multiply / add steps.  Every kernel that
-// offers the fast mode calls these functions, so the f32-output gate (tests/test_warp_fast_gpu.py) checks the very
-// arithmetic the tuned u8 / u16 kernels run.
+// ---- VS_WARP_LANCZOS2_FAST: the contracted form of the sampler ------------------------------------------------------
+// The reference builds its generators for a target with FMA (CMakeLists.txt:151 "...-fma-...") and without strict_float,
+// so on the reference's own machine LLVM may fuse a multiply into the add that consumes it.  This mode is the sampler of
+// generators.cpp:31-47 / :684-697 with exactly those fusions, same tap order, same accumulators, same sampling position:
+//   w(t)   : "c + val * x2" -> fma(val, x2, c), six times (x2 = t * t and the |t| >= 2 select unchanged)
+//   w2d    = wx[rx] * wy[ry]                        a rounded product (generators.cpp:687)
+//   num    = fma(w2d, val, num)                     rx inner, ry outer, from 0 (:694)
+//   den    = den + w2d                              (:695: nothing of its own to fuse)
+//   out    = num / den                              one IEEE divide (:697)
+// Its CPU twin is oracle/vs_oracle.cpp VSO_WARP_LANCZOS2_CONTRACTED (std::fmaf), pinned by a literal restatement with an
+// exact rational fma (tests/test_oracle_known_answers.py); every kernel that offers the mode is bit-identical to it
+// (tests/test_warp_fast_gpu.py: np.array_equal on float and integer outputs).
 __device__ __forceinline__ float lanczos2_fma(float x) {
     const float x2 = x * x;
     float v = 0.000858519f;
@@ -61,33 +62,25 @@ __device__ __forceinline__ float lanczos2_fma(float x) {
     v = __builtin_fmaf(v, x2, 0.999861f);
     return fabsf(x) >= 2.0f ? 0.0f : v;
 }
+// taps 1..4 of the 5-tap window: tap 0 has weight exactly 0 (|-2 - frac| >= 2), and fma(+-0, val, num) == num, den + +-0 == den
 __device__ __forceinline__ void lanczos_weights4_fma(float frac, float w[4]) {
     w[0] = lanczos2_fma(-1.0f - frac);
     w[1] = lanczos2_fma(0.0f - frac);
     w[2] = lanczos2_fma(1.0f - frac);
     w[3] = lanczos2_fma(2.0f - frac);
 }
-// reciprocal of the weight sum: den is within a few percent of 1, so one Newton step on v_rcp_f32 (1 ulp) is enough
-__device__ __forceinline__ float lanczos_fast_rden(const float wx[4], const float wy[4]) {
-    const float den = ((wx[0] + wx[1]) + (wx[2] + wx[3])) * ((wy[0] + wy[1]) + (wy[2] + wy[3]));
-    float r = __builtin_amdgcn_rcpf(den);
-    return __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
-}
-// one channel: v[ry][rx] = the 4x4 window as floats
-__device__ __forceinline__ float lanczos_fast_combine(const float v[4][4], const float wx[4], const float wy[4], float rden) {
-    float h[4];
+// one channel: v[ry][rx] = the live 4x4 window as floats
+__device__ __forceinline__ float lanczos_contracted_combine(const float v[4][4], const float wx[4], const float wy[4]) {
+    float num = 0.0f, den = 0.0f;
 #pragma unroll
-    for (int ry = 0; ry < 4; ry++) {
-        float a = wx[0] * v[ry][0];
-        a = __builtin_fmaf(wx[1], v[ry][1], a);
-        a = __builtin_fmaf(wx[2], v[ry][2], a);
-        h[ry] = __builtin_fmaf(wx[3], v[ry][3], a);
-    }
-    float n = wy[0] * h[0];
-    n = __builtin_fmaf(wy[1], h[1], n);
-    n = __builtin_fmaf(wy[2], h[2], n);
-    n = __builtin_fmaf(wy[3], h[3], n);
-    return n * rden;
+    for (int ry = 0; ry < 4; ry++)
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+            const float w2d = wx[rx] * wy[ry];
+            num = __builtin_fmaf(w2d, v[ry][rx], num);
+            den = den + w2d;
+        }
+    return num / den;
 }
 
 // Lanczos2 sample of a single-channel u8 image with clamp-to-edge addressing:

@@ -60,6 +60,7 @@ struct PairState {
     int32_t pad;
     int32_t iterations[kMaxLevels];
     double condition[kMaxLevels];
+    double level_T[kMaxLevels][4];   // the estimate each level ended on (vs_align_info::level_transform)
 #ifdef VS_PROFILE_STAMPS
     unsigned long long stamps[kMaxLevels][6];   // diagnostic build only: shader-clock ticks per phase of a level
 #endif
@@ -79,6 +80,8 @@ struct GnParams {
     int max_iters;
     int pipeline;   // 1: the one-barrier iteration loop on the LDS-resident level (latency mode, few pairs in flight)
     int stall_helpers;   // test hook (VS_GN_STALL_HELPERS=1): helpers never report back, the leader's bounded wait must expire
+    int sel_depth_cap;   // test hook (VS_GN_SELECT_DEPTH=k > 0): the on-device introselect gets k partition rounds instead of 2 lg n, so
+                         // ordinary frames take the "libstdc++ would have heap-selected" exit (fail_reason 100 -> host redo)
 };
 
 // ---- phase-correlation start value (alignment.cpp:376-387) -----------------------------------------
@@ -736,7 +739,8 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         static const int pipe_env = []() { const char* e = getenv("VS_GN_PIPELINE"); return e ? atoi(e) : -1; }();
         const int pipeline = pipe_env >= 0 ? pipe_env : (n_pairs <= kPipelineMaxPairs ? 1 : 0);
         static const int stall_env = []() { const char* e = getenv("VS_GN_STALL_HELPERS"); return e ? atoi(e) : 0; }();
-        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env};
+        static const int depth_env = []() { const char* e = getenv("VS_GN_SELECT_DEPTH"); return e ? atoi(e) : 0; }();
+        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env, depth_env};
         bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
         if (!use_host) {
             // VS_SELECT_DEVICE: every level of every pair in one launch (selection = on-device introselect)
@@ -882,7 +886,13 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             const PairState& st = h_states[q];
             vs_align_info& inf = infos[i];
             inf.status = st.status; inf.fail_reason = st.fail_reason; inf.fail_level = st.fail_level;
-            for (int l = 0; l < levels; l++) { inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l]; }
+            for (int l = 0; l < levels; l++) {
+                inf.iterations[l] = st.iterations[l]; inf.condition[l] = st.condition[l]; tm.gn_iterations += st.iterations[l];
+                if (st.iterations[l] > 0) {      // the level was reached (a level always runs at least one iteration)
+                    inf.selected_x[l] = L[l].nsel; inf.selected_y[l] = L[l].nsel;      // alignment.cpp:464-465: both sets keep size * fraction
+                    inf.level_transform[l] = vs_transform{st.level_T[l][0], st.level_T[l][1], st.level_T[l][2], st.level_T[l][3]};
+                }
+            }
             if (p.phase_correlate) { inf.phase_dx = h_pres[q].dx; inf.phase_dy = h_pres[q].dy; inf.phase_response = h_pres[q].response; }
             vs_transform t{st.T[0], st.T[1], st.T[2], st.T[3]};
             if (st.status == 1) {

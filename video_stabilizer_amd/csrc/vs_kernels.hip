@@ -850,13 +850,13 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
     float flx = floorf(Wx), fly = floorf(Wy);
     int ix = (int)flx, iy = (int)fly;
     float frx = Wx - flx, fry = Wy - fly;
-    float wx[4], wy[4], rden = 0.0f;
+    float wx[4], wy[4];
     if (MODE == 0) { lanczos_weights4(frx, wx); lanczos_weights4(fry, wy); }
-    if (MODE == 2) { lanczos_weights4_fma(frx, wx); lanczos_weights4_fma(fry, wy); rden = lanczos_fast_rden(wx, wy); }
+    if (MODE == 2) { lanczos_weights4_fma(frx, wx); lanczos_weights4_fma(fry, wy); }
     for (int c = 0; c < channels; c++) {
         float v;
         if (MODE == 2) {
-            // VS_WARP_LANCZOS2_FAST (vs_device.hpp): the arithmetic of the tuned kernels, here with float output too
+            // VS_WARP_LANCZOS2_FAST (vs_device.hpp): the contracted sampler, here with float output too
             float t[4][4];
 #pragma unroll
             for (int ry = 0; ry < 4; ry++) {
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
                     }
                 }
             }
-            v = lanczos_fast_combine(t, wx, wy, rden);
+            v = lanczos_contracted_combine(t, wx, wy);
         } else if (MODE == 0) {
             float num = 0.0f, den = 0.0f;
 #pragma unroll

@@ -5,7 +5,8 @@
 // separately, one divide) or image_warp's bilinear (generators.cpp:148-163), evaluated per channel at
 // image_warp's coordinates (generators.cpp:141-142).  VS_WARP_LANCZOS2 / VS_WARP_BILINEAR results are
 // bit-identical to the generic kernel and to the CPU oracle: same fp32 operations in the same order, no
-// FMA contraction.  VS_WARP_LANCZOS2_FAST runs the tolerance-gated arithmetic of vs_device.hpp.
+// FMA contraction.  VS_WARP_LANCZOS2_FAST is the contracted form of the same sampler (vs_device.hpp), bit-identical to
+// the oracle's VSO_WARP_LANCZOS2_CONTRACTED.
 //
 // Structure (one 256-thread workgroup = one 64x16 output tile of one frame):
 //   1. The similarity is affine, so the tile's source footprint is the bounding box of its four
@@ -161,11 +162,12 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], fl
     for (int j = 0; j < 2; j++) { num[j][0] = nbg[j].x; num[j][1] = nbg[j].y; num[j][2] = nrd[j].x; num[j][3] = nrd[j].y; }
 }
 
-// VS_WARP_LANCZOS2_FAST of two output pixels: vs_device.hpp's lanczos2_fma / lanczos_fast_rden / lanczos_fast_combine,
-// written out for the LDS tile.  Everything is scalar fp32: on gfx950 a packed fp32 instruction costs the issue time of
-// two scalar ones AND slows the scalar instructions around it (tools/ubench_mix.hip: fma alone 3.2 cycles, pk_fma 5.6,
-// a 3:1 mix 4.9 per instruction), so a stream without packed instructions is the fastest form of the same arithmetic.
-__device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], float q[2][3]) {
+// VS_WARP_LANCZOS2_FAST of two output pixels: the contracted sampler of vs_device.hpp (oracle twin VSO_WARP_LANCZOS2_CONTRACTED)
+// written out for the LDS tile -- Horner steps as single fmas, w2d = wx * wy a rounded product, num = fma(w2d, val, num) per
+// channel and den = den + w2d in the reference's tap order (rx inner, ry outer).  Everything is scalar fp32: on gfx950 a packed
+// fp32 instruction costs the issue time of two scalar ones AND slows the scalar instructions around it (tools/ubench_mix.hip:
+// fma alone 3.2 cycles, pk_fma 5.6, a 3:1 mix 4.9 per instruction).  num[j] = {numB, numG, numR, den}; the caller divides.
+__device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], float num[2][4]) {
     // weight chain c of pixel j: 0..3 = x taps 1..4, 4..7 = y taps 1..4
     float x[2][8], x2[2][8], v[2][8];
 #pragma unroll
@@ -184,7 +186,6 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
         for (int c = 0; c < 8; c++)
 #pragma unroll
             for (int j = 0; j < 2; j++) v[j][c] = __builtin_fmaf(v[j][c], x2[j][c], C[s]);
-    float rden[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
@@ -192,36 +193,24 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
         v[j][3] = fabsf(x[j][3]) >= 2.0f ? 0.0f : v[j][3];
         v[j][4] = fabsf(x[j][4]) >= 2.0f ? 0.0f : v[j][4];
         v[j][7] = fabsf(x[j][7]) >= 2.0f ? 0.0f : v[j][7];
-        rden[j] = lanczos_fast_rden(&v[j][0], &v[j][4]);
+        num[j][0] = 0.0f; num[j][1] = 0.0f; num[j][2] = 0.0f; num[j][3] = 0.0f;
     }
-    float n[2][3];
 #pragma unroll
     for (int ry = 0; ry < 4; ry++) {
-        float hh[2][3];
 #pragma unroll
         for (int rx = 0; rx < 4; rx++) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const f4 val = t[j][ry * WS_RS + rx];
-                const float w = v[j][rx];
-                if (rx == 0) { hh[j][0] = w * val.x; hh[j][1] = w * val.y; hh[j][2] = w * val.z; }
-                else {
-                    hh[j][0] = __builtin_fmaf(w, val.x, hh[j][0]);
-                    hh[j][1] = __builtin_fmaf(w, val.y, hh[j][1]);
-                    hh[j][2] = __builtin_fmaf(w, val.z, hh[j][2]);
-                }
+                const float w2d = v[j][rx] * v[j][4 + ry];
+                num[j][0] = __builtin_fmaf(w2d, val.x, num[j][0]);
+                num[j][1] = __builtin_fmaf(w2d, val.y, num[j][1]);
+                num[j][2] = __builtin_fmaf(w2d, val.z, num[j][2]);
+                num[j][3] = num[j][3] + w2d;
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const float wy = v[j][4 + ry];
-#pragma unroll
-            for (int c = 0; c < 3; c++) n[j][c] = ry == 0 ? wy * hh[j][c] : __builtin_fmaf(wy, hh[j][c], n[j][c]);
         }
         if (VS_WARP_FAST_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int j = 0; j < 2; j++) { q[j][0] = n[j][0] * rden[j]; q[j][1] = n[j][1] * rden[j]; q[j][2] = n[j][2] * rden[j]; }
 }
 
 // image_warp's bilinear (generators.cpp:148-163) per channel; t = staged pixel (iy, ix)
@@ -269,14 +258,13 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
         float wx[4], wy[4];
         lanczos_weights4_fma(frx, wx);
         lanczos_weights4_fma(fry, wy);
-        const float rden = lanczos_fast_rden(wx, wy);
         for (int c = 0; c < 3; c++) {
             float v[4][4];
 #pragma unroll
             for (int ry = 0; ry < 4; ry++)
 #pragma unroll
                 for (int rx = 0; rx < 4; rx++) v[ry][rx] = fetch(ix + rx - 1, iy + ry - 1, c);
-            out[c] = store_u(lanczos_fast_combine(v, wx, wy, rden), maxv);
+            out[c] = store_u(lanczos_contracted_combine(v, wx, wy), maxv);
         }
     } else {
 #pragma unroll
@@ -456,7 +444,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
     const float c0 = -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
     uint32_t o[RPW][3];
-    float num[RPW][4];                                         // exact mode: {numB, numG, numR, den} kept for the operator/ fallback
+    float num[RPW][4];                                         // Lanczos modes: {numB, numG, numR, den} kept for the operator/ fallback
     bool all_ok = true;
     // rows are processed two at a time, the two rows' instructions alternating in source order: a packed-fp32 result
     // cannot feed the very next VALU instruction without a wait state on gfx950, and the other row's operation fills it
@@ -484,7 +472,12 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                 div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else if (MODE == 2) {
-            fast_pair(t, fr, q);
+            fast_pair(t, fr, &num[kp]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
+                div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
+            }
         } else {
             sample_bilinear(t[0], fr[0], q[0]);
             sample_bilinear(t[1], fr[1], q[1]);
@@ -497,7 +490,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         }
         if (MODE == 2 && VS_WARP_FAST_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // keeps the second pair's 32 LDS reads (128 VGPRs) behind the first pair
     }
-    if (MODE == 0 && __any(!all_ok)) {
+    if (MODE != 1 && __any(!all_ok)) {
         // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
         for (int k = 0; k < RPW; k++) {
