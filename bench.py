@@ -11,15 +11,20 @@ A "step" is one pass of the hot path over the rank's clips, which are already re
   c4 (configs[3]): C clips x 120 frames 1080p per GPU (clip i -> rank i mod N), align + warp.
   c5 (configs[4]): C clips x 60 frames 4K 10-bit BGR per GPU through the full VideoStabilizer loop
       (lag 10, L1 smoother, decay, warp, crop) -- vs_stabilizer_process_batch.
-value = frames per second, whole job (all ranks).  One process per GPU; clips are independent, so ranks share nothing
-but the barriers that bracket the timed region and one max/sum all-reduce for the report ("weak" scaling).
+value = ALIGNED frames per second, whole job (all ranks): frames for which AlignNextFrame returns true (the first frame of a
+clip has no predecessor: 239 of 240 count).  One process per GPU; clips are independent, so ranks share nothing but the
+barriers that bracket the timed region and one max/sum all-reduce for the report ("weak" scaling).
 
 The JSON line also carries
   roofline      the dominant kernel of the timed region (bgr_image_warp): algorithmic bytes / mean launch time, HIP
                 events on the launch stream, against the 8 TB/s HBM peak; `traffic` scaled from the committed PMC passes
   roofline_4k   the same kernel where the north star quotes it: 32 x 4K frames per launch, isolated, after the timed
-                region (exact and fast arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
+                region (exact and contracted arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
                 the kernel is VALU-issue-bound, the HBM fraction is what that leaves
+  c3            (default run, one GPU) the 4K half of the metric: BASELINE configs[2] through the same step, a few steps
+  c4_strong     (default run, N > 1) BASELINE configs[3]: 64 clips in total, 64 / N per rank, with per-rank seconds
+  parity        the gate SURVEY 8(d) asks for with every benchmark: the GPU results for the first frames of the clip against
+                the CPU restatement that cpu_baseline runs anyway; a broken gate makes the run fail (exit code 3)
   align_only    the same clip through the alignment stages alone (configs[1] read literally), with per-stage times
   cpu_baseline  the CPU restatement of the reference path (oracle/, kind "port") on the host cores, bounded sample
 torch is used for device memory, streams, events and torch.distributed only.
@@ -41,6 +46,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# dense fp32 vector peak: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = one wave-instruction per 2 cycles per SIMD (MI355X_MICROARCH.md)
+VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2
 
 WORKLOADS = {
     "c2": dict(name="1080p single clip, 3-level pyramid (pyramid_min_width=256), align + bgr_image_warp Lanczos2",
@@ -54,14 +61,44 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+def usable_threads():
+    """hardware threads this process can keep busy (affinity mask, capped by the container's CPU quota), and the host's total"""
+    total = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = total
+    q = cgroup_cpu_quota()
+    if q is not None:
+        avail = max(1, min(avail, int(q + 0.999)))
+    return avail, total
+
+
+def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0, record=None):
     """oracle (CPU restatement of the reference) on the host cores: one independent clip copy per thread, kernels
-    single-threaded -- the reference's own multi-clip regime (grid_search_align.cpp:105-210)."""
+    single-threaded -- the reference's own multi-clip regime (grid_search_align.cpp:105-210).  `record` (a list) receives
+    thread 0's per-frame results (ok, transform, iterations, fail_reason): the parity gate reads them, no extra CPU work."""
     from oracle import oracle as O
     n = frames_host.shape[0]
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    avail, total = usable_threads()
+    threads = max(1, min(avail, 16))
 
-    def run(count, k=None, done=None):
+    def run(count, k=None, done=None, rec=None):
         if stabilizer:
             st = O.Stabilizer(warp_mode=O.WARP_LANCZOS2, **params_kw)
             for i in range(count):
@@ -72,23 +109,43 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
             a = O.Aligner(**params_kw)
             for i in range(count):
                 ok, t = a.align_next(frames_host[i])
+                if rec is not None:
+                    d = a.debug()
+                    rec.append((ok, t.tup(), list(d.iterations[:d.levels]), int(d.fail_reason)))
                 O.bgr_image_warp(frames_host[i], t if ok else O.Transform.of())
                 if done is not None:
                     done[k] += 1
+
+    def many_clip(nthreads, sample, rec=None):
+        done = [0] * nthreads
+        th = [threading.Thread(target=run, args=(sample, k, done, rec if k == 0 else None)) for k in range(nthreads)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return sum(done) / (time.perf_counter() - t0)
 
     t0 = time.perf_counter()
     run(2)                                                     # calibrate on one thread to size the sample
     per_frame = (time.perf_counter() - t0) / 2
     sample = int(max(3, min(n, seconds_budget / max(per_frame, 1e-6))))
-    done = [0] * threads
-    th = [threading.Thread(target=run, args=(sample, k, done)) for k in range(threads)]
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
+    rate16 = many_clip(threads, sample, record)
     what = "full stabilizer loop" if stabilizer else "align + Lanczos2 warp"
+    out = {"value": round(rate16, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "first %d frames of one clip, %s, %d threads x 1 clip copy each (the reference's many-clip regime, "
+                     "grid_search_align.cpp:105-210), CPU restatement of the Halide path (not Halide)" % (sample, what, threads)}
+    # "over all host cores" -- every hardware thread this process may run on, same regime, a sample sized so that
+    # the leg takes ~10 s whatever the thread count turns out to be worth (a 2-frame probe per thread sizes it)
+    if avail > threads:
+        probe = many_clip(avail, 2)
+        sample_all = int(max(3, min(n, 10.0 * probe / avail)))
+        rate_all = many_clip(avail, sample_all)
+        out["all_cores"] = {"value": round(rate_all, 2), "unit": "frames/s", "cores": avail,
+                            "sample": "first %d frames of one clip per thread, %d threads" % (sample_all, avail)}
+    else:
+        out["all_cores"] = {"value": round(rate16, 2), "unit": "frames/s", "cores": threads,
+                            "sample": "the process may run on %d hardware threads: the figure above already uses all of them" % avail}
     # SURVEY 8(d) mode (i): ONE clip, the image-sized stages row-parallel over the same cores (the analogue of the .parallel(y)
     # of the reference's Halide schedules; the Gauss-Newton sums stay serial as sparse_ica.schedule.h has them)
     O.set_threads(threads)
@@ -97,11 +154,12 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0):
     run(single_n)
     dt1 = time.perf_counter() - t0
     O.set_threads(1)
-    return {"value": round(sum(done) / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "first %d frames of one clip, %s, %d threads x 1 clip copy each (the reference's many-clip regime, "
-                      "grid_search_align.cpp:105-210), CPU restatement of the Halide path (not Halide)" % (sample, what, threads),
-            "single_clip": {"value": round(single_n / dt1, 2), "unit": "frames/s", "threads": threads,
-                            "sample": "first %d frames of one clip, stages row-parallel over %d threads" % (single_n, threads)}}
+    out["single_clip"] = {"value": round(single_n / dt1, 2), "unit": "frames/s", "threads": threads,
+                          "sample": "first %d frames of one clip, stages row-parallel over %d threads" % (single_n, threads)}
+    out["hardware_threads"] = total
+    out["usable_threads"] = avail
+    out["cpu_quota"] = cgroup_cpu_quota()
+    return out
 
 
 def cpu_model():
@@ -136,19 +194,24 @@ def spawn_ranks(n, argv, n_devices_hint=None):
     return rc
 
 
+def load_profile(*names):
+    for nm in names:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", nm))), nm
+        except Exception:
+            pass
+    return {}, None
+
+
 def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     """bgr_image_warp where the north star quotes it: `frames` 4K u8 frames per launch, nothing else running."""
     W, H = 3840, 2160
     src = torch.randint(0, 256, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint8)
     dst = torch.empty_like(src)
     ts = [capi.Transform.of(0.002, -0.0015, 3.3 + 0.37 * i, -2.7 - 0.21 * i) for i in range(frames)]
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_warp_pmc.json")))
-    except Exception:
-        pass
+    pmc, pmc_name = load_profile("r03_warp_pmc.json", "r02_warp_pmc.json")
     out = {}
-    for name, mode in (("exact", capi.WARP_LANCZOS2), ("fast", capi.WARP_LANCZOS2_FAST)):
+    for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted")):
         def run():
             capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
                                              max_value=255, stream=stream.cuda_stream)
@@ -166,14 +229,18 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         med = ms[len(ms) // 2]
         nbytes = W * H * 3 * 2 * frames
         ach = nbytes / (med * 1e-3) / 1e9
-        p = pmc.get(name, {})
-        out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,%s,clamp>" % ("lanczos2" if name == "exact" else "lanczos2 fast"),
+        p = pmc.get(key, {})
+        ipp = p.get("valu_instr_per_px")
+        # VALU-peak fraction: wave-instructions the launch issues / what 1024 SIMDs issue in that time at one per 2 cycles
+        valu_peak_frac = round(ipp * W * H * frames / 64.0 / (med * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if ipp else None
+        out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,%s,clamp>" % ("lanczos2" if name == "exact" else "lanczos2 contracted (VS_WARP_LANCZOS2_FAST)"),
                      "bound": "hbm", "binding": "valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": int(p["traffic_bytes_per_frame"] * frames) if "traffic_bytes_per_frame" in p else None,
                      "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
-                     "valu_instr_per_px": p.get("valu_instr_per_px"), "valu_frac": p.get("valu_frac"), "lds_frac": p.get("lds_frac"),
+                     "valu_instr_per_px": ipp, "valu_peak_frac": valu_peak_frac, "valu_frac": p.get("valu_frac"), "lds_frac": p.get("lds_frac"),
+                     "parity": "np.array_equal with the CPU restatement (%s)" % ("VSO_WARP_LANCZOS2" if name == "exact" else "VSO_WARP_LANCZOS2_CONTRACTED"),
                      "counters": "valu_instr_per_px / valu_frac / lds_frac / traffic: rocprofv3 PMC passes of this kernel committed in "
-                                 "profiles/r02_warp_pmc.json (not measured in this run); achieved: HIP events in this run"}
+                                 "profiles/%s (not measured in this run); achieved, valu_peak_frac: HIP events in this run" % pmc_name}
     del src, dst
     return out
 
@@ -217,31 +284,149 @@ def host_fed(torch, capi, dev, frames_dev, W, H, fmt, params_kw, reps=3):
             "note": "alignment of a host-resident clip, PCIe-inclusive (never `value`); pipelined ingest, pageable host memory"}
 
 
+class AlignWarp:
+    """The timed step for the align + warp workloads (c2 / c3 / c4): the rank's clips resident in HBM, one aligner handle, one
+    output buffer.  The warp of pass k (caller's stream) overlaps the alignment of pass k+1 (the handle's stream)."""
+
+    def __init__(self, torch, capi, synth, dev, wl, n, n_clips, seeds, params_kw, args, factory_seed):
+        self.torch, self.capi, self.dev, self.wl, self.n, self.n_clips, self.args = torch, capi, dev, wl, n, n_clips, args
+        self.W, self.H, self.bits = wl["w"], wl["h"], wl["bits"]
+        self.fmt = capi.FMT_BGR8 if self.bits == 8 else capi.FMT_BGR16
+        self.max_value = 255 if self.bits == 8 else (1 << self.bits) - 1
+        factory = synth.TorchClipFactory(self.W, self.H, factory_seed, dev, channels=3, bits=self.bits)
+        dt = torch.uint8 if self.bits == 8 else torch.int16
+        # the rank's clips live back to back in one tensor, so the aligner can take all of them in one call
+        self.frames = torch.empty((n_clips * n, self.H, self.W, 3), dtype=dt, device=dev)
+        self.clips = [factory.make(n, seeds[j], out=self.frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
+        torch.cuda.synchronize()
+        self.N = n_clips * n
+        self.stream = torch.cuda.current_stream()
+        self.aligner = capi.Aligner(device=dev.index,
+                                    select_mode=capi.SELECT_DEVICE if args.select == "device" else capi.SELECT_STL_HOST, **params_kw)
+        self.warped = None if args.no_warp else torch.empty_like(self.frames)
+        self.ev = []
+        self.shared(True)
+
+    def shared(self, on):
+        # the timed step overlaps the warp of pass k with the alignment of pass k+1 (two streams): full batches then go through
+        # the small-footprint build of the solver kernel, which shares CUs with the warp grid (bit-identical results)
+        on = on and not self.args.no_warp and not self.args.exclusive_solver
+        self.aligner.set_batch_mode(self.capi.BATCH_SHARED if on else self.capi.BATCH_EXCLUSIVE)
+
+    def align(self):
+        return self.aligner.align_clips(self.N, self.n_clips, mem_ptr=self.frames.data_ptr(), w=self.W, h=self.H, fmt=self.fmt, raw=True)
+
+    def warp(self, ts, mode, timed=False):
+        torch = self.torch
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+        self.capi.bgr_image_warp_batch_device(self.frames.data_ptr(), self.N, self.W, self.H, 3, 8 if self.bits == 8 else 16, ts,
+                                              self.warped.data_ptr(), mode, self.capi.BORDER_CLAMP, max_value=self.max_value,
+                                              stream=self.stream.cuda_stream)
+        if timed:
+            b.record(self.stream)
+            self.ev.append((a, b))
+
+    def step(self, timed=False, mode=None):
+        status, ts = self.align()
+        if not self.args.no_warp:
+            if mode is None:
+                mode = self.capi.WARP_LANCZOS2 if self.args.warp_mode == "exact" else self.capi.WARP_LANCZOS2_FAST
+            self.warp(ts, mode, timed)
+        return sum(status)
+
+    def free(self):
+        self.frames = self.warped = self.clips = None
+        self.aligner = None
+        self.torch.cuda.empty_cache()
+
+
+def stage_table(t, steps):
+    return {k: {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // max(1, steps)}
+            for k, v in t.items() if isinstance(v, dict) and v["launches"]}
+
+
+def parity_gate(torch, capi, aw, params_kw, oracle_rec, frames_host, warp_frames=(1, 2, 17, 40)):
+    """"parity gates run with every benchmark".  The GPU side is the path the timed step runs (full batch, device
+    selection, exact and contracted warps of the whole clip); the CPU side is what cpu_baseline's first thread computed on the
+    first frames of the same clip, plus the oracle's warp of a few frames BY THE GPU'S TRANSFORMS (so that the pixel gate
+    tests the warp alone).  Gates: status equal; iteration counts equal; |d(A,B,TX,TY)| <= 1e-4; warped pixels equal."""
+    import numpy as np
+    from oracle import oracle as O
+    status, ts = aw.align()
+    P = len(oracle_rec)
+    gi = [aw.aligner.info(i) for i in range(P)]
+    st_eq = all(bool(status[i]) == bool(oracle_rec[i][0]) for i in range(P))
+    reason_eq = all((int(gi[i].fail_reason) == oracle_rec[i][3]) for i in range(P))
+    it_eq = all(list(gi[i].iterations[:gi[i].levels]) == oracle_rec[i][2] for i in range(P) if oracle_rec[i][0])
+    dmax = 0.0
+    for i in range(P):
+        g = ts[i]
+        dmax = max(dmax, max(abs(a - b) for a, b in zip((g.A, g.B, g.TX, g.TY), oracle_rec[i][1])))
+    res = {"frames": P, "status_equal": bool(st_eq and reason_eq), "iterations_equal": bool(it_eq),
+           "transform_max_abs_diff": dmax, "transform_tolerance": 1e-4}
+    ok = st_eq and reason_eq and it_eq and dmax <= 1e-4
+    if aw.warped is not None:
+        idx = [i for i in warp_frames if i < P]
+        O.set_threads(min(16, usable_threads()[0]))
+        try:
+            for name, gmode, omode in (("warp_pixels_equal", capi.WARP_LANCZOS2, O.WARP_LANCZOS2),
+                                       ("contracted_warp_pixels_equal", capi.WARP_LANCZOS2_FAST, O.WARP_LANCZOS2_CONTRACTED)):
+                aw.warp(ts, gmode)
+                torch.cuda.synchronize()
+                same = True
+                for i in idx:
+                    got = aw.warped[i].cpu().numpy()
+                    if got.dtype == np.int16:
+                        got = got.view(np.uint16)
+                    want = O.bgr_image_warp(frames_host[i], O.Transform.of(ts[i].A, ts[i].B, ts[i].TX, ts[i].TY), omode,
+                                            O.BORDER_CLAMP, max_value=aw.max_value)
+                    same = same and bool(np.array_equal(got, want))
+                res[name] = same
+                ok = ok and same
+        finally:
+            O.set_threads(1)
+        res["warp_frames_checked"] = idx
+    res["pass"] = bool(ok)
+    res["note"] = ("GPU = the timed path (one %d-frame batch, on-device selection, bgr_image_warp of every frame); CPU = the oracle "
+                   "(CPU restatement of the reference, parity unpinned: DESIGN.md section 2) on the first %d frames" % (aw.N, P))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override the clip length")
     ap.add_argument("--clips-per-gpu", type=int, default=0)
     ap.add_argument("--select", default="device", choices=["host", "device"])
     ap.add_argument("--no-warp", action="store_true", help="alignment only (c2/c3/c4)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the parity gate that rides on it")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to rehearse the N>1 flow on one GPU")
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
     ap.add_argument("--default-levels", action="store_true",
                     help="reference default pyramid_min_width/height = 20 (6 levels at 1080p, 7 at 4K) instead of 256")
     ap.add_argument("--warp-mode", default="exact", choices=["exact", "fast"],
-                    help="exact = VS_WARP_LANCZOS2 (bit-identical to the CPU restatement, the default and the parity claim); "
-                         "fast = VS_WARP_LANCZOS2_FAST (opt-in fused-multiply-add variant, within 1 LSB)")
+                    help="exact = VS_WARP_LANCZOS2 (the reference's un-contracted fp32 order; the default and `value`); "
+                         "fast = VS_WARP_LANCZOS2_FAST (the contracted form; bit-identical to the oracle's contracted twin)")
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     ap.add_argument("--no-roofline-4k", action="store_true", help="skip the isolated 32 x 4K bgr_image_warp measurement")
     ap.add_argument("--exclusive-solver", action="store_true", help="keep the solver kernel in VS_BATCH_EXCLUSIVE mode inside the overlapped step")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-resident (PCIe-inclusive) alignment measurement")
+    ap.add_argument("--no-c3", action="store_true", help="skip the 4K (configs[2]) leg of the default one-GPU run")
+    ap.add_argument("--c4-strong", action="store_true", help="run the 64-clip strong-scaling leg (configs[3]) even on one GPU")
+    ap.add_argument("--no-c4-strong", action="store_true", help="skip it on N > 1")
+    ap.add_argument("--c4-clips", type=int, default=64, help="total clips of the strong-scaling leg (rehearsals use fewer)")
+    ap.add_argument("--c4-frames", type=int, default=120)
     args = ap.parse_args()
+    default_run = args.workload is None
+    if default_run:
+        args.workload = "c2"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: be the launcher.  Nothing above has imported torch or made a HIP call.
@@ -260,6 +445,8 @@ def main():
     if world > 1 or args.force_dist:
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
         dist = vsdist.init(args.dist_backend, rank, world, device_id=dev if args.dist_backend == "nccl" else None)
+        assert dist.get_world_size() == world, "process group has %d ranks, launcher says %d" % (dist.get_world_size(), world)
+        assert world == args.gpus or args.force_dist, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
     red_dev = dev if args.dist_backend == "nccl" else None     # where the three report scalars are reduced
 
     wl = WORKLOADS[args.workload]
@@ -267,56 +454,12 @@ def main():
     n = args.frames or wl["frames"]
     n_clips = args.clips_per_gpu or wl["clips"]
     fmt = capi.FMT_BGR8 if bits == 8 else capi.FMT_BGR16
-    max_value = 255 if bits == 8 else (1 << bits) - 1
-    # global clip index of local clip j = rank + j*world (clip i -> rank i mod N); textures per rank, path per clip
-    factory = synth.TorchClipFactory(W, H, wl["seed"] + 1000 * rank, dev, channels=3, bits=bits)
-    # the rank's clips live back to back in one tensor, so the aligner can take all of them in one call
-    all_frames = torch.empty((n_clips * n, H, W, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
-    clips = [factory.make(n, wl["seed"] + 1000 * (rank + j * world), out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
-    torch.cuda.synchronize()
-
     params_kw = {} if args.default_levels else dict(pyramid_min_width=256)
     if args.phase_correlate:
         params_kw["phase_correlate"] = 1
     stream = torch.cuda.current_stream()
-    ev = []   # (start, end) events around the warp launches of the timed steps
-
-    if wl["stabilizer"]:
-        crop = 32
-        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2, **params_kw)   # the library default is the reference's bilinear
-        out_buf = torch.empty((n_clips * n, H - 2 * crop, W - 2 * crop, 3), dtype=clips[0].dtype, device=dev)
-        aligner = None
-
-        def step(timed):
-            # all clips of the rank in one call (vs_stabilizer_process_clips): each clip through a fresh stabilizer,
-            # alignment and warps of all clips batched together
-            r, _ = stab.process_clips_device(all_frames.data_ptr(), n_clips, n, W, H, fmt, out_buf.data_ptr())
-            return r
-    else:
-        aligner = capi.Aligner(device=local_rank,
-                               select_mode=capi.SELECT_DEVICE if args.select == "device" else capi.SELECT_STL_HOST, **params_kw)
-        warped = torch.empty_like(all_frames)
-        N = n_clips * n
-        # the timed step overlaps the warp of pass k with the alignment of pass k+1 (two streams): full batches go through the
-        # small-footprint build of the solver kernel, which shares CUs with the warp grid (bit-identical results)
-        if not args.no_warp and not args.exclusive_solver:
-            aligner.set_batch_mode(capi.BATCH_SHARED)
-
-        def step(timed, warp_mode=None):
-            # all clips of the rank in one call (vs_aligner_align_clips): every stage is one launch over all clips
-            status, ts = aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
-            if not args.no_warp:
-                if timed:
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(stream)
-                if warp_mode is None:
-                    warp_mode = capi.WARP_LANCZOS2 if args.warp_mode == "exact" else capi.WARP_LANCZOS2_FAST
-                capi.bgr_image_warp_batch_device(all_frames.data_ptr(), N, W, H, 3, 8 if bits == 8 else 16, ts, warped.data_ptr(),
-                                                 warp_mode, capi.BORDER_CLAMP, max_value=max_value, stream=stream.cuda_stream)
-                if timed:
-                    b.record(stream)
-                    ev.append((a, b))
-            return sum(status)
+    # global clip index of local clip j = rank + j*world (clip i -> rank i mod N); textures per rank, path per clip
+    seeds = [wl["seed"] + 1000 * (rank + j * world) for j in range(n_clips)]
 
     def timed_loop(fn, k):
         """k calls of fn between barrier + synchronize on both sides; seconds on this rank, last return value"""
@@ -331,44 +474,84 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0, r
 
+    def roofline_of(aw, nframes_total):
+        ms = sum(a.elapsed_time(b) for a, b in aw.ev) / len(aw.ev)          # one launch per step over all the rank's frames
+        bytes_per_launch = aw.W * aw.H * 3 * 2 * (1 if aw.bits == 8 else 2) * nframes_total  # W*H*3*(in+out) B per frame
+        achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes, scaled to this launch's frame count; null when
+        # there is no profile for this frame format
+        traffic, tname = None, None
+        try:
+            tj, tname = load_profile("r03_traffic.json", "r02_traffic.json")
+            key, per = {(1920, 8): ("c2_1080p_240_frames", 240), (3840, 8): ("c3_4k_32_frames", 32)}[(aw.W, aw.bits)]
+            traffic = int(tj[key]["traffic_bytes"] / per * nframes_total)
+        except Exception:
+            pass
+        return {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm", "binding": "valu",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": "scaled from the committed PMC passes (profiles/%s), not measured in this run" % tname,
+                "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
+                "note": "VALU-issue-bound, not HBM-bound: the reference's un-contracted fp32 order needs 248 separately rounded "
+                        "operations per output pixel, <= 0.24 of the HBM peak at perfect VALU issue (DESIGN.md section 5); launches "
+                        "overlap the next pass's aligner kernels"}
+
+    if wl["stabilizer"]:
+        crop = 32
+        factory = synth.TorchClipFactory(W, H, wl["seed"] + 1000 * rank, dev, channels=3, bits=bits)
+        all_frames = torch.empty((n_clips * n, H, W, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
+        clips = [factory.make(n, seeds[j], out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
+        torch.cuda.synchronize()
+        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2, **params_kw)   # the library default is the reference's bilinear
+        out_buf = torch.empty((n_clips * n, H - 2 * crop, W - 2 * crop, 3), dtype=clips[0].dtype, device=dev)
+        aw = None
+
+        def step(timed):
+            # all clips of the rank in one call (vs_stabilizer_process_clips): each clip through a fresh stabilizer,
+            # alignment and warps of all clips batched together
+            r, _ = stab.process_clips_device(all_frames.data_ptr(), n_clips, n, W, H, fmt, out_buf.data_ptr())
+            return r
+    else:
+        aw = AlignWarp(torch, capi, synth, dev, wl, n, n_clips, seeds, params_kw, args, wl["seed"] + 1000 * rank)
+        clips = aw.clips
+
+        def step(timed):
+            return aw.step(timed)
+
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    if aligner:
-        aligner.enable_timing(True)
+    if aw:
+        aw.aligner.enable_timing(True)
     dt, good = timed_loop(lambda: step(True), args.steps)
     # whole-job numbers: max seconds over ranks, frames summed over ranks (the only collectives of the run)
     dt, total_frames, total_good = vsdist.aggregate(dt, n * n_clips * args.steps, int(good) * args.steps, device=red_dev)
-    tm = aligner.timings() if aligner else None
+    tm = aw.aligner.timings() if aw else None
 
     align_only = None
-    if aligner and not args.no_warp:
+    if aw and not args.no_warp:
         # second, separately reported figure: the alignment stages alone (BASELINE configs[1] read literally)
-        def fn():
-            aligner.align_clips(N, n_clips, mem_ptr=all_frames.data_ptr(), w=W, h=H, fmt=fmt, raw=True)
-        aligner.set_batch_mode(capi.BATCH_EXCLUSIVE)          # nothing else runs: one 512-thread workgroup per pair
-        aligner.enable_timing(True)
-        dt_a, _ = timed_loop(fn, args.steps)
+        aw.shared(False)                                       # nothing else runs: one 512-thread workgroup per pair
+        aw.aligner.enable_timing(True)
+        dt_a, _ = timed_loop(lambda: aw.align(), args.steps)
         dt_a, frames_a, _ = vsdist.aggregate(dt_a, n * n_clips * args.steps, 0, device=red_dev)
-        align_only = (dt_a, frames_a, aligner.timings())
+        align_only = (dt_a, frames_a, aw.aligner.timings())
+        aw.shared(True)
 
-    fast_warp = None
-    if aligner and not args.no_warp and not args.exclusive_solver:
-        aligner.set_batch_mode(capi.BATCH_SHARED)
-    if aligner and not args.no_warp and args.warp_mode == "exact":
-        # third figure: the same step with the tolerance-gated warp arithmetic (VS_WARP_LANCZOS2_FAST: within the north star's
-        # "1 ULP of the Lanczos path", tests/test_warp_fast_gpu.py) -- reported beside `value`, never as `value`
-        step(False, capi.WARP_LANCZOS2_FAST)
-        dt_f, _ = timed_loop(lambda: step(False, capi.WARP_LANCZOS2_FAST), args.steps)
-        dt_f, frames_f, _ = vsdist.aggregate(dt_f, n * n_clips * args.steps, 0, device=red_dev)
-        fast_warp = (dt_f, frames_f)
+    contracted = None
+    if aw and not args.no_warp and args.warp_mode == "exact":
+        # third figure: the same step with the contracted form of the sampler (VS_WARP_LANCZOS2_FAST: the arithmetic the
+        # reference's own FMA target may run, bit-identical to the oracle's contracted twin) -- beside `value`, never as `value`
+        aw.step(False, capi.WARP_LANCZOS2_FAST)
+        dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_LANCZOS2_FAST), args.steps)
+        dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
+        contracted = (dt_f, good_f)
 
+    rc = 0
+    out = None
     if rank == 0:
-        def stage_table(t):
-            return {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // max(1, args.steps)}
-                    for k, v in t.items() if isinstance(v, dict) and v["launches"]}
         out = {
-            "metric": "aligned frames/sec", "value": round(total_frames / dt, 2), "unit": "frames/s",
+            "metric": "aligned frames/sec", "value": round((total_good if not wl["stabilizer"] else total_frames) / dt, 2), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "dist_backend": (args.dist_backend if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
@@ -379,60 +562,114 @@ def main():
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
+                       "solver": "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp or wl["stabilizer"])
+                       else "shared (VS_BATCH_SHARED: 256-thread small-footprint build under the previous pass's warp, bit-identical)",
                        "phase_correlate": bool(args.phase_correlate),
                        "warp": None if (args.no_warp and not wl["stabilizer"]) else
-                       ("bgr_image_warp lanczos2" if args.warp_mode == "exact" else "bgr_image_warp lanczos2, opt-in fast mode (<= 1 LSB from exact)"), "resident": "HBM"},
+                       ("bgr_image_warp lanczos2" if args.warp_mode == "exact" else "bgr_image_warp lanczos2, contracted form (VS_WARP_LANCZOS2_FAST)"), "resident": "HBM"},
+            "frames_per_step": total_frames // args.steps,
             ("outputs_per_step" if wl["stabilizer"] else "aligned_per_step"): total_good // args.steps,
+            "value_counts": ("stabilized output frames + the lag frames that produce none" if wl["stabilizer"] else
+                             "aligned frames only (AlignNextFrame true): the first frame of a clip has no predecessor"),
         }
         if tm:
-            out["stages"] = stage_table(tm)
+            out["stages"] = stage_table(tm, args.steps)
             out["gn_iterations_per_frame"] = round(tm["gn_iterations"] / max(1, tm["frames"]), 2)
         if align_only:
             dt_a, frames_a, tm_a = align_only
             out["align_only"] = {"value": round(frames_a / dt_a, 2), "unit": "frames/s",
-                                 "ms_per_step": round(1e3 * dt_a / args.steps, 4), "stages": stage_table(tm_a),
-                                 "note": "same clips, alignment stages only (no warp launch competing for the CUs)"}
-        if fast_warp:
-            out["fast_warp"] = {"value": round(fast_warp[1] / fast_warp[0], 2), "unit": "frames/s",
-                                "ms_per_step": round(1e3 * fast_warp[0] / args.steps, 4),
-                                "note": "same step with bgr_image_warp in VS_WARP_LANCZOS2_FAST (fused multiply-adds; float output within the "
-                                        "ULP bound and integer output <= 1 LSB / >= 99.99 % identical, tests/test_warp_fast_gpu.py)"}
-        if ev:
-            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # one launch per step over all the rank's frames
-            bytes_per_launch = W * H * 3 * 2 * (1 if bits == 8 else 2) * n * n_clips  # W*H*3*(in+out) B per frame
-            achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-            # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), scaled to
-            # this launch's frame count; null when there is no profile for this frame format
-            traffic = None
+                                 "ms_per_step": round(1e3 * dt_a / args.steps, 4), "stages": stage_table(tm_a, args.steps),
+                                 "note": "same clips, alignment stages only, all frames counted (no warp launch competing for the CUs; "
+                                         "solver kernel in VS_BATCH_EXCLUSIVE mode)"}
+        if contracted:
+            out["contracted_warp"] = {"value": round(contracted[1] / contracted[0], 2), "unit": "frames/s",
+                                      "ms_per_step": round(1e3 * contracted[0] / args.steps, 4),
+                                      "note": "same step with bgr_image_warp in VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as "
+                                              "the reference's own target allows (CMakeLists.txt:151 fma, no strict_float); np.array_equal with the "
+                                              "oracle's VSO_WARP_LANCZOS2_CONTRACTED (tests/test_warp_fast_gpu.py, `parity` below)"}
+        if aw and aw.ev:
+            out["roofline"] = roofline_of(aw, n * n_clips)
+
+    # ---- parity gate + CPU baseline (rank 0 of a one-GPU run; the oracle is the checker, never the thing measured) ----------
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        fh = clips[0][: min(n, 64)].cpu().numpy()
+        if bits != 8:
+            fh = fh.view("uint16")
+        rec = []
+        out["cpu_baseline"] = cpu_baseline(fh, params_kw, wl["stabilizer"], record=rec)
+        out["cpu_baseline"]["cpu_model"] = cpu_model()
+        if aw is not None and rec:
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-                key, per = {(1920, 8): ("c2_1080p_240_frames", 240), (3840, 8): ("c3_4k_32_frames", 32)}[(W, bits)]
-                traffic = int(tj[key]["traffic_bytes"] / per * n * n_clips)
-            except Exception:
-                pass
-            out["roofline"] = {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm", "binding": "valu",
-                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                               "traffic_source": "scaled from the committed PMC passes (profiles/r02_traffic.json), not measured in this run",
-                               "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
-                               "note": "VALU-issue-bound, not HBM-bound: ~230 VALU instructions per output pixel in the "
-                                       "reference's exact fp32 order (DESIGN.md, profiles/r02_bgr_image_warp.md); launches "
-                                       "overlap the next clip's aligner kernels"}
-        if not args.no_roofline_4k:
-            out["roofline_4k"] = roofline_4k(torch, capi, dev, stream)
-        if not args.no_host_fed and aligner is not None:
-            out["host_fed"] = host_fed(torch, capi, dev, clips[0], W, H, fmt, params_kw)
-        if not args.no_cpu_baseline and world == 1:
-            fh = clips[0][: min(n, 64)].cpu().numpy()
-            if bits != 8:
-                fh = fh.view("uint16")
-            out["cpu_baseline"] = cpu_baseline(fh, params_kw, wl["stabilizer"])
-            out["cpu_baseline"]["cpu_model"] = cpu_model()
-            out["cpu_baseline"]["hardware_threads"] = os.cpu_count()
+                out["parity"] = parity_gate(torch, capi, aw, params_kw, rec, fh)
+                if not out["parity"]["pass"]:
+                    rc = 3
+            except Exception as e:      # a gate that cannot run is a failed gate
+                out["parity"] = {"pass": False, "error": repr(e)}
+                rc = 3
+
+    if rank == 0 and not args.no_roofline_4k:
+        out["roofline_4k"] = roofline_4k(torch, capi, dev, stream)
+    if rank == 0 and not args.no_host_fed and aw is not None:
+        out["host_fed"] = host_fed(torch, capi, dev, clips[0], W, H, fmt, params_kw)
+
+    # ---- the 4K half of the metric (default one-GPU run): BASELINE configs[2] through the same step --------------------------
+    if default_run and world == 1 and not args.no_c3 and aw is not None:
+        aw.free()
+        aw = None
+        clips = None
+        try:
+            wl3 = WORKLOADS["c3"]
+            steps3, n3 = max(2, args.steps // 2), wl3["frames"]
+            a3 = AlignWarp(torch, capi, synth, dev, wl3, n3, 1, [wl3["seed"]], params_kw, args, wl3["seed"])
+            a3.step(False)
+            torch.cuda.synchronize()
+            a3.aligner.enable_timing(True)
+            dt3, good3 = timed_loop(lambda: a3.step(True), steps3)
+            tm3 = a3.aligner.timings()
+            a3.step(False, capi.WARP_LANCZOS2_FAST)
+            dt3f, good3f = timed_loop(lambda: a3.step(False, capi.WARP_LANCZOS2_FAST), steps3)
+            out["c3"] = {"workload": wl3["name"], "value": round(good3 * steps3 / dt3, 2), "unit": "frames/s",
+                         "ms_per_step": round(1e3 * dt3 / steps3, 4), "steps": steps3, "frames_per_step": n3, "aligned_per_step": int(good3),
+                         "stages": stage_table(tm3, steps3), "gn_iterations_per_frame": round(tm3["gn_iterations"] / max(1, tm3["frames"]), 2),
+                         "roofline": roofline_of(a3, n3),
+                         "contracted_warp": {"value": round(good3f * steps3 / dt3f, 2), "ms_per_step": round(1e3 * dt3f / steps3, 4)},
+                         "note": "4K level 0 has 20736 tiles per point set: above the small-footprint solver's 16384, so the solver kernel "
+                                 "stays one 512-thread workgroup (+ one helper) per pair"}
+            a3.free()
+        except Exception as e:
+            out["c3"] = {"error": repr(e)}
+
+    # ---- BASELINE configs[3] as a strong-scaling leg: 64 clips in total, clip i -> rank i mod N --------------------------------
+    if default_run and not args.no_c4_strong and (world > 1 or args.c4_strong) and not args.no_warp:
+        if aw is not None:
+            aw.free()
+            aw = None
+            clips = None
+        wl4 = WORKLOADS["c4"]
+        mine = vsdist.shard_clips(args.c4_clips, rank, world)
+        steps4 = 2
+        a4 = AlignWarp(torch, capi, synth, dev, wl4, args.c4_frames, len(mine), [wl4["seed"] + i for i in mine], params_kw, args,
+                       wl4["seed"] + 1000 * rank)
+        a4.step(False)
+        dt4, good4 = timed_loop(lambda: a4.step(False), steps4)
+        per_rank = vsdist.gather_seconds(dt4, device=red_dev)
+        dt4m, frames4, good4t = vsdist.aggregate(dt4, args.c4_frames * len(mine) * steps4, int(good4) * steps4, device=red_dev)
+        if rank == 0:
+            out["c4_strong"] = {"workload": wl4["name"], "clips_total": args.c4_clips, "frames_per_clip": args.c4_frames,
+                                "clips_per_rank": [len(vsdist.shard_clips(args.c4_clips, r, world)) for r in range(world)],
+                                "value": round(good4t / dt4m, 2), "unit": "frames/s", "scaling": "strong", "steps": steps4,
+                                "ms_per_step": round(1e3 * dt4m / steps4, 4), "per_rank_seconds": [round(x, 5) for x in per_rank],
+                                "note": "total work fixed (BASELINE configs[3]); no data-path collective (grid_search_align.cpp:159-210's "
+                                        "independence model); per-rank seconds show a host-side knee if one rank lags"}
+        a4.free()
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -34,12 +34,24 @@ def test_bench_line_contract(gpu_vs):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]
     assert j["align_only"]["value"] > j["value"]
     assert j["rccl_ranks"] == 1
-    # the north star's own operating point: 32 x 4K frames, isolated, exact and fast arithmetic
-    for name in ("exact", "fast"):
+    assert c["all_cores"]["value"] > 0 and c["all_cores"]["cores"] >= c["cores"] and c["usable_threads"] >= 1
+    # `value` counts aligned frames only
+    assert j["frames_per_step"] == 8 and abs(j["value"] - 7 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-3 * j["value"]
+    # the parity gate that rides on the CPU baseline: the timed GPU path against the oracle on the clip's first frames
+    p = j["parity"]
+    assert p["pass"] is True and p["status_equal"] and p["iterations_equal"] and p["transform_max_abs_diff"] <= 1e-4
+    assert p["warp_pixels_equal"] is True and p["contracted_warp_pixels_equal"] is True and p["frames"] == 8
+    # the north star's own operating point: 32 x 4K frames, isolated, exact and contracted arithmetic
+    for name in ("exact", "contracted"):
         q = j["roofline_4k"][name]
         assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
         assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
-    assert j["roofline_4k"]["fast"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
+    assert j["roofline_4k"]["contracted"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
+    assert j["contracted_warp"]["value"] > 0
+    # the 4K half of the metric (BASELINE configs[2]) in the same line
+    c3 = j["c3"]
+    assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
+    assert c3["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120 and "gn" in c3["stages"]
     hf = j["host_fed"]
     assert hf["identical_to_device_resident"] is True and hf["value"] > 0 and 0 < hf["of_pinned_h2d"] <= 1.05
 
@@ -49,7 +61,8 @@ def test_bench_spawns_its_own_ranks(gpu_vs):
     GPU of the box; the real run is nccl = RCCL with one GPU per rank) and rank 0 reports n_gpus == 2."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0"],
+                          "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0",
+                          "--c4-clips", "5", "--c4-frames", "6"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -57,6 +70,11 @@ def test_bench_spawns_its_own_ranks(gpu_vs):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "gloo"
     assert j["aligned_per_step"] == 2 * 5                           # both ranks' clips are counted
+    # N > 1, default workload: BASELINE configs[3] as a strong-scaling leg beside the weak `value` (here 5 clips of 6 frames:
+    # clip i -> rank i mod 2), with every rank's seconds
+    s = j["c4_strong"]
+    assert s["scaling"] == "strong" and s["clips_total"] == 5 and s["clips_per_rank"] == [3, 2] and len(s["per_rank_seconds"]) == 2
+    assert s["value"] > 0 and all(x > 0 for x in s["per_rank_seconds"])
 
 
 def test_bench_two_ranks_gloo_rehearsal(gpu_vs):
@@ -65,7 +83,8 @@ def test_bench_two_ranks_gloo_rehearsal(gpu_vs):
     for r in range(2):
         env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2",
-                                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0"],
+                                       "--warmup", "1", "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0",
+                                       "--no-c4-strong"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (o, e) in zip(procs, outs):

@@ -23,7 +23,8 @@ time.sleep(0.05 * (rank + 1))
 d.barrier()
 dt = time.perf_counter() - t0
 secs, tot_f, tot_a = D.aggregate(dt, frames, aligned)
-print(json.dumps({"rank": rank, "clips": clips, "secs": secs, "frames": tot_f, "aligned": tot_a, "own": dt}))
+per_rank = D.gather_seconds(dt)
+print(json.dumps({"rank": rank, "clips": clips, "secs": secs, "frames": tot_f, "aligned": tot_a, "own": dt, "per_rank": per_rank}))
 d.destroy_process_group()
 '''
 
@@ -49,6 +50,14 @@ def test_two_rank_gloo_shard_and_aggregate(tmp_path):
         assert o["frames"] == total and o["aligned"] == total - 7
         assert o["secs"] >= max(x["own"] for x in outs) - 1e-9        # max over ranks, identical on every rank
     assert outs[0]["secs"] == outs[1]["secs"]
+    # the per-rank view (bench.py's c4_strong.per_rank_seconds): every rank sees every rank's own seconds, in rank order
+    for o in outs:
+        assert o["per_rank"] == [outs[0]["own"], outs[1]["own"]] and max(o["per_rank"]) == o["secs"]
+
+
+def test_gather_seconds_without_a_process_group():
+    from video_stabilizer_amd import dist as D
+    assert D.gather_seconds(1.25) == [1.25]
 
 
 def test_shard_covers_every_clip_once():

@@ -36,3 +36,15 @@ def aggregate(seconds, frames, aligned, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c[0].item()), int(c[1].item())
+
+
+def gather_seconds(seconds, device=None):
+    """every rank's seconds, in rank order (the per-rank view beside aggregate()'s maximum: a rank that lags shows up here)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(seconds)]
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
