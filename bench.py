@@ -291,7 +291,7 @@ class AlignWarp:
     def __init__(self, torch, capi, synth, dev, wl, n, n_clips, seeds, params_kw, args, factory_seed):
         self.torch, self.capi, self.dev, self.wl, self.n, self.n_clips, self.args = torch, capi, dev, wl, n, n_clips, args
         self.W, self.H, self.bits = wl["w"], wl["h"], wl["bits"]
-        self.fmt = capi.FMT_BGR8 if self.bits == 8 else capi.FMT_BGR16
+        self.fmt = capi.FMT_BGR8 if self.bits == 8 else capi.FMT_BGR10
         self.max_value = 255 if self.bits == 8 else (1 << self.bits) - 1
         factory = synth.TorchClipFactory(self.W, self.H, factory_seed, dev, channels=3, bits=self.bits)
         dt = torch.uint8 if self.bits == 8 else torch.int16
@@ -453,7 +453,7 @@ def main():
     W, H, bits = wl["w"], wl["h"], wl["bits"]
     n = args.frames or wl["frames"]
     n_clips = args.clips_per_gpu or wl["clips"]
-    fmt = capi.FMT_BGR8 if bits == 8 else capi.FMT_BGR16
+    fmt = capi.FMT_BGR8 if bits == 8 else capi.FMT_BGR10
     params_kw = {} if args.default_levels else dict(pyramid_min_width=256)
     if args.phase_correlate:
         params_kw["phase_correlate"] = 1

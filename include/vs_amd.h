@@ -35,11 +35,16 @@ extern "C" {
 
 enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
 /* Frame formats.  16-bit containers say how many bits the samples really use: the aligner derives its 8-bit luma with
- * gray >> (bits - 8) and the stabilizer's warp saturates at (1 << bits) - 1.  VS_FMT_BGR16 is the historical name of the
- * 10-bit format (BASELINE config 5, "4K 10-bit BGR"); the reference itself is 8-bit only (imgproc.cpp:207-209). */
-enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR10 = 2, VS_FMT_BGR16 = 2, VS_FMT_BGR12 = 3, VS_FMT_BGR16_FULL = 4 };
-/* bits per sample of a format: 8, 10, 12 or 16; 0 for an unknown format */
+ * gray >> (bits - 8) and the stabilizer's warp saturates at vs_format_max_value().  The reference itself is 8-bit only
+ * (imgproc.cpp:207-209); BASELINE config 5 ("4K 10-bit BGR") is VS_FMT_BGR10.
+ * VS_FMT_BGR16 is the format of the first release, kept with the behaviour it had there and a value of its own: a u16
+ * container whose luma is taken as 10-bit (gray >> 2) while the warp saturates at 65535 -- callers that pass it with 12- or
+ * 16-bit samples keep every sample value (it used to alias VS_FMT_BGR10 and clipped them to 1023). */
+enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR10 = 2, VS_FMT_BGR12 = 3, VS_FMT_BGR16_FULL = 4, VS_FMT_BGR16 = 5 };
+/* bits per sample the alignment luma assumes: 8, 10, 12 or 16 (VS_FMT_BGR16: 10); 0 for an unknown format */
 int vs_format_bits(int format);
+/* largest sample value the stabilizer's warp stores: 255, 1023, 4095, 65535 (VS_FMT_BGR16: 65535); 0 for an unknown format */
+int vs_format_max_value(int format);
 /* VS_WARP_LANCZOS2: the reference sampler's exact sequence of fp32 roundings (bit-identical to the CPU restatement).
  * VS_WARP_LANCZOS2_FAST: opt-in, same sampler with fused multiply-adds and one refined reciprocal; integer outputs stay
  * within 1 LSB of the exact mode (> 99.9 % identical), ~1.4x faster.  Tuned for 3-channel integer frames; other

@@ -53,7 +53,7 @@ class AlignDebug(C.Structure):
 
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
-FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
+FMT_GRAY8, FMT_BGR8 = 0, 1
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4
 
 _lib = None
@@ -450,7 +450,7 @@ def _fmt_of(frame):
         assert frame.dtype == np.uint8
         return FMT_GRAY8
     assert frame.ndim == 3 and frame.shape[2] == 3
-    return FMT_BGR8 if frame.dtype == np.uint8 else FMT_BGR16
+    return FMT_BGR8 if frame.dtype == np.uint8 else FMT_BGR10
 
 
 class Aligner:

@@ -71,7 +71,7 @@ static void TestImageWarpCorrectness() {                               // align_
 // height(), channels(), dimensions(), dim(i).stride() / .extent(), (w, h[, c]) constructors, planar dense allocation): the
 // operator templates of the facade must give the same bytes through it as through vs::Buffer<T>.
 namespace halide_like {
-struct Dim { int e, s; int extent() const { return e; } int stride() const { return s; } };
+struct Dim { int e, s, m = 0; int extent() const { return e; } int stride() const { return s; } int min() const { return m; } };
 template <typename T, int Dims = -1, int InClassDimStorage = 4>
 class Buffer {
 public:
@@ -87,7 +87,13 @@ public:
     T* data() { return own_.data(); }
     const T* data() const { return own_.data(); }
     T& operator()(int x, int y = 0, int c = 0) { return own_[((size_t)c * height() + y) * width() + x]; }
+    // what Halide::Runtime::Buffer offers beyond the dense case: crops (non-zero min), strided views, the host-dirty flag
+    void set_min(int d, int m) { d_[d].m = m; }
+    void set_stride(int d, int st) { d_[d].s = st; }
+    void set_host_dirty(bool v = true) { dirty_ = v; }
+    bool host_dirty() const { return dirty_; }
 private:
+    bool dirty_ = false;
     std::vector<Dim> d_;
     std::vector<T> own_;
 };
@@ -126,6 +132,9 @@ static std::vector<double> run_chain(const std::vector<uint8_t>& g0, const std::
     F32 warped(w, h);
     CHECK(ImageWarp(a, T, warped));
     for (int y = 3; y < h; y += 11) for (int x = 2; x < w; x += 9) sig.push_back(warped(x, y));
+    if constexpr (vs::has_host_dirty<F32>::value)          // outputs written through the host pointer are marked for buffer classes that track it
+        CHECK(half.host_dirty() && gx.host_dirty() && gy.host_dirty() && lmx.host_dirty() && jy.host_dirty() && wdx.host_dirty() &&
+              jtr.host_dirty() && warped.host_dirty() && !a.host_dirty());
     return sig;
 }
 
@@ -159,6 +168,35 @@ static void AlignImagePair() {                                         // align_
     CHECK(produced == 3);
 }
 
+// a cropped or strided Halide buffer must be refused, not written as if it were dense -- inputs and outputs alike, including an
+// existing output whose shape already matches (no device is touched: the checks come first)
+static void TestViewsAreRefused() {
+    using U8 = halide_like::Buffer<uint8_t>; using F32 = halide_like::Buffer<float>; using U16 = halide_like::Buffer<uint16_t>;
+    U8 in(64, 48), out(32, 24), crop(32, 24), strided(32, 24);
+    crop.set_min(0, 4);
+    strided.set_stride(1, 40);
+    CHECK(!PyrDown(in, crop) && !PyrDown(in, strided) && !PyrDown(crop, out));
+    F32 gx(64, 48), gy(64, 48), gcrop(64, 48);
+    gcrop.set_min(1, 2);
+    CHECK(!GradXY(in, gcrop, gy) && !GradXY(in, gx, gcrop));
+    U16 lmx(32, 24, 2), lmy(32, 24, 2);                   // 64x48 -> tile size 2 -> 32 x 24 tiles: shapes match, no reallocation
+    lmy.set_min(0, 1);
+    int ts = 0;
+    CHECK(!GradArgMax(gx, gy, ts, lmx, lmy) && ts == 2);
+    U16 lm2(32, 24, 2), lmok(32, 24, 2);
+    F32 jx(32, 24, 4), jy(32, 24, 4);
+    jy.set_stride(2, 32 * 24 + 1);
+    CHECK(!SparseJacobian(gx, gy, lm2, lmok, jx, jy));
+    U16 wd(32, 24);
+    wd.set_min(1, 1);
+    SimilarityTransform T;
+    CHECK(!SparseWarpDiff(in, in, lm2, T, wd));
+    F32 warped(64, 48);
+    warped.set_stride(1, 70);
+    CHECK(!ImageWarp(in, T, warped));
+    CHECK(!out.host_dirty() && !gx.host_dirty());         // nothing was written
+}
+
 static void TestOperatorsThroughBothBufferClasses() {
     const int w = 320, h = 240;
     auto c0 = texture(w, h, 0, 0), c1 = texture(w, h, 0.75, -0.5);
@@ -177,6 +215,7 @@ int main(int argc, char** argv) {
     TestSimilarityTransformInverse();
     TestSimilarityTransformCompose();
     TestRandomized();
+    TestViewsAreRefused();
     if (mode == "gpu") {
         TestImageWarpCorrectness();
         TestOperatorsThroughBothBufferClasses();

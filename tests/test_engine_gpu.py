@@ -209,6 +209,45 @@ def test_deep_formats_carry_their_bit_depth(gpu_vs, oracle, bits, fmt_name):
     assert outs == 11
 
 
+def test_full_range_u16_through_the_batch_entry_points(gpu_vs):
+    """Every batch / clip entry point takes fmt=: full-range 16-bit frames keep their range through process_batch (declared
+    FMT_BGR16_FULL) and equal the frame-at-a-time path; the first release's FMT_BGR16 (10-bit luma, 65535 saturation) has a
+    value of its own again and no longer clips samples to 1023; undeclared u16 frames are 10-bit (clipped at 1023)."""
+    from video_stabilizer_amd import synth
+    f10, _ = synth.make_clip(480, 270, 8, seed=73, channels=3, bits=10)
+    frames = (f10.astype(np.uint32) << 6).astype(np.uint16)                 # full 16-bit range
+    kw = dict(lag=2, crop_pixels=8, warp_mode=gpu_vs.WARP_LANCZOS2)
+    assert gpu_vs.FMT_BGR16 not in (gpu_vs.FMT_BGR10, gpu_vs.FMT_BGR12, gpu_vs.FMT_BGR16_FULL)
+    assert gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR16) == 65535 and gpu_vs.lib().vs_format_bits(gpu_vs.FMT_BGR16) == 10
+    assert gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR10) == 1023 and gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR16_FULL) == 65535
+    # declared full range: batch == frame at a time, nothing clipped
+    out_b, has_b = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames, fmt=gpu_vs.FMT_BGR16_FULL)
+    seq = gpu_vs.Stabilizer(device=0, **kw)
+    for i, f in enumerate(frames):
+        o = seq.process(f, fmt=gpu_vs.FMT_BGR16_FULL)
+        assert (o is not None) == bool(has_b[i])
+        if o is not None:
+            assert np.array_equal(o, out_b[i])
+    assert sum(has_b) == len(frames) - 2 and int(out_b.max()) > 40000
+    # clips form and the aligner's batch forms take the format too (same transforms as frame at a time)
+    out_c, has_c = gpu_vs.Stabilizer(device=0, **kw).process_clips(frames, 1, fmt=gpu_vs.FMT_BGR16_FULL)
+    assert has_c == has_b and np.array_equal(out_c, out_b)
+    al = gpu_vs.Aligner(device=0)
+    st_b, ts_b = al.align_batch(frames, fmt=gpu_vs.FMT_BGR16_FULL)
+    one = gpu_vs.Aligner(device=0)
+    for i, f in enumerate(frames):
+        ok, t = one.align_next(f, fmt=gpu_vs.FMT_BGR16_FULL)
+        assert bool(st_b[i]) == ok and t.tup() == ts_b[i].tup()
+    st_c, ts_c = gpu_vs.Aligner(device=0).align_clips(frames, 1, fmt=gpu_vs.FMT_BGR16_FULL)
+    assert st_c == st_b and [t.tup() for t in ts_c] == [t.tup() for t in ts_b]
+    # the first release's format: full-range output (not clipped to 1023)
+    out_l, has_l = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames, fmt=gpu_vs.FMT_BGR16)
+    assert has_l == has_b and int(out_l.max()) > 40000
+    # undeclared u16 = 10-bit: saturates at 1023
+    out_d, _ = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames)
+    assert int(out_d.max()) == 1023
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_stabilizer_matches_oracle(gpu_vs, oracle, mode):
     from video_stabilizer_amd import synth

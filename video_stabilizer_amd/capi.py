@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VS_AMD_LIB", os.path.join(_HERE, "libvs_amd.so"))
 
 MEM_HOST, MEM_DEVICE = 0, 1
-FMT_GRAY8, FMT_BGR8, FMT_BGR16 = 0, 1, 2
-FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use (FMT_BGR16 == FMT_BGR10)
+FMT_GRAY8, FMT_BGR8 = 0, 1
+FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use
+FMT_BGR16 = 5                                       # first-release format: 10-bit luma (gray >> 2), warp output saturates at 65535
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE = 0, 1
@@ -81,6 +82,7 @@ SIGNATURES = {
     "vs_version": (C.c_char_p, []),
     "vs_device_count": (_i32, []),
     "vs_format_bits": (_i32, [_i32]),
+    "vs_format_max_value": (_i32, [_i32]),
     "vs_aligner_stream": (_vp, [_vp]),
     "vs_aligner_wait_stream": (_i32, [_vp, _vp]),
     "vs_stabilizer_stream": (_vp, [_vp]),
@@ -470,7 +472,7 @@ def bgr_to_gray(src, shift_to_8=None):
 def _fmt_of(frame_dtype, ndim_tail):
     if ndim_tail == 2:
         return FMT_GRAY8
-    return FMT_BGR8 if frame_dtype == np.uint8 else FMT_BGR16
+    return FMT_BGR8 if frame_dtype == np.uint8 else FMT_BGR10      # u16 numpy frames are 10-bit unless the caller passes fmt=
 
 
 class Aligner:
@@ -499,11 +501,11 @@ class Aligner:
         r = _check(lib().vs_aligner_align_next(self.h, _p(frame), ww, hh, stride, fmt, MEM_HOST, C.byref(self.params), C.byref(t)))
         return bool(r), t
 
-    def align_batch(self, frames):
+    def align_batch(self, frames, fmt=None):
         """frames: numpy (n,h,w[,3]).  returns (status[n], [Transform]*n)"""
         frames = np.ascontiguousarray(frames)
         n = frames.shape[0]
-        fmt = _fmt_of(frames.dtype, frames.ndim - 1)
+        fmt = _fmt_of(frames.dtype, frames.ndim - 1) if fmt is None else fmt
         hh, ww = frames.shape[1:3]
         ch = 1 if fmt == FMT_GRAY8 else 3
         out = (Transform * n)()
@@ -529,7 +531,7 @@ class Aligner:
         if mem_ptr is None:
             frames = np.ascontiguousarray(frames)
             n = frames.shape[0]
-            fmt = _fmt_of(frames.dtype, frames.ndim - 1)
+            fmt = _fmt_of(frames.dtype, frames.ndim - 1) if fmt is None else fmt
             h, w = frames.shape[1:3]
             ptr, mem = _p(frames), MEM_HOST
         else:
@@ -621,12 +623,12 @@ class Stabilizer:
     def wait_stream(self, stream_handle):
         _check(lib().vs_stabilizer_wait_stream(self.h, C.c_void_p(stream_handle)))
 
-    def process_batch(self, frames, out=None):
+    def process_batch(self, frames, out=None, fmt=None):
         """frames (n,h,w,3) numpy.  returns (outputs (n,oh,ow,3), has_output list).  out: a buffer of that shape to reuse
         (frames without an output are left untouched in it)"""
         frames = np.ascontiguousarray(frames)
         n, hh, ww = frames.shape[:3]
-        fmt = _fmt_of(frames.dtype, 3)
+        fmt = _fmt_of(frames.dtype, 3) if fmt is None else fmt
         c = max(self.params.crop_pixels, 0)
         if out is None:
             out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
@@ -646,11 +648,11 @@ class Stabilizer:
                                                      (h - 2 * c) * (w - 2 * c) * 3, has, C.byref(ow), C.byref(oh)))
         return r, list(has)
 
-    def process_clips(self, frames, n_clips):
+    def process_clips(self, frames, n_clips, fmt=None):
         """frames (n_clips*fpc, h, w, 3) numpy: every clip through a fresh stabilizer, batched together"""
         frames = np.ascontiguousarray(frames)
         n, hh, ww = frames.shape[:3]
-        fmt = _fmt_of(frames.dtype, 3)
+        fmt = _fmt_of(frames.dtype, 3) if fmt is None else fmt
         c = max(self.params.crop_pixels, 0)
         out = np.zeros((n, hh - 2 * c, ww - 2 * c, 3), frames.dtype)
         has = (C.c_int32 * n)()

@@ -27,3 +27,6 @@ done
 for p in $pids; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs
 echo "built $OUT"
+# link-level drop-in for the reference's sixteen Halide AOT symbols (include/vs_halide_abi.h): plain host C++ on libvs_amd.so
+g++ -std=c++17 -O2 -fPIC -Wall -shared -o "$HERE/../libvs_halide_abi.so" "$HERE/vs_halide_abi.cpp" -L"$HERE/.." -lvs_amd '-Wl,-rpath,$ORIGIN'
+echo "built $HERE/../libvs_halide_abi.so"

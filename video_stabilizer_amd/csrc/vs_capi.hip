@@ -72,8 +72,8 @@ using vsi::set_error;
 // is tracked as busy from the moment its copy is enqueued (an event is recorded right behind the copy) and fence() moves
 // that event behind the consuming kernel; it is reused only after its event has completed, so the source of an in-flight
 // copy is never overwritten -- also when the call fails between upload() and fence().
-// One ring per (thread, device): calls from different threads or for different devices never wait on each other and need
-// no lock (the header promises that distinct handles are independent).  Events are pooled, not created per call.
+// One ring per (running thread, device): calls from different threads or for different devices never wait on each other and
+// need no lock on the call path (the header promises that distinct handles are independent).  Events are pooled.
 namespace {
 struct ParamRing {
     static constexpr size_t kSlots = 1 << 15;    // 32768 float4 = 512 KiB
@@ -126,13 +126,35 @@ struct ParamRing {
         return VS_OK;
     }
 };
-// rings live for the life of the process (no teardown at thread exit: the HIP runtime may already be gone by then)
+// A thread takes a ring per device on first use and hands it back to a process-wide pool when it exits; the next thread that
+// needs one for that device reuses it (its in-flight spans are retired by event as always).  So the pinned / device memory
+// held is bounded by the largest number of threads that were inside bgr_image_warp entry points at the same time, not by the
+// number of threads that ever called one (a thread-per-frame caller used to leave 1 MiB behind per thread).  Nothing is freed
+// at thread or process exit: the HIP runtime may already be gone by then.
+struct RingPool {
+    std::mutex mu;
+    std::vector<ParamRing*> free_[16];
+};
+RingPool& ring_pool() { static RingPool* p = new RingPool(); return *p; }      // never destroyed: outlives every thread's holder
+struct RingHolder {
+    ParamRing* r[16] = {};
+    ~RingHolder() {
+        RingPool& p = ring_pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        for (int d = 0; d < 16; d++) if (r[d]) p.free_[d].push_back(r[d]);
+    }
+};
 ParamRing* param_ring() {
-    thread_local ParamRing* rings[16] = {};
+    thread_local RingHolder holder;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return nullptr;
-    if (!rings[device]) rings[device] = new ParamRing();
-    return rings[device];
+    if (!holder.r[device]) {
+        RingPool& p = ring_pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        if (!p.free_[device].empty()) { holder.r[device] = p.free_[device].back(); p.free_[device].pop_back(); }
+        else holder.r[device] = new ParamRing();
+    }
+    return holder.r[device];
 }
 }  // namespace
 

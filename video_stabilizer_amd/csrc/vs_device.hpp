@@ -48,7 +48,7 @@ __device__ __forceinline__ void lanczos_weights4(float frac, float w[4]) {
 //   num    = fma(w2d, val, num)                     rx inner, ry outer, from 0 (:694)
 //   den    = den + w2d                              (:695: nothing of its own to fuse)
 //   out    = num / den                              one IEEE divide (:697)
-// Its CPU twin is oracle/vs_oracle.cpp VSO_WARP_LANCZOS2_CONTRACTED (std::fmaf), pinned by a literal restatement with an
+// Its CPU twin is the checker's VSO_WARP_LANCZOS2_CONTRACTED (oracle/, std::fmaf), pinned by a literal restatement with an
 // exact rational fma (tests/test_oracle_known_answers.py); every kernel that offers the mode is bit-identical to it
 // (tests/test_warp_fast_gpu.py: np.array_equal on float and integer outputs).
 __device__ __forceinline__ float lanczos2_fma(float x) {

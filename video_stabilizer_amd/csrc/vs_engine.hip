@@ -318,6 +318,8 @@ struct vs_aligner {
     vs_aligner_params params;
     int select_mode = VS_SELECT_DEVICE;   // same survivors in the same order as the host path (tests/test_select_gpu.py)
     int batch_mode = VS_BATCH_EXCLUSIVE;  // VS_BATCH_SHARED: full batches through the small-footprint solver kernel
+    int cu_count = kChipCUs;              // hipDeviceProp_t::multiProcessorCount of `device` (vs_aligner_create)
+    bool coop_ok = true;                  // helper workgroups: only on the architecture their sc1 hand-offs were validated on (gfx950)
 
     // sequence state (alignment.hpp:61-70)
     int W = -1, H = -1, fmt = -1;
@@ -766,8 +768,8 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
             static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
             int group = 1;
-            if (n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles)
-                group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : std::max(1, std::min(kCoopGroup, kChipCUs / n_pairs));
+            if (coop_ok && n_pairs <= kCoopMaxPairs && L[0].nt >= kCoopMinTiles)
+                group = coop_env >= 0 ? std::max(1, std::min(coop_env, kCoopMaxGroup)) : std::max(1, std::min(kCoopGroup, cu_count / n_pairs));
             // full batches of a handle in VS_BATCH_SHARED mode: the small-footprint build (shares CUs with whatever else is
             // running, e.g. the previous clip's warp launch); VS_GN_CORESIDENT=0 / 1 overrides the rule (1: every launch, helpers off)
             bool cores = false;
@@ -823,6 +825,12 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
                 if (!all) VS_HIP(hipStreamSynchronize(s));
+                else {
+                    // the results are in; helper workgroups may still be winding down, and a fault in any of them must be this
+                    // call's error, not the next one's: one non-blocking look at the stream
+                    const hipError_t qe = hipStreamQuery(s);
+                    if (qe != hipSuccess && qe != hipErrorNotReady) VS_HIP(qe);
+                }
             } else {
                 VS_HIP(hipStreamSynchronize(s));
             }
@@ -952,6 +960,13 @@ vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
     if (hipSetDevice(device) != hipSuccess) { set_error(VS_ERR_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
     vs_aligner* a = new vs_aligner();
     a->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) a->cu_count = prop.multiProcessorCount;
+            a->coop_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        }
+    }
     if (params) a->params = *params; else vs_aligner_params_default(&a->params);
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error(VS_ERR_HIP, "hipStreamCreate failed");
@@ -1252,7 +1267,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
                                     out_w, out_h);
     else
-        r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, mem, 0, out, out_frame_stride, has_output,
+        r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, mem, -1, out, out_frame_stride, has_output,
                           out_w, out_h);
     if (s) for (auto& f : s->down) if (f.valid()) {          // every download has landed before the call returns
         const hipError_t de = f.get();
@@ -1320,8 +1335,13 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
 }
 
 static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
-                         int format, int mem, int out_mem, int slot, void* out, size_t out_frame_stride, int32_t* has_output,
+                         int format, int mem, int out_mem, int slot_arg, void* out, size_t out_frame_stride, int32_t* has_output,
                          int* out_w, int* out_h) {
+    // slot_arg >= 0: a chunk of the pipelined host batch -- its outputs leave through output area `slot_arg` and a downloader
+    // thread of their own, under the next chunk's compute.  slot_arg < 0: a call on its own (process / process_batch that fits
+    // one chunk): the copies go onto the handle's stream, nothing to overlap with, no thread.
+    const bool threaded_download = slot_arg >= 0;
+    const int slot = threaded_download ? slot_arg : 0;
     VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
     VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0);
     VS_ARG(stride >= 3 * w);
@@ -1460,7 +1480,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
                                 : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
             const size_t dst_fs = to_host ? (size_t)ow * oh * 3 : out_frame_stride;
             int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
-                                                 s->params.warp_mode, s->params.warp_border, (1 << fbits) - 1, crop, crop, ow, oh,
+                                                 s->params.warp_mode, s->params.warp_border, vs_format_max_value(format), crop, crop, ow, oh,
                                                  dst, dst_fs, ow * 3, VS_MEM_DEVICE, st);
             if (wr < 0) return wr;
             j = e;
@@ -1468,6 +1488,18 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         for (size_t j = 0; j < jobs.size(); j++)
             if (jobs[j].release) s->pool.push_back(jobs[j].release);   // reused only by later work on this stream
         if (to_host) {
+            const bool dense_out = out_frame_stride * esz == obytes;
+            if (!threaded_download) {
+                // runs of outputs that are contiguous on both sides as one copy, behind the warps on the same stream; the
+                // synchronisation at the end of this call covers them
+                for (size_t j = 0; j < jobs.size();) {
+                    size_t k = j + 1;
+                    while (dense_out && k < jobs.size() && jobs[k].i == jobs[k - 1].i + 1) k++;
+                    VS_HIP(hipMemcpyAsync((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz,
+                                          (const uint8_t*)s->batch_out[slot] + j * obytes, obytes * (k - j), hipMemcpyDeviceToHost, st));
+                    j = k;
+                }
+            } else {
             // hand the area to the downloader: it waits (on its own stream) for the warps above, then copies every output
             // to the caller's memory -- runs of outputs that are contiguous on both sides as one copy
             if (!s->down_stream) VS_HIP(hipStreamCreateWithFlags(&s->down_stream, hipStreamNonBlocking));
@@ -1492,6 +1524,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
                 }
                 return e != hipSuccess ? e : hipStreamSynchronize(ds);
             });
+            }
         }
     }
     if (clip_len > 0) VS_TRY(vs_stabilizer_reset(s));   // nothing carries over from the last clip

@@ -83,14 +83,28 @@ namespace vs {
 template <class B> using elem_t = std::remove_cv_t<std::remove_pointer_t<decltype(std::declval<B&>().data())>>;
 template <class B, class = void> struct has_dim : std::false_type {};
 template <class B> struct has_dim<B, std::void_t<decltype(std::declval<const B&>().dim(0).stride())>> : std::true_type {};
+template <class B, class = void> struct has_min : std::false_type {};
+template <class B> struct has_min<B, std::void_t<decltype(std::declval<const B&>().dim(0).min())>> : std::true_type {};
+template <class B, class = void> struct has_host_dirty : std::false_type {};
+template <class B> struct has_host_dirty<B, std::void_t<decltype(std::declval<B&>().set_host_dirty())>> : std::true_type {};
+// a buffer the kernels can address: host memory, dense planar strides, every dimension starting at 0 (a cropped or strided
+// Halide buffer is refused, never written as if it were dense)
 template <class B>
 inline bool dense(const B& b) {
     if constexpr (has_dim<B>::value) {
         long want = 1;
-        for (int d = 0; d < b.dimensions(); d++) { if (b.dim(d).stride() != want) return false; want *= b.dim(d).extent(); }
+        for (int d = 0; d < b.dimensions(); d++) {
+            if (b.dim(d).stride() != want) return false;
+            if constexpr (has_min<B>::value) { if (b.dim(d).min() != 0) return false; }
+            want *= b.dim(d).extent();
+        }
     }
     return b.data() != nullptr;
 }
+template <class... Bs> inline bool all_dense(const Bs&... bs) { return (dense(bs) && ...); }
+// outputs were written through their host pointer: tell a buffer class that tracks it (Halide::Runtime::Buffer does)
+template <class B> inline void wrote(B& b) { if constexpr (has_host_dirty<B>::value) b.set_host_dirty(); }
+template <class... Bs> inline bool done(bool ok, Bs&... outs) { if (ok) (wrote(outs), ...); return ok; }
 template <class B>
 inline int channels_of(const B& b) {
     if constexpr (has_dim<B>::value) return b.dimensions() > 2 ? (int)b.dim(2).extent() : 1;
@@ -102,16 +116,19 @@ inline int channels_of(const B& b) {
 template <class BIn, class BOut>
 inline bool PyrDown(BIn& input, BOut& output) {
     static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, uint8_t>::value, "PyrDown: u8 -> u8");
-    if (!vs::dense(input) || !vs::dense(output)) return false;
-    return vs_pyr_down(input.data(), input.width(), input.height(), input.width(), output.data(), output.width(), output.height(),
-                       output.width(), VS_MEM_HOST, nullptr) == 0;
+    if (!vs::all_dense(input, output)) return false;
+    return vs::done(vs_pyr_down(input.data(), input.width(), input.height(), input.width(), output.data(), output.width(), output.height(),
+                                output.width(), VS_MEM_HOST, nullptr) == 0, output);
 }
 // imgproc.cpp:135-142
 template <class BIn, class BOut>
 inline bool GradXY(BIn& input, BOut& output_x, BOut& output_y) {
     static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, float>::value, "GradXY: u8 -> f32, f32");
-    if (!vs::dense(input) || !vs::dense(output_x) || !vs::dense(output_y)) return false;
-    return vs_grad_xy(input.data(), input.width(), input.height(), input.width(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
+    if (!vs::all_dense(input, output_x, output_y)) return false;
+    if (output_x.width() != input.width() || output_x.height() != input.height() || output_y.width() != input.width() ||
+        output_y.height() != input.height()) return false;
+    return vs::done(vs_grad_xy(input.data(), input.width(), input.height(), input.width(), output_x.data(), output_y.data(), VS_MEM_HOST,
+                               nullptr) == 0, output_x, output_y);
 }
 // imgproc.cpp:144-202 (tile-size rule + (re)allocation + dispatch)
 template <class BGrad, class BMax>
@@ -123,9 +140,13 @@ inline bool GradArgMax(BGrad& grad_x, BGrad& grad_y, int& tile_size, BMax& local
         local_max_x = BMax(wt, ht, 2);
         local_max_y = BMax(wt, ht, 2);
     }
-    if (!vs::dense(grad_x) || !vs::dense(grad_y)) return false;
-    return vs_grad_argmax(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), tile_size, local_max_x.data(), local_max_y.data(),
-                          VS_MEM_HOST, nullptr) == 0;
+    // every buffer is checked, the outputs after their (re)allocation: an existing output of the right shape may still be a
+    // cropped or strided view
+    if (!vs::all_dense(grad_x, grad_y, local_max_x, local_max_y)) return false;
+    if (local_max_y.dimensions() != 3 || local_max_y.width() != wt || local_max_y.height() != ht || vs::channels_of(local_max_x) != 2 ||
+        vs::channels_of(local_max_y) != 2 || grad_y.width() != grad_x.width() || grad_y.height() != grad_x.height()) return false;
+    return vs::done(vs_grad_argmax(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), tile_size, local_max_x.data(),
+                                   local_max_y.data(), VS_MEM_HOST, nullptr) == 0, local_max_x, local_max_y);
 }
 // imgproc.cpp:26-44
 template <class BGrad, class BMax, class BJac>
@@ -136,9 +157,12 @@ inline bool SparseJacobian(BGrad& grad_x, BGrad& grad_y, BMax& local_max_x, BMax
         output_x = BJac(local_max_x.width(), local_max_x.height(), 4);
         output_y = BJac(local_max_x.width(), local_max_x.height(), 4);
     }
-    if (!vs::dense(grad_x) || !vs::dense(grad_y) || !vs::dense(local_max_x) || !vs::dense(local_max_y)) return false;
-    return vs_sparse_jac(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), local_max_x.data(), local_max_y.data(),
-                         local_max_x.width(), local_max_x.height(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0;
+    if (!vs::all_dense(grad_x, grad_y, local_max_x, local_max_y, output_x, output_y)) return false;
+    if (output_y.dimensions() != 3 || output_y.width() != local_max_x.width() || output_y.height() != local_max_x.height() ||
+        vs::channels_of(output_x) != 4 || vs::channels_of(output_y) != 4) return false;
+    return vs::done(vs_sparse_jac(grad_x.data(), grad_y.data(), grad_x.width(), grad_x.height(), local_max_x.data(), local_max_y.data(),
+                                  local_max_x.width(), local_max_x.height(), output_x.data(), output_y.data(), VS_MEM_HOST, nullptr) == 0,
+                    output_x, output_y);
 }
 // imgproc.cpp:46-78: selected_pixels (n,2) u16, selected_jacobians (n,4) f32
 template <class BImg, class BPix, class BJac, class BOut>
@@ -148,14 +172,14 @@ inline bool SparseICA(BImg& input_template, BImg& input_keyframe, BPix& selected
                   std::is_same<vs::elem_t<BJac>, float>::value && std::is_same<vs::elem_t<BOut>, double>::value,
                   "SparseICA: u8, u8, u16, u16, f32, f32 -> f64");
     if (output.dimensions() != 1 || output.width() != 4) output = BOut(4);
-    if (!vs::dense(input_template) || !vs::dense(input_keyframe) || !vs::dense(selected_pixels_x) || !vs::dense(selected_pixels_y) ||
-        !vs::dense(selected_jacobians_x) || !vs::dense(selected_jacobians_y)) return false;
+    if (!vs::all_dense(input_template, input_keyframe, selected_pixels_x, selected_pixels_y, selected_jacobians_x, selected_jacobians_y, output))
+        return false;
     float p[4];
     vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
-    return vs_sparse_ica(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(), input_keyframe.width(),
+    return vs::done(vs_sparse_ica(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(), input_keyframe.width(),
                          selected_pixels_x.data(), selected_pixels_x.width(), selected_pixels_y.data(), selected_pixels_y.width(),
                          selected_jacobians_x.data(), selected_jacobians_y.data(), p[0], p[1], p[2], p[3], output.data(), VS_MEM_HOST,
-                         nullptr) == 0;
+                         nullptr) == 0, output);
 }
 // imgproc.cpp:80-106
 template <class BImg, class BMax>
@@ -163,22 +187,22 @@ inline bool SparseWarpDiff(BImg& input_template, BImg& input_keyframe, BMax& loc
     static_assert(std::is_same<vs::elem_t<BImg>, uint8_t>::value && std::is_same<vs::elem_t<BMax>, uint16_t>::value, "SparseWarpDiff: u8, u8, u16 -> u16");
     if (output.dimensions() != 2 || output.width() != local_max.width() || output.height() != local_max.height())
         output = BMax(local_max.width(), local_max.height());
-    if (!vs::dense(input_template) || !vs::dense(input_keyframe) || !vs::dense(local_max)) return false;
+    if (!vs::all_dense(input_template, input_keyframe, local_max, output)) return false;
     float p[4];
     vs_ul_params_sparse(&transform.c(), input_template.width(), input_template.height(), p);
-    return vs_sparse_warpdiff(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(),
+    return vs::done(vs_sparse_warpdiff(input_template.data(), input_keyframe.data(), input_keyframe.width(), input_keyframe.height(),
                               input_keyframe.width(), local_max.data(), local_max.width(), local_max.height(), p[0], p[1], p[2], p[3],
-                              output.data(), VS_MEM_HOST, nullptr) == 0;
+                              output.data(), VS_MEM_HOST, nullptr) == 0, output);
 }
 // imgproc.cpp:116-133
 template <class BIn, class BOut>
 inline bool ImageWarp(BIn& input, const SimilarityTransform& transform, BOut& output) {
     static_assert(std::is_same<vs::elem_t<BIn>, uint8_t>::value && std::is_same<vs::elem_t<BOut>, float>::value, "ImageWarp: u8 -> f32");
-    if (!vs::dense(input) || !vs::dense(output)) return false;
+    if (!vs::all_dense(input, output)) return false;
     float p[4];
     vs_ul_params_warp(&transform.c(), input.width(), input.height(), p);
-    return vs_image_warp(input.data(), input.width(), input.height(), input.width(), p[0], p[1], p[2], p[3], output.data(), output.width(),
-                         output.height(), VS_MEM_HOST, nullptr) == 0;
+    return vs::done(vs_image_warp(input.data(), input.width(), input.height(), input.width(), p[0], p[1], p[2], p[3], output.data(),
+                                  output.width(), output.height(), VS_MEM_HOST, nullptr) == 0, output);
 }
 
 // imgproc.cpp:446-484 warpBySimilarityTransform on an interleaved BGR image (h x w x 3, u8).  OpenCV's warpAffine
