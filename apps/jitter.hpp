@@ -15,6 +15,14 @@
 
 namespace vsjit {
 
+// printed once by every tool that reports the score (the score must say what it is where it is read)
+inline const char* score_note() {
+    return "note: jitter score = median flow magnitude of the similarity THIS library measures between successive frames (not OpenCV's "
+           "Farneback flow, eval_jitter.cpp:43-70): it sees global camera motion only, and a grid search over aligner parameters scores "
+           "an aligner with an aligner -- failures that fool the measuring aligner as well go unseen; compare scores of this tool only";
+}
+
+
 // median with the mean of the two middle elements for even sizes (eval_jitter.cpp:8-19)
 inline double median(std::vector<double>& v) {
     if (v.empty()) return 0.0;

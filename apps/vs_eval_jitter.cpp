@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     try {
         vs_aligner* a = vs_aligner_create(nullptr, device);
         if (!a) { std::cerr << "vs_aligner_create: " << vs_last_error() << "\n"; return 1; }
+        std::cerr << vsjit::score_note() << std::endl;
         for (const auto& path : paths) {
             vsio::Clip clip;
             std::string err;

@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
                         c.label = s.str();
                         combos.push_back(c);
                     }
+        std::cerr << vsjit::score_note() << std::endl;
         std::cout << "Running " << combos.size() << " parameter combinations using " << args.jobs << " threads" << std::endl;
         const vsh::GridResult r = vsh::run_grid(clip, input_jitter, combos, args.jobs, args.device);
         if (r.best < 0) { std::cerr << "No combination produced output." << std::endl; return 1; }

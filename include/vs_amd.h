@@ -170,6 +170,10 @@ int vs_optimal_dft_size(int n);
 /* int image_warp(in, A, B, TX, TY, out)                   imgproc.cpp:131, generators.cpp:126-164 */
 int vs_image_warp(const uint8_t* in, int w, int h, int stride,
                   float A, float B, float TX, float TY, float* out, int ow, int oh, int mem, void* stream);
+/* Streams passed to the bgr_image_warp entry points: the library keeps one event per in-flight call on the caller's stream (its
+ * parameter ring) until a later call on the same thread retires it.  Before DESTROYING such a stream call vs_stream_retire(stream):
+ * it waits for the library's work on that stream and drops every reference to it.  (Handles do this for their own streams.) */
+int vs_stream_retire(void* stream);
 /* bgr_image_warp: the full-frame colour warp (replaces warpBySimilarityTransform's cv::warpAffine,
  * imgproc.cpp:446-484 / stabilizer.cpp:97-99; the generator itself is absent from the reference,
  * schedules/bgr_image_warp.schedule.h is its orphan -- SURVEY D2).  `t` is the output->input

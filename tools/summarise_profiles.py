@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/r2prof/, scratch) into the committed summaries
-under profiles/: kernel-stats CSVs of the bench runs, and r02_warp_pmc.json / r02_traffic.json, which bench.py reads for the
-counter-derived fields of its roofline objects.  usage: python tools/summarise_profiles.py [gpurun_out/r2prof]"""
+under profiles/: kernel-stats CSVs of the bench runs, and rNN_warp_pmc.json / rNN_traffic.json, which bench.py reads for the
+counter-derived fields of its roofline objects.  usage: python tools/summarise_profiles.py [gpurun_out/r3prof] [r03]"""
 import collections
 import csv
 import glob
@@ -13,6 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2prof")
 DST = os.path.join(ROOT, "profiles")
+RN = sys.argv[2] if len(sys.argv) > 2 else "r02"        # round prefix of the files written
+SECOND = "fast" if RN == "r02" else "contracted"        # round 3: VS_WARP_LANCZOS2_FAST is the contracted form of the sampler
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
@@ -33,9 +35,9 @@ for wl in ("c2", "c3"):
     f = sorted(glob.glob(os.path.join(SRC, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "vs_k_" in r[0] or "vsp" in r[0]]     # the library's kernels (torch's generator kernels dropped)
-    with open(os.path.join(DST, "r02_bench_%s_kernel_stats.csv" % wl), "w", newline="") as o:
+    with open(os.path.join(DST, RN + "_bench_%s_kernel_stats.csv" % wl), "w", newline="") as o:
         csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
-    shutil.copy(os.path.join(SRC, "stats_%s.json" % wl), os.path.join(DST, "r02_bench_%s_line.json" % wl))
+    shutil.copy(os.path.join(SRC, "stats_%s.json" % wl), os.path.join(DST, RN + "_bench_%s_line.json" % wl))
 
 PX4, PX32 = 3840 * 2160 * 4, 3840 * 2160 * 32
 out = {"_comment": "vs_k_bgr_warp_c3<u8> on MI355X, rocprofv3 --pmc passes of tools/warp_bench.py (tools/collect_profiles.sh): SQ / GRBM "
@@ -47,7 +49,7 @@ out = {"_comment": "vs_k_bgr_warp_c3<u8> on MI355X, rocprofv3 --pmc passes of to
                    "cycles_per_valu_instr = SIMD cycles of the dispatch / VALU instructions, to hold against the issue costs of "
                    "profiles/r02_ubench_mix.txt.  "
                    "lds_frac = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs)."}
-for name, m in (("exact", "lanczos2"), ("fast", "fast")):
+for name, m in (("exact", "lanczos2"), (SECOND, "fast")):
     a, b = counters("pmcA_" + m), counters("pmcB_" + m)
     fz, wz = counters("pmcF_" + m)["FETCH_SIZE"], counters("pmcW_" + m)["WRITE_SIZE"]
     cyc = b["GRBM_GUI_ACTIVE"] / N_XCD
@@ -65,19 +67,20 @@ for name, m in (("exact", "lanczos2"), ("fast", "fast")):
         "traffic_bytes_per_frame": int((2 * fz + wz) * 1024 / 32),
         "algorithmic_bytes_per_frame": 3840 * 2160 * 3 * 2,
     }
-json.dump(out, open(os.path.join(DST, "r02_warp_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(DST, RN + "_warp_pmc.json"), "w"), indent=1)
 
 fz, wz = counters("pmcF_c2")["FETCH_SIZE"], counters("pmcW_c2")["WRITE_SIZE"]
-tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2,clamp> per launch of 240 x 1080p frames (round 2 kernel), separate "
-                  "--pmc FETCH_SIZE / WRITE_SIZE passes, counter unit KiB, FETCH_SIZE doubled (see r02_warp_pmc.json).",
+tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2,clamp> per launch of 240 x 1080p frames (" + RN + " kernel), separate "
+                  "--pmc FETCH_SIZE / WRITE_SIZE passes, counter unit KiB, FETCH_SIZE doubled (see " + RN + "_warp_pmc.json).",
       "c2_1080p_240_frames": {"fetch_size_kib_raw": int(fz), "write_size_kib": int(wz), "traffic_bytes": int((2 * fz + wz) * 1024),
                               "algorithmic_bytes": 1920 * 1080 * 3 * 2 * 240},
       "c3_4k_32_frames": {"fetch_size_kib_raw": out["exact"]["fetch_size_kib_raw_32_frames"], "write_size_kib": out["exact"]["write_size_kib_32_frames"],
                           "traffic_bytes": out["exact"]["traffic_bytes_per_frame"] * 32, "algorithmic_bytes": 3840 * 2160 * 3 * 2 * 32}}
-json.dump(tr, open(os.path.join(DST, "r02_traffic.json"), "w"), indent=1)
-for f, t in (("host_fed_1080p.json", "r02_host_fed_1080p.json"), ("host_fed_4k.json", "r02_host_fed_4k.json"),
-             ("latency_1080p.json", "r02_latency_1080p.json"), ("latency_4k.json", "r02_latency_4k.json")):
-    shutil.copy(os.path.join(SRC, f), os.path.join(DST, t))
+json.dump(tr, open(os.path.join(DST, RN + "_traffic.json"), "w"), indent=1)
+for f in ("host_fed_1080p.json", "host_fed_4k.json", "latency_1080p.json", "latency_4k.json", "latency_cpp.txt", "step_trace_shared.md",
+          "step_trace_exclusive.md", "pmc_align_summary.txt", "stats_c2x.json"):
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, RN + "_" + f))
 for f, t in (("ubench_valu.txt", "r02_ubench_valu.txt"), ("ubench_mix.txt", "r02_ubench_mix.txt")):
     p = os.path.join(ROOT, "gpurun_out", "r2", f)
     if os.path.exists(p):

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vs_last_error": (C.c_char_p, []),
     "vs_version": (C.c_char_p, []),
     "vs_device_count": (_i32, []),
+    "vs_stream_retire": (_i32, [_vp]),
     "vs_format_bits": (_i32, [_i32]),
     "vs_format_max_value": (_i32, [_i32]),
     "vs_aligner_stream": (_vp, [_vp]),

@@ -80,8 +80,9 @@ struct ParamRing {
     float4* host = nullptr;
     float4* dev = nullptr;
     size_t head = 0;
-    struct Busy { size_t begin, end; hipEvent_t ev; };
+    struct Busy { size_t begin, end; hipEvent_t ev; hipStream_t stream; };
     std::deque<Busy> busy;
+    std::mutex mu;                               // the owning thread (upload / fence) against vsi::retire_stream from any thread
     std::vector<hipEvent_t> pool;
     int take_event(hipEvent_t* ev) {
         if (!pool.empty()) { *ev = pool.back(); pool.pop_back(); return VS_OK; }
@@ -95,6 +96,7 @@ struct ParamRing {
         return VS_OK;
     }
     int upload(const float* src, size_t n, hipStream_t s, float4** out) {
+        std::lock_guard<std::mutex> g(mu);
         if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
         if (!host) VS_HIP(hipHostMalloc((void**)&host, kSlots * sizeof(float4)));
         if (!dev) VS_HIP(hipMalloc((void**)&dev, kSlots * sizeof(float4)));
@@ -108,7 +110,7 @@ struct ParamRing {
         }
         while (busy.size() > 64) VS_TRY_RING(retire(busy.begin()));   // keep the list short: retire the oldest
         memcpy(host + b, src, n * sizeof(float4));
-        Busy bz{b, e, nullptr};
+        Busy bz{b, e, nullptr, s};
         VS_TRY_RING(take_event(&bz.ev));
         hipError_t err = hipMemcpyAsync(dev + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s);
         if (err == hipSuccess) err = hipEventRecord(bz.ev, s);
@@ -120,10 +122,20 @@ struct ParamRing {
     }
     // called after the consuming kernel has been enqueued on `s`: the span stays busy until that kernel is done
     int fence(float4* p, hipStream_t s) {
+        std::lock_guard<std::mutex> g(mu);
         const size_t b = (size_t)(p - dev);
         for (auto& z : busy)
-            if (z.begin == b) { VS_HIP(hipEventRecord(z.ev, s)); return VS_OK; }
+            if (z.begin == b) { VS_HIP(hipEventRecord(z.ev, s)); z.stream = s; return VS_OK; }
         return VS_OK;
+    }
+    // every span whose event was recorded on `s` is waited for and retired NOW, while the stream still exists: this runtime's
+    // hipEventSynchronize looks at the stream an event was last recorded on, so an event must never outlive that stream in here
+    void forget_stream(hipStream_t s) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto it = busy.begin(); it != busy.end();) {
+            if (it->stream == s) { (void)hipEventSynchronize(it->ev); pool.push_back(it->ev); it = busy.erase(it); }
+            else ++it;
+        }
     }
 };
 // A thread takes a ring per device on first use and hands it back to a process-wide pool when it exits; the next thread that
@@ -134,6 +146,7 @@ struct ParamRing {
 struct RingPool {
     std::mutex mu;
     std::vector<ParamRing*> free_[16];
+    std::vector<ParamRing*> all;                 // every ring ever made (rings are never destroyed)
 };
 RingPool& ring_pool() { static RingPool* p = new RingPool(); return *p; }      // never destroyed: outlives every thread's holder
 struct RingHolder {
@@ -152,11 +165,23 @@ ParamRing* param_ring() {
         RingPool& p = ring_pool();
         std::lock_guard<std::mutex> g(p.mu);
         if (!p.free_[device].empty()) { holder.r[device] = p.free_[device].back(); p.free_[device].pop_back(); }
-        else holder.r[device] = new ParamRing();
+        else { holder.r[device] = new ParamRing(); p.all.push_back(holder.r[device]); }
     }
     return holder.r[device];
 }
 }  // namespace
+
+// A stream is about to be destroyed (a handle's own stream: ~vs_aligner; a caller's stream: vs_stream_retire): nothing in the
+// library may refer to it afterwards.
+void vsi::retire_stream(hipStream_t s) {
+    std::vector<ParamRing*> rings;
+    {
+        RingPool& p = ring_pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        rings = p.all;
+    }
+    for (ParamRing* r : rings) r->forget_stream(s);
+}
 
 static inline size_t img_span(int w, int h, int stride, int channels) {
     return (size_t)(h - 1) * stride + (size_t)w * channels;
@@ -167,6 +192,11 @@ static inline int finish_host(int mem, hipStream_t s) {
 }
 
 extern "C" {
+
+int vs_stream_retire(void* stream) {
+    vsi::retire_stream((hipStream_t)stream);
+    return VS_OK;
+}
 
 int vs_device_count(void) {
     int n = 0;

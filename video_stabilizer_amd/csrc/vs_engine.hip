@@ -401,7 +401,7 @@ struct vs_aligner {
         release();
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) { vsi::retire_stream(stream); (void)hipStreamDestroy(stream); }   // (the stabilizer warps on this stream)
     }
     void release();
     int configure(int w, int h, int format, const vs_aligner_params& p);

@@ -58,6 +58,9 @@ struct Staged {
 };
 
 bool device_ready();   // true when a HIP device is usable (sets last error otherwise)
+// `s` is about to be destroyed: wait for and drop everything the library still tracks on it (bgr_image_warp's parameter ring
+// keeps an event per in-flight call; an event must not outlive the stream it was recorded on)
+void retire_stream(hipStream_t s);
 
 }  // namespace vsi
 #endif

@@ -51,8 +51,13 @@ namespace {
 #define VS_WARP_TILE_H 16                // output rows per workgroup (4 waves: VS_WARP_TILE_H / 4 rows per wave)
 #endif
 
+#ifndef VS_WARP_ROW_BLOCK
+#define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
+#endif
 constexpr int WT_W = 64, WT_H = VS_WARP_TILE_H;      // output tile
-constexpr int RPW = WT_H / 4;            // output rows per wave (even)
+constexpr int RPW = WT_H / 4;            // output rows per wave
+constexpr int RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW;
+static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
 constexpr int WS_W = 80;                 // staged source pixels per row (multiple of 4)
 constexpr int WS_H = WT_H + 8;           // staged source rows (multiple of 4)
 constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;   // fill items per thread: (row quads x column groups) / 16 per wave / 4 waves
@@ -436,20 +441,26 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         return;
     }
 
-    // ---- the four rows of this wave, one straight-line block ----
+    // ---- the rows of this wave, RB at a time, each group one straight-line block ----
     const int xq = min(x, roi.w - 1);                        // lanes right of the window sample its last column (masked below)
     const float fx = (float)(xq + roi.x);
     const float A1x = A1 * fx, Bx = B * fx;
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
     const float c0 = -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
-    uint32_t o[RPW][3];
-    float num[RPW][4];                                         // Lanczos modes: {numB, numG, numR, den} kept for the operator/ fallback
+    const bool lane_in = x < roi.w;
+    const int yw_first = yw;
+#pragma unroll 1
+    for (int kb = 0; kb < RPW; kb += RB) {
+    const int yw = yw_first + kb;                            // first row of this block
+    if (yw >= roi.h) break;                                  // wave-uniform
+    uint32_t o[RB][3];
+    float num[RB][4];                                          // Lanczos modes: {numB, numG, numR, den} kept for the operator/ fallback
     bool all_ok = true;
     // rows are processed two at a time, the two rows' instructions alternating in source order: a packed-fp32 result
     // cannot feed the very next VALU instruction without a wait state on gfx950, and the other row's operation fills it
 #pragma unroll
-    for (int kp = 0; kp < RPW; kp += 2) {
+    for (int kp = 0; kp < RB; kp += 2) {
         f2 fr[2];
         lds_f4 t[2];
 #pragma unroll
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     if (MODE != 1 && __any(!all_ok)) {
         // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
-        for (int k = 0; k < RPW; k++) {
+        for (int k = 0; k < RB; k++) {
             float den = num[k][3];
             asm volatile("" : "+v"(den));                    // keeps the three divisions inside this branch (no speculation)
 #pragma unroll
@@ -502,17 +513,16 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     }
 
     // ---- stores ----
-    // all four rows are final here: without this pin the compiler sinks each row's arithmetic into the conditional store
+    // all rows of the block are final here: without this pin the compiler sinks each row's arithmetic into the conditional store
     // blocks below while its LDS reads stay hoisted at the top, and the tile values spill to scratch in between
 #pragma unroll
-    for (int k = 0; k < RPW; k++) asm volatile("" :: "v"(o[k][0]), "v"(o[k][1]), "v"(o[k][2]));
-    const bool lane_in = x < roi.w;
+    for (int k = 0; k < RB; k++) asm volatile("" :: "v"(o[k][0]), "v"(o[k][1]), "v"(o[k][2]));
     if (sizeof(T) == 1) {
         const bool quad_in = (x | 3) < roi.w;
         const uint32_t sel = quad_sel(m);
         const uint32_t loff = (uint32_t)(x & ~3) * 3u + 4u * (uint32_t)m;
 #pragma unroll
-        for (int k = 0; k < RPW; k++) {
+        for (int k = 0; k < RB; k++) {
             const int y = yw + k;
             const uint32_t p = o[k][0] | (o[k][1] << 8) | (o[k][2] << 16);
             const uint32_t d = quad_pack_bgr(p, sel);        // every lane of the wave takes part in the shuffle
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     } else {
         const bool pair_in = (x | 1) < roi.w;
 #pragma unroll
-        for (int k = 0; k < RPW; k++) {
+        for (int k = 0; k < RB; k++) {
             const int y = yw + k;
             uint32_t d0, d1;
             pair_pack_bgr16(o[k], x & 1, d0, d1);
@@ -548,6 +558,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
             }
         }
     }
+    }   // row blocks
 }
 
 }  // namespace
