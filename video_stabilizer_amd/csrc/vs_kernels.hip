@@ -3,6 +3,8 @@
 // All of these are HBM/latency-bound byte and fp32 work: wave64, coalesced 4..16-byte accesses,
 // LDS staging for the stencils, no MFMA (DESIGN.md "Why no MFMA").
 #include "vs_kernels.hpp"
+#include <cstdlib>
+#include <algorithm>
 
 #include <utility>
 #include "vs_device.hpp"
@@ -230,20 +232,23 @@ __device__ __forceinline__ uint32_t gray_of(const T* p, int shift_to_8) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src, int w, int h, int src_stride,
-                                                       int shift_to_8, uint8_t* __restrict__ g0, uint8_t* __restrict__ g1,
+__global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src_all, int w, int h, int src_stride,
+                                                       int shift_to_8, uint8_t* __restrict__ g0_all, uint8_t* __restrict__ g1_all,
                                                        int ow, int oh, size_t src_frame_stride, size_t pyr_frame_stride,
                                                        int tiles_x, int tiles_per_frame, int total_tiles, int chunk) {
     __shared__ __attribute__((aligned(8))) uint8_t tile[PD_IH][PD_IWP];
     __shared__ __attribute__((aligned(8))) uint32_t hsum[PD_IH][PD_TW / 2];
+    // One workgroup per tile -- or, when the launch is given fewer workgroups than tiles (a multiple of 8: vsk::ingest_pyr's
+    // `max_workgroups`, for callers that share the GPU), each workgroup walks every gridDim.x-th tile id of its XCD's run.
+    for (int bid = (int)blockIdx.x; bid < 8 * chunk; bid += (int)gridDim.x) {
     // XCD-aware order (see vs_warp.hip): each XCD walks a contiguous raster run of tiles
-    const int logical = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (logical >= total_tiles) return;
+    const int logical = (bid & 7) * chunk + (bid >> 3);
+    if (logical < total_tiles) {                                  // (uniform)
     const int frame = logical / tiles_per_frame, tl = logical - frame * tiles_per_frame;
     const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
-    src += (size_t)frame * src_frame_stride;
-    g0 += (size_t)frame * pyr_frame_stride;
-    g1 += (size_t)frame * pyr_frame_stride;
+    const T* __restrict__ src = src_all + (size_t)frame * src_frame_stride;
+    uint8_t* __restrict__ g0 = g0_all + (size_t)frame * pyr_frame_stride;
+    uint8_t* __restrict__ g1 = g1_all + (size_t)frame * pyr_frame_stride;
     const int x0 = txi * PD_TW, y0 = tyi * PD_TH;          // level-1 tile origin
     const int ix0 = 2 * x0 - 4, iy0 = 2 * y0 - 2;          // level-0 origin of the staged tile
     // gray = (B*3735 + G*19235 + R*9798 + 16384) >> 15 on the dot-product units.  u8: the pixel's bytes {B,G,R,x} against the
@@ -386,6 +391,9 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
     }
     __syncthreads();
     pyr_passes(tile, hsum, x0, y0, g1, ow, oh, ow);
+    }
+    if (bid + (int)gridDim.x < 8 * chunk) __syncthreads();       // the tile buffers are refilled by the next round
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -979,11 +987,14 @@ hipError_t ingest_pyr(const void* src, int w, int h, int src_stride, int bits, i
     const long long total = (long long)tiles_x * tiles_y * n_frames;
     if (total > 0x3fffffffLL) return hipErrorNotSupported;
     const int chunk = (int)((total + 7) / 8);
+    // experiment knob (read once): cap the number of workgroups of this launch (a multiple of 8); 0 = one per tile
+    static const int wg_cap = []() { const char* e = getenv("VS_INGEST_WGS"); return e ? (atoi(e) & ~7) : 0; }();
+    const int grid = wg_cap > 0 ? std::min(wg_cap, chunk * 8) : chunk * 8;
     if (bits == 8)
-        hipLaunchKernelGGL(vs_k_ingest_pyr<uint8_t>, dim3(chunk * 8), dim3(256), 0, s, (const uint8_t*)src, w, h, src_stride,
+        hipLaunchKernelGGL(vs_k_ingest_pyr<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, w, h, src_stride,
                            shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
     else
-        hipLaunchKernelGGL(vs_k_ingest_pyr<uint16_t>, dim3(chunk * 8), dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
+        hipLaunchKernelGGL(vs_k_ingest_pyr<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
                            shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
     return hipGetLastError();
 }
