@@ -562,7 +562,7 @@ def main():
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
-                       "solver": "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp or wl["stabilizer"] or W > 1920)
+                       "solver": "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp or wl["stabilizer"])
                        else "shared (VS_BATCH_SHARED: 256-thread small-footprint build under the previous pass's warp, bit-identical)",
                        "phase_correlate": bool(args.phase_correlate),
                        "warp": None if (args.no_warp and not wl["stabilizer"]) else
@@ -633,8 +633,7 @@ def main():
                          "stages": stage_table(tm3, steps3), "gn_iterations_per_frame": round(tm3["gn_iterations"] / max(1, tm3["frames"]), 2),
                          "roofline": roofline_of(a3, n3),
                          "contracted_warp": {"value": round(good3f * steps3 / dt3f, 2), "ms_per_step": round(1e3 * dt3f / steps3, 4)},
-                         "note": "4K level 0 has 20736 tiles per point set: above the small-footprint solver's 16384, so the solver kernel "
-                                 "stays one 512-thread workgroup (+ one helper) per pair"}
+                         "note": "solver in VS_BATCH_SHARED mode; the 4K level 0 (20736 tiles per set) selects on the pair's global scratch"}
             a3.free()
         except Exception as e:
             out["c3"] = {"error": repr(e)}

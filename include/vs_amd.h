@@ -232,11 +232,11 @@ typedef struct vs_align_info {
 vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);
 void vs_aligner_destroy(vs_aligner* a);
 int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
-/* Which build of the per-pair solver kernel a full batch (> 128 frame pairs, levels of <= 16384 tiles) runs through.  The
+/* Which build of the per-pair solver kernel a batch (>= 32 frame pairs, levels of <= 26000 tiles) runs through.  The
  * results are bit-identical either way.
  *   VS_BATCH_EXCLUSIVE (default)  one 512-thread workgroup per pair, a whole CU each: fastest when nothing else is running.
- *   VS_BATCH_SHARED               the small-footprint build (256 threads, <= 128 VGPRs, ~33 KB LDS: the footprint of one
- *                                 bgr_image_warp workgroup).  For callers that keep the GPU busy on another stream while the
+ *   VS_BATCH_SHARED               the small-footprint build (256 threads, <= 128 VGPRs, <= 36 KB LDS: the footprint of one
+ *                                 bgr_image_warp workgroup; levels whose selection arrays do not fit select on global scratch).  For callers that keep the GPU busy on another stream while the
  *                                 alignment runs -- typically the warp of the previous clip (stabilizer.cpp:97-99 after
  *                                 :19): the pairs move into CUs as the other grid's workgroups retire instead of waiting
  *                                 for whole CUs to drain. */

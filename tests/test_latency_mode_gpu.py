@@ -121,7 +121,7 @@ def test_coresident_build_equals_the_plain_launch_bit_for_bit():
 
 
 def test_shared_mode_full_batch_equals_the_plain_launch():
-    # vs_aligner_set_batch_mode(VS_BATCH_SHARED), more than 128 pairs: the small-footprint build; 640x480 with the reference's default pyramid keeps the
+    # vs_aligner_set_batch_mode(VS_BATCH_SHARED), 32 pairs or more: the small-footprint build; 640x480 with the reference's default pyramid keeps the
     # clip small (5 levels of 1200 / 300 tiles per set)
     plain = _run(640, 480, 140, True, pmw=20, VS_GN_CORESIDENT=0)
     assert sum(r[0] for r in plain) >= 130
@@ -147,3 +147,14 @@ def test_depth_limit_exit_is_redone_on_the_host_with_the_same_result():
     assert _run(1920, 1080, 5, True, VS_GN_SELECT_DEPTH=3, VS_GN_CORESIDENT=1) == plain
     big = _run(640, 480, 140, True, pmw=20, VS_GN_CORESIDENT=0)
     assert _run(640, 480, 140, True, pmw=20, VS_GN_SELECT_DEPTH=2) == big
+
+
+def test_coresident_build_at_4k_selects_the_finest_level_on_global_scratch():
+    # a 4K level 0 has 20736 tiles per point set: 124 KB of selection arrays cannot live in the small build's 32 KB of LDS, so that
+    # level's introselect runs on the pair's global scratch (128 elements per thread, the tail in LDS) -- same permutation, same bits
+    plain = _run(3840, 2160, 4, True, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    assert sum(r[0] for r in plain) == 3
+    assert _run(3840, 2160, 4, True, VS_GN_CORESIDENT=1) == plain
+    assert _run(3840, 2160, 4, False, VS_GN_CORESIDENT=1) == _run(3840, 2160, 4, False, VS_GN_PIPELINE=0, VS_GN_HELPERS=1, VS_GN_CORESIDENT=0)
+    # the depth-limit exit of the global-scratch selection goes through the same host redo
+    assert _run(3840, 2160, 3, True, VS_GN_CORESIDENT=1, VS_GN_SELECT_DEPTH=3) == plain[:3]

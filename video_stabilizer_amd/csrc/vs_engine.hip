@@ -265,7 +265,8 @@ constexpr int kGnThreads = VS_NT_SMALL, kGnVirt = VS_NT_SMALL;
 // 512 of nt512 (virtual threads: bit-identical sums), at most 128 VGPRs (4 waves per SIMD) and ~33 KB of LDS (selection arrays
 // of one point set; no staged image) -- the footprint of ONE bgr_image_warp workgroup, so a pair's workgroup moves into a CU as
 // soon as one warp workgroup leaves it and the alignment of clip k+1 runs under the warp launch of clip k instead of waiting
-// for whole CUs to drain.  Levels of up to 64 * 256 tiles (1080p: 5184; a 4K level 0 has 20736 and stays with nt512).
+// for whole CUs to drain.  Levels whose selection arrays (6 B per tile) exceed 32 KB -- a 4K level 0: 20736 tiles -- select on a
+// per-pair global scratch (introselect_block_g), up to 128 * 256 tiles.
 #if VS_NT_SMALL == 512
 namespace nt256v {
 constexpr int kGnThreads = 256, kGnVirt = 512;
@@ -278,7 +279,9 @@ constexpr int kGnThreads = 256, kGnVirt = 512;
 }  // namespace nt256v
 #define VS_HAVE_NT256V 1
 #endif
-constexpr int kCoResidentMaxTiles = 64 * 256;
+constexpr int kCoResidentMaxTiles = 128 * 256;          // introselect_block_g: 128 elements per thread (and <= kSelectCap)
+constexpr int kSharedMinPairs = 32;                    // VS_BATCH_SHARED: launches of at least this many pairs take the small-footprint build
+constexpr size_t kCoResidentDynMax = 32 * 1024;        // dynamic LDS of the small-footprint build; larger levels select on global scratch
 #ifndef VS_SMALL_WG_TILES
 #define VS_SMALL_WG_TILES 26000
 #endif
@@ -342,6 +345,7 @@ struct vs_aligner {
     int32_t* idx = nullptr;
     uint8_t* recs = nullptr;      // per pair: float4 j[2*nt_max] | u32 xy[2*nt_max] | f32 tv[2*nt_max]
     uint8_t* coop = nullptr;      // helper-workgroup control blocks + exchange buffers (kCoopMaxPairs pairs), see CoopCtrl
+    uint8_t* selbuf = nullptr; size_t selbuf_bytes = 0;   // small-footprint solver: per pair u32 keys[nt_max] | u16 ranks[nt_max] (levels that do not fit its LDS)
     int coop_epoch = 0;
     void* stage = nullptr; size_t stage_bytes = 0;   // host-frame upload area (single chunk)
     // host-resident video: two upload areas filled alternately by an uploader thread on its own stream, so the
@@ -445,8 +449,9 @@ int vs_aligner::ensure_phase() {
 
 void vs_aligner::release() {
     release_phase();
-    void* d[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop, stage, ingest[0], ingest[1]};
+    void* d[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop, stage, ingest[0], ingest[1], selbuf};
     for (void* p : d) if (p) (void)hipFree(p);
+    selbuf = nullptr; selbuf_bytes = 0;
     ingest[0] = ingest[1] = nullptr; ingest_bytes = 0;
     void* hp[] = {h_wd, h_idx, h_states, h_descs};
     for (void* p : hp) if (p) (void)hipHostFree(p);
@@ -776,13 +781,24 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
 #ifdef VS_HAVE_NT256V
             static const int cores_env = []() { const char* e = getenv("VS_GN_CORESIDENT"); return e ? atoi(e) : -1; }();
             cores = small_wg && nt_max <= kCoResidentMaxTiles &&
-                    (cores_env >= 0 ? cores_env != 0 : (batch_mode == VS_BATCH_SHARED && n_pairs > kCoopMaxPairs));
+                    (cores_env >= 0 ? cores_env != 0 : (batch_mode == VS_BATCH_SHARED && n_pairs >= kSharedMinPairs));
+            const size_t selbuf_pair = (((size_t)nt_max * 6 + 255) & ~(size_t)255);
             if (cores) {
                 group = 1;
-                dyn = 0;
+                dyn = 16;
+                bool need_global = false;
                 for (int l = 0; l < levels; l++) {
                     const size_t nt = (size_t)L[l].nt;
-                    dyn = std::max(dyn, ((nt <= 32 * (nt256v::kGnThreads / 2) ? nt * 12 : nt * 6) + 15) & ~(size_t)15);
+                    const size_t need = ((nt <= 32 * (nt256v::kGnThreads / 2) && nt * 12 <= kCoResidentDynMax ? nt * 12 : nt * 6) + 15) & ~(size_t)15;
+                    if (need <= kCoResidentDynMax) dyn = std::max(dyn, need); else need_global = true;
+                }
+                // (the kernel takes a non-null scratch pointer as "LDS block sized per level": always passed in this mode)
+                const size_t want = need_global ? selbuf_pair * (size_t)std::max(cap, n_pairs) : 256;
+                if (selbuf_bytes < want) {
+                    if (selbuf) (void)hipFree(selbuf);
+                    selbuf = nullptr; selbuf_bytes = 0;
+                    VS_HIP(hipMalloc((void**)&selbuf, want));
+                    selbuf_bytes = want;
                 }
             }
             const auto kernel = cores ? nt256v::vs_k_align_pairs : (small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs);
@@ -807,7 +823,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             if (direct) for (int q = 0; q < n_pairs; q++) dpack.d[q] = hd[q];
             hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(kthreads), dyn, s,
                                direct ? h_states : states, descs, pyr, pyr_frame, lm, lm_frame, jac, jac_frame, recs, recs_pair, nt_max, (int)dyn,
-                               fl, gp, group, coop, epoch, wv, dpack, direct ? 1 : 0);
+                               fl, gp, group, coop, epoch, wv, dpack, direct ? 1 : 0, cores ? selbuf : nullptr, selbuf_pair);
             VS_HIP(hipGetLastError());
             t_end(1);
             if (!direct) VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
