@@ -177,3 +177,37 @@ def test_c5_one_gpus_share_at_full_size(gpu_vs):
     r1, has1 = alone.process_batch_device(allf[c * fpc].data_ptr(), fpc, w, h, gpu_vs.FMT_BGR10, out1.data_ptr())
     assert has1 == has[:fpc] and r1 == fpc - lag
     assert torch.equal(out1[lag:], out[c * fpc + lag:(c + 1) * fpc])
+
+
+@pytest.mark.parametrize("bits,mode", [(8, 0), (10, 2)])
+def test_overlapped_clip_groups_equal_clip_by_clip(gpu_vs, bits, mode):
+    """vs_stabilizer_process_clips on dense device-resident clips cuts the batch into clip groups and runs the warps of group g
+    on a stream of their own under the alignment of group g + 1 (small-footprint solver build).  7 clips x 12 frames -> groups of
+    3 / 3 / 1 clips: outputs and flags must equal every clip run through a fresh stabilizer on its own, bit for bit."""
+    torch = pytest.importorskip("torch")
+    from video_stabilizer_amd import synth
+    dev = torch.device("cuda", 0)
+    w, h, fpc, n_clips = 640, 360, 12, 7
+    factory = synth.TorchClipFactory(w, h, 4100, dev, channels=3, bits=bits)
+    dt = torch.uint8 if bits == 8 else torch.int16
+    allf = torch.empty((n_clips * fpc, h, w, 3), dtype=dt, device=dev)
+    for c in range(n_clips):
+        factory.make(fpc, 4100 + c, out=allf[c * fpc:(c + 1) * fpc])
+    torch.cuda.synchronize()
+    fmt = gpu_vs.FMT_BGR8 if bits == 8 else gpu_vs.FMT_BGR10
+    kw = dict(lag=3, smoother_memory=2, crop_pixels=8, warp_mode=mode)
+    out = torch.zeros((n_clips * fpc, h - 16, w - 16, 3), dtype=dt, device=dev)
+    r, has = gpu_vs.Stabilizer(device=0, **kw).process_clips_device(allf.data_ptr(), n_clips, fpc, w, h, fmt, out.data_ptr())
+    assert r == n_clips * (fpc - 3) and sum(has) == r
+    for c in range(n_clips):
+        one = torch.zeros((fpc, h - 16, w - 16, 3), dtype=dt, device=dev)
+        r1, has1 = gpu_vs.Stabilizer(device=0, **kw).process_batch_device(allf[c * fpc].data_ptr(), fpc, w, h, fmt, one.data_ptr())
+        assert has1 == has[c * fpc:(c + 1) * fpc], c
+        assert torch.equal(one, out[c * fpc:(c + 1) * fpc]), c
+    # a second call on the same handle (streams, events and scratch reused) gives the same bytes
+    st = gpu_vs.Stabilizer(device=0, **kw)
+    out2 = torch.zeros_like(out)
+    for _ in range(2):
+        out2.zero_()
+        st.process_clips_device(allf.data_ptr(), n_clips, fpc, w, h, fmt, out2.data_ptr())
+    assert torch.equal(out2, out)

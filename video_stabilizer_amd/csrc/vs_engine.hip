@@ -1207,6 +1207,10 @@ struct vs_stabilizer {
     hipEvent_t down_ev[2] = {nullptr, nullptr};
     hipStream_t down_stream = nullptr, up_stream = nullptr;
     void* pipe_in[2] = {nullptr, nullptr}; size_t pipe_in_bytes = 0;     // upload areas of a pipelined host batch
+    // device-resident clip batches: the warps of clip group g run on warp_stream under the alignment of group g + 1 (stab_run)
+    hipStream_t warp_stream = nullptr;
+    hipEvent_t warp_ev = nullptr;
+    bool overlap_warps = false;    // set by stab_run around the group calls
     std::vector<vs_transform> t_buf;
     std::vector<int32_t> st_buf;
     vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
@@ -1244,6 +1248,8 @@ void vs_stabilizer_destroy(vs_stabilizer* s) {
     for (void* q : s->batch_out) if (q) (void)hipFree(q);
     for (void* q : s->pipe_in) if (q) (void)hipFree(q);
     for (hipEvent_t e : s->down_ev) if (e) (void)hipEventDestroy(e);
+    if (s->warp_stream) { vsi::retire_stream(s->warp_stream); (void)hipStreamDestroy(s->warp_stream); }
+    if (s->warp_ev) (void)hipEventDestroy(s->warp_ev);
     if (s->down_stream) (void)hipStreamDestroy(s->down_stream);
     if (s->up_stream) (void)hipStreamDestroy(s->up_stream);
     vs_smoother_destroy(s->smoother);
@@ -1279,10 +1285,50 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         if (clip_len > 0) chunk = std::max(clip_len, chunk - chunk % clip_len);
     }
     int r;
+    // Device-resident clip batches (vs_stabilizer_process_clips, VS_MEM_DEVICE, dense frames): the clips are cut into groups and the
+    // warps of group g go to a stream of their own, so that they run under the alignment of group g + 1 -- which then takes the
+    // small-footprint solver build (VS_BATCH_SHARED: it shares CUs with the warp grid).  Every group goes through stab_run_impl
+    // exactly as a process_clips call of its own would (clips are independent: stabilizer.cpp keeps no state across a reset), so
+    // the grouping cannot change results.  VS_STAB_OVERLAP=0 turns it off.
+    static const bool overlap_env = []() { const char* e = getenv("VS_STAB_OVERLAP"); return e ? atoi(e) != 0 : true; }();
+    const int n_clips_all = clip_len > 0 ? n / clip_len : 0;
+    const bool dense_dev = s && mem == VS_MEM_DEVICE && w > 0 && stride == 3 * w && frame_stride == (size_t)h * stride;
+    int group_clips = 0;
+    if (overlap_env && dense_dev && clip_len >= 2 && n_clips_all >= 2 && n == n_clips_all * clip_len) {
+        // groups of at least kSharedMinPairs pairs (the small build's threshold), at most 8 groups
+        group_clips = std::max(1, (kSharedMinPairs + clip_len - 2) / (clip_len - 1));
+        group_clips = std::max(group_clips, (n_clips_all + 7) / 8);
+        if (group_clips >= n_clips_all) group_clips = 0;
+    }
     if (chunk > 0 && n > chunk)
         r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
                                     out_w, out_h);
-    else
+    else if (group_clips > 0) {
+        vs_aligner* a = s->aligner;
+        r = 0;
+        hipError_t he = hipSetDevice(a->device);
+        if (he == hipSuccess && !s->warp_stream) he = hipStreamCreateWithFlags(&s->warp_stream, hipStreamNonBlocking);
+        if (he == hipSuccess && !s->warp_ev) he = hipEventCreateWithFlags(&s->warp_ev, hipEventDisableTiming);
+        // whatever the handle's stream was told to wait for (vs_stabilizer_wait_stream) holds for the warps too
+        if (he == hipSuccess) he = hipEventRecord(s->warp_ev, a->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s->warp_stream, s->warp_ev, 0);
+        if (he != hipSuccess) r = set_error(VS_ERR_HIP, "stabilizer warp stream: %s", hipGetErrorString(he));
+        const int saved_mode = a->batch_mode;
+        a->batch_mode = VS_BATCH_SHARED;
+        s->overlap_warps = true;
+        const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
+        for (int c0 = 0; r >= 0 && c0 < n_clips_all; c0 += group_clips) {
+            const int nc = std::min(group_clips, n_clips_all - c0), f0 = c0 * clip_len;
+            const int rg = stab_run_impl(s, (const uint8_t*)frames + (size_t)f0 * frame_stride * esz, frame_stride, nc * clip_len, clip_len, w, h,
+                                         stride, format, mem, mem, -1, (uint8_t*)out + (size_t)f0 * out_frame_stride * esz, out_frame_stride,
+                                         has_output + f0, out_w, out_h);
+            r = rg < 0 ? rg : r + rg;
+        }
+        s->overlap_warps = false;
+        a->batch_mode = saved_mode;
+        const hipError_t we = hipStreamSynchronize(s->warp_stream);          // every warp has landed before the call returns
+        if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
+    } else
         r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, mem, -1, out, out_frame_stride, has_output,
                           out_w, out_h);
     if (s) for (auto& f : s->down) if (f.valid()) {          // every download has landed before the call returns
@@ -1495,9 +1541,11 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
             void* dst = to_host ? (void*)((uint8_t*)s->batch_out[slot] + j * obytes)
                                 : (void*)((uint8_t*)out + (size_t)jobs[j].i * out_frame_stride * esz);
             const size_t dst_fs = to_host ? (size_t)ow * oh * 3 : out_frame_stride;
+            // (device output of an overlapped clip batch: the warps go to warp_stream and run under the next group's alignment)
+            hipStream_t ws = (s->overlap_warps && !to_host) ? s->warp_stream : st;
             int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
                                                  s->params.warp_mode, s->params.warp_border, vs_format_max_value(format), crop, crop, ow, oh,
-                                                 dst, dst_fs, ow * 3, VS_MEM_DEVICE, st);
+                                                 dst, dst_fs, ow * 3, VS_MEM_DEVICE, ws);
             if (wr < 0) return wr;
             j = e;
         }
