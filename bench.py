@@ -562,7 +562,9 @@ def main():
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
                        else "on-device replica of libstdc++ nth_element (same survivors, same order)",
-                       "solver": "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp or wl["stabilizer"])
+                       "solver": "clip groups overlapped inside vs_stabilizer_process_clips: the warps of group g run under the alignment of group "
+                                 "g + 1 (small-footprint solver build)" if wl["stabilizer"] else
+                       "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp)
                        else "shared (VS_BATCH_SHARED: 256-thread small-footprint build under the previous pass's warp, bit-identical)",
                        "phase_correlate": bool(args.phase_correlate),
                        "warp": None if (args.no_warp and not wl["stabilizer"]) else
