@@ -22,7 +22,7 @@ The JSON line also carries
                 region (exact and contracted arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
                 the kernel is VALU-issue-bound, the HBM fraction is what that leaves
   c3            (default run, one GPU) the 4K half of the metric: BASELINE configs[2] through the same step, a few steps
-  c4_strong     (default run, N > 1) BASELINE configs[3]: 64 clips in total, 64 / N per rank, with per-rank seconds
+  c4_strong     (default run) BASELINE configs[3] as a strong-scaling leg: 64 clips in total, 64 / N per rank, per-rank seconds
   parity        the gate SURVEY 8(d) asks for with every benchmark: the GPU results for the first frames of the clip against
                 the CPU restatement that cpu_baseline runs anyway; a broken gate makes the run fail (exit code 3)
   align_only    the same clip through the alignment stages alone (configs[1] read literally), with per-stage times
@@ -419,8 +419,8 @@ def main():
     ap.add_argument("--exclusive-solver", action="store_true", help="keep the solver kernel in VS_BATCH_EXCLUSIVE mode inside the overlapped step")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-resident (PCIe-inclusive) alignment measurement")
     ap.add_argument("--no-c3", action="store_true", help="skip the 4K (configs[2]) leg of the default one-GPU run")
-    ap.add_argument("--c4-strong", action="store_true", help="run the 64-clip strong-scaling leg (configs[3]) even on one GPU")
-    ap.add_argument("--no-c4-strong", action="store_true", help="skip it on N > 1")
+    ap.add_argument("--c4-strong", action="store_true", help="run the 64-clip strong-scaling leg (configs[3]) on one GPU even if free memory looks short")
+    ap.add_argument("--no-c4-strong", action="store_true", help="skip the strong-scaling leg")
     ap.add_argument("--c4-clips", type=int, default=64, help="total clips of the strong-scaling leg (rehearsals use fewer)")
     ap.add_argument("--c4-frames", type=int, default=120)
     args = ap.parse_args()
@@ -641,7 +641,13 @@ def main():
             out["c3"] = {"error": repr(e)}
 
     # ---- BASELINE configs[3] as a strong-scaling leg: 64 clips in total, clip i -> rank i mod N --------------------------------
-    if default_run and not args.no_c4_strong and (world > 1 or args.c4_strong) and not args.no_warp:
+    # (on one GPU the leg is the N = 1 point of the strong curve: 64 clips = 48 GB of frames + 48 GB of output; it runs when the
+    # card has the room, and a failure there must not cost the line its headline)
+    want_c4 = default_run and not args.no_c4_strong and not args.no_warp
+    if want_c4 and world == 1 and not args.c4_strong:
+        need = 2.3 * args.c4_clips * args.c4_frames * 1920 * 1080 * 3
+        want_c4 = torch.cuda.mem_get_info(dev)[0] > need
+    if want_c4:
         if aw is not None:
             aw.free()
             aw = None
@@ -649,9 +655,16 @@ def main():
         wl4 = WORKLOADS["c4"]
         mine = vsdist.shard_clips(args.c4_clips, rank, world)
         steps4 = 2
-        a4 = AlignWarp(torch, capi, synth, dev, wl4, args.c4_frames, len(mine), [wl4["seed"] + i for i in mine], params_kw, args,
-                       wl4["seed"] + 1000 * rank)
-        a4.step(False)
+        try:
+            a4 = AlignWarp(torch, capi, synth, dev, wl4, args.c4_frames, len(mine), [wl4["seed"] + i for i in mine], params_kw, args,
+                           wl4["seed"] + 1000 * rank)
+            a4.step(False)
+        except Exception as e:
+            if world > 1:
+                raise                                    # every rank takes part in the collectives below: fail loudly
+            a4 = None
+            out["c4_strong"] = {"error": repr(e)}
+    if want_c4 and a4 is not None:
         dt4, good4 = timed_loop(lambda: a4.step(False), steps4)
         per_rank = vsdist.gather_seconds(dt4, device=red_dev)
         dt4m, frames4, good4t = vsdist.aggregate(dt4, args.c4_frames * len(mine) * steps4, int(good4) * steps4, device=red_dev)

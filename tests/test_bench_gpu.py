@@ -18,8 +18,8 @@ def _last_json(out):
 
 
 def test_bench_line_contract(gpu_vs):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--steps", "2", "--warmup", "1"],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--steps", "2", "--warmup", "1",
+                          "--c4-clips", "3", "--c4-frames", "6"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _last_json(out.stdout)
     assert KEYS <= set(j)
@@ -52,6 +52,9 @@ def test_bench_line_contract(gpu_vs):
     c3 = j["c3"]
     assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
     assert c3["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120 and "gn" in c3["stages"]
+    # ... and the N = 1 point of the strong-scaling leg (BASELINE configs[3]; 3 clips of 6 frames here)
+    s4 = j["c4_strong"]
+    assert s4["scaling"] == "strong" and s4["clips_per_rank"] == [3] and s4["value"] > 0 and len(s4["per_rank_seconds"]) == 1
     hf = j["host_fed"]
     assert hf["identical_to_device_resident"] is True and hf["value"] > 0 and 0 < hf["of_pinned_h2d"] <= 1.05
 
