@@ -6,6 +6,7 @@
 #include "vs_kernels.hpp"
 #include "vs_phase.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -395,22 +396,27 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(roi.w, roi.h, dst_stride, channels)));
     if (!vsi::device_ready()) return VS_ERR_HIP;
     const size_t esz = bits / 8, osz = f32out ? 4 : esz;
-    std::vector<float> P((size_t)n_frames * 4);
+    // kernel parameters of every frame, then (tuned 3-channel kernel) the extents its tile prologue uses: one upload of 2n float4
+    static const bool host_extents = []() { const char* e = getenv("VS_WARP_HOST_EXTENTS"); return e ? atoi(e) != 0 : true; }();
+    const bool tuned = channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535);
+    const bool with_extents = tuned && host_extents && (size_t)n_frames * 2 <= ParamRing::kSlots / 2;   // (the ring takes half its slots per call)
+    std::vector<float> P((size_t)n_frames * (with_extents ? 8 : 4));
     for (int i = 0; i < n_frames; i++) vs_ul_params_warp(&t[i], w, h, &P[(size_t)i * 4]);
+    if (with_extents) vsk::bgr_warp_c3_extents(P.data(), n_frames, roi, P.data() + (size_t)n_frames * 4);
     // Per-frame kernel parameters travel host -> device through a pinned ring (ParamRing below), so a
     // VS_MEM_DEVICE call stays asynchronous and never reads a host buffer that has gone out of scope.
     float4* pdev = nullptr;
     ParamRing* ring = param_ring();
     if (!ring) return set_error(VS_ERR_UNSUPPORTED, "no current HIP device with index < 16");
-    VS_TRY(ring->upload(P.data(), (size_t)n_frames, s, &pdev));
+    VS_TRY(ring->upload(P.data(), P.size() / 4, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
     VS_TRY(a.in(src, in_bytes, mem, s));
     VS_TRY(o.out_image(dst, (size_t)roi.w * channels * osz, (size_t)roi.h, (size_t)dst_stride * osz, (size_t)n_frames, dst_fs * osz, mem));
     hipError_t e = hipErrorNotSupported;
-    if (channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535))
-        e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, mode, border, max_value, o.dev, dst_stride, n_frames, src_fs,
-                             dst_fs, roi, s);
+    if (tuned)
+        e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, with_extents ? pdev + n_frames : nullptr, mode, border, max_value, o.dev,
+                             dst_stride, n_frames, src_fs, dst_fs, roi, s);
     if (e == hipErrorNotSupported)   // layouts without a tuned kernel (other channel counts, float output): one thread per pixel, same arithmetic
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);

@@ -31,6 +31,8 @@
 // The exact mode needs 248 separately rounded fp32 operations per pixel (112 Horner, 16 weight products, 96 tap
 // multiply / adds, 16 den adds, 8 selects) = 128 packed instructions = 632 cycles per 64 pixels before any overhead.
 #include "vs_kernels.hpp"
+#include <algorithm>
+#include <cmath>
 #include "vs_device.hpp"
 
 using namespace vsd;
@@ -312,7 +314,7 @@ template <typename T, int MODE, int BORDER>
 __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EXACT_MINWAVES) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
-    float maxv, vsk::Roi roi) {
+    float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
     __shared__ f4 tile[WS_H * WS_RS];                      // {B,G,R,1} per staged source pixel
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
@@ -335,16 +337,27 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     const int x0 = txi * WT_W, y0 = tyi * WT_H;
     const int x1 = min(x0 + WT_W, roi.w) - 1, y1 = min(y0 + WT_H, roi.h) - 1;
 
-    // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is
-    // monotone), so its extremes over the tile sit at corners chosen by the signs of A1 and B: 4 evaluations.
+    // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is monotone), so its
+    // extremes over the tile sit at corners chosen by the signs of A1 and B: 4 evaluations -- or, when the host has sent the
+    // frame's extents (vsk::bgr_warp_c3: the range of A1*i - B*j and B*i + A1*j over a full 64 x 16 tile, widened by a bound on
+    // the fp32 rounding of the position arithmetic), ONE evaluation at the tile origin plus four adds: every position a pixel
+    // of the tile computes lies inside [W00 + lo, W00 + hi], which is all the footprint has to guarantee (it may come out a
+    // pixel larger than the exact one; the window has 8 columns and 3 rows to spare for near-identity transforms).
     const float fx0 = (float)(x0 + roi.x), fx1 = (float)(x1 + roi.x), fy0 = (float)(y0 + roi.y), fy1 = (float)(y1 + roi.y);
+    float mnx, mxx, mny, mxy;
+    if (extents != nullptr) {                               // (uniform)
+        const float4 E = extents[frame];
+        const float Wx00 = A1 * fx0 - B * fy0 + TX, Wy00 = B * fx0 + A1 * fy0 + TY;
+        mnx = Wx00 + E.x; mxx = Wx00 + E.y; mny = Wy00 + E.z; mxy = Wy00 + E.w;
+    } else {
     const float xa = A1 >= 0.f ? fx0 : fx1, xb = A1 >= 0.f ? fx1 : fx0;     // x minimising / maximising A1*x
     const float ya = B >= 0.f ? fy0 : fy1, yb = B >= 0.f ? fy1 : fy0;       // y minimising / maximising B*y
-    const float mnx = A1 * xa - B * yb + TX, mxx = A1 * xb - B * ya + TX;
+    mnx = A1 * xa - B * yb + TX; mxx = A1 * xb - B * ya + TX;
     const float xc = B >= 0.f ? fx0 : fx1, xd = B >= 0.f ? fx1 : fx0;       // x minimising / maximising B*x
     const float yc = A1 >= 0.f ? fy0 : fy1, yd = A1 >= 0.f ? fy1 : fy0;
-    const float mny = B * xc + A1 * yc + TY, mxy = B * xd + A1 * yd + TY;
-    bool fits = fabsf(mnx) < 1.0e6f && fabsf(mxx) < 1.0e6f && fabsf(mny) < 1.0e6f && fabsf(mxy) < 1.0e6f;
+    mny = B * xc + A1 * yc + TY; mxy = B * xd + A1 * yd + TY;
+    }
+    bool fits = fmaxf(fmaxf(fabsf(mnx), fabsf(mxx)), fmaxf(fabsf(mny), fabsf(mxy))) < 1.0e6f;
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
     if (fits) {
         sx_lo = ((int)floorf(mnx) - 1) & ~3;               // first staged column: a multiple of 4 pixels (12 bytes)
@@ -364,6 +377,24 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         bool live[FILL_SLOTS], direct[FILL_SLOTS];
         const T* rowp[FILL_SLOTS];
         u32x3 q0[FILL_SLOTS], q1[FILL_SLOTS];
+        // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
+        // tests per item, one offset from a uniform base
+        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform
+        if (interior) {
+            const T* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
+#pragma unroll
+            for (int s = 0; s < FILL_SLOTS; s++) {
+                it[s] = fill_item(lane, wv + 4 * s);
+                live[s] = it[s].row < rows && it[s].g < groups;
+                direct[s] = live[s];
+                rowp[s] = base;
+                const uint32_t off = (uint32_t)it[s].row * (uint32_t)src_stride + 12u * (uint32_t)it[s].g;      // elements
+                if (live[s]) {
+                    q0[s] = *(const u32x3*)(base + off);
+                    if (sizeof(T) == 2) q1[s] = *(const u32x3*)(base + off + 6);
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
             it[s] = fill_item(lane, wv + 4 * s);
@@ -376,6 +407,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                 q0[s] = *(const u32x3*)(rowp[s] + sx * 3);
                 if (sizeof(T) == 2) q1[s] = *(const u32x3*)(rowp[s] + sx * 3 + 6);
             }
+        }
         }
         uint32_t one = 1u;
         asm volatile("" : "+v"(one));                        // opaque: keeps the conversion below from folding to a constant
@@ -566,8 +598,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 namespace vsk {
 
 template <typename T>
-static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, int mode, int border, T* dst,
-                            int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
+static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, const float4* extents_dev, int mode,
+                            int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + WT_H - 1) / WT_H;
     const long long tpf = (long long)tiles_x * tiles_y;
     if (tpf > 0x3fffffLL) return hipErrorNotSupported;
@@ -579,10 +611,11 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
         const T* sp = src + (size_t)f0 * src_fs;
         T* dp = dst + (size_t)f0 * dst_fs;
         const float4* pp = params_dev + f0;
+        const float4* ep = extents_dev ? extents_dev + f0 : nullptr;
         dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
 #define VS_LAUNCH(M, Bd) \
         hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
-                           tiles_x, magic, (int)tpf, chunk, maxv, roi)
+                           tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
         if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
         else if (mode == 0) VS_LAUNCH(0, 1);
         else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
@@ -594,13 +627,38 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
     return hipGetLastError();
 }
 
-hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, int mode, int border,
-                       int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
+hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, const float4* extents_dev,
+                       int mode, int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi,
+                       hipStream_t s) {
     if (bits == 8)
-        return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, mode, border, (uint8_t*)dst, dst_stride, n_frames,
-                                  src_fs, dst_fs, (float)max_value, roi, s);
-    return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, mode, border, (uint16_t*)dst, dst_stride, n_frames,
-                               src_fs, dst_fs, (float)max_value, roi, s);
+        return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint8_t*)dst, dst_stride,
+                                  n_frames, src_fs, dst_fs, (float)max_value, roi, s);
+    return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint16_t*)dst, dst_stride,
+                               n_frames, src_fs, dst_fs, (float)max_value, roi, s);
+}
+
+// The per-frame extents the tuned kernel's tile prologue adds to the position of a tile's origin (see the kernel): for the kernel
+// parameters P = {A, B, TX, TY} of a frame, {min, max of A1*i - B*j, min, max of B*i + A1*j} over i in [0, 63], j in [0, 15],
+// widened by eps = 2^-20 * M, M = a bound on every intermediate of the fp32 position arithmetic over the output window (the
+// arithmetic makes four roundings of relative size 2^-24 on values below M, for the pixel and for the tile origin: 8 * 2^-24 * M;
+// eps doubles that and covers the adds below), and rounded outward to float.
+void bgr_warp_c3_extents(const float* P4, int n_frames, Roi roi, float* E4) {
+    for (int f = 0; f < n_frames; f++) {
+        const double A1 = (double)(1.0f + P4[4 * f]), B = (double)P4[4 * f + 1], TX = (double)P4[4 * f + 2], TY = (double)P4[4 * f + 3];
+        const double X = (double)(roi.x + roi.w) + 64.0, Y = (double)(roi.y + roi.h) + 16.0;
+        const double M = std::max(std::fabs(A1) * X + std::fabs(B) * Y + std::fabs(TX), std::fabs(B) * X + std::fabs(A1) * Y + std::fabs(TY)) + 1.0;
+        const double eps = M * (1.0 / 1048576.0);
+        const double ax = A1 * (WT_W - 1), bx = -B * (WT_H - 1), ay = B * (WT_W - 1), by = A1 * (WT_H - 1);
+        const double lo_x = std::min(0.0, ax) + std::min(0.0, bx) - eps, hi_x = std::max(0.0, ax) + std::max(0.0, bx) + eps;
+        const double lo_y = std::min(0.0, ay) + std::min(0.0, by) - eps, hi_y = std::max(0.0, ay) + std::max(0.0, by) + eps;
+        const double v[4] = {lo_x, hi_x, lo_y, hi_y};
+        for (int k = 0; k < 4; k++) {
+            float q = (float)v[k];
+            if (!std::isfinite(v[k]) || !std::isfinite(q)) q = (k & 1) ? 3.0e38f : -3.0e38f;      // (the kernel's |.| < 1e6 test then refuses the window)
+            else if ((k & 1) ? (double)q < v[k] : (double)q > v[k]) q = std::nextafterf(q, (k & 1) ? INFINITY : -INFINITY);
+            E4[4 * f + k] = q;
+        }
+    }
 }
 
 }  // namespace vsk
