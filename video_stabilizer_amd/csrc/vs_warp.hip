@@ -49,6 +49,9 @@ namespace {
 #ifndef VS_WARP_EXACT_MINWAVES
 #define VS_WARP_EXACT_MINWAVES 4
 #endif
+#ifndef VS_WARP_COORDS_FIRST
+#define VS_WARP_COORDS_FIRST 0           // 1: a scheduling fence between the rows' position arithmetic and the sampler blocks
+#endif
 #ifndef VS_WARP_TILE_H
 #define VS_WARP_TILE_H 16                // output rows per workgroup (4 waves: VS_WARP_TILE_H / 4 rows per wave)
 #endif
@@ -491,21 +494,28 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     bool all_ok = true;
     // rows are processed two at a time, the two rows' instructions alternating in source order: a packed-fp32 result
     // cannot feed the very next VALU instruction without a wait state on gfx950, and the other row's operation fills it
+    // (VS_WARP_COORDS_FIRST: the positions of all RB rows before the first sampler block -- scalar fp32 instructions cost more
+    // between packed ones than among themselves, tools/ubench_mix.hip)
+    f2 fr_all[RB];
+    lds_f4 t_all[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const int yq = min(yw + k, roi.h - 1);               // rows below the window repeat its last row (masked below)
+        const float fy = (float)(yq + roi.y);
+        const float Wx = A1x - B * fy + TX;                  // generators.cpp:141
+        const float Wy = Bx + A1 * fy + TY;                  // generators.cpp:142
+        const float flx = floorf(Wx), fly = floorf(Wy);
+        fr_all[k] = f2{Wx - flx, Wy - fly};
+        const int boff = (int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0));
+        t_all[k] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
+    }
+#if VS_WARP_COORDS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int kp = 0; kp < RB; kp += 2) {
-        f2 fr[2];
-        lds_f4 t[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int yq = min(yw + kp + j, roi.h - 1);      // rows below the window repeat its last row (masked below)
-            const float fy = (float)(yq + roi.y);
-            const float Wx = A1x - B * fy + TX;              // generators.cpp:141
-            const float Wy = Bx + A1 * fy + TY;              // generators.cpp:142
-            const float flx = floorf(Wx), fly = floorf(Wy);
-            fr[j] = f2{Wx - flx, Wy - fly};
-            const int boff = (int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0));
-            t[j] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
-        }
+        const f2 fr[2] = {fr_all[kp], fr_all[kp + 1]};
+        const lds_f4 t[2] = {t_all[kp], t_all[kp + 1]};
         float q[2][3];
         if (MODE == 0) {
             exact_pair(t, fr, &num[kp]);
