@@ -1210,7 +1210,10 @@ struct vs_stabilizer {
     // device-resident clip batches: the warps of clip group g run on warp_stream under the alignment of group g + 1 (stab_run)
     hipStream_t warp_stream = nullptr;
     hipEvent_t warp_ev = nullptr;
-    bool overlap_warps = false;    // set by stab_run around the group calls
+    bool overlap_warps = false;    // set by stab_run around the group / chunk calls
+    bool defer_own = false;        // set for all but the last time chunk of one long device-resident clip: frames still queued stay
+                                   // pointers into the caller's batch (it outlives the call), only the last chunk copies them out
+    std::vector<void*> held_release;   // buffers whose last reader is a warp on warp_stream: back into the pool after its synchronisation
     std::vector<vs_transform> t_buf;
     std::vector<int32_t> st_buf;
     vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
@@ -1300,6 +1303,9 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         group_clips = std::max(group_clips, (n_clips_all + 7) / 8);
         if (group_clips >= n_clips_all) group_clips = 0;
     }
+    // one long clip: time chunks of >= 48 frames (the small solver build's threshold with room to spare), at most 8 of them
+    int time_chunk = 0;
+    if (overlap_env && dense_dev && clip_len == 0 && n >= 96) time_chunk = std::max(48, (n + 7) / 8);
     if (chunk > 0 && n > chunk)
         r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
                                     out_w, out_h);
@@ -1328,6 +1334,40 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         a->batch_mode = saved_mode;
         const hipError_t we = hipStreamSynchronize(s->warp_stream);          // every warp has landed before the call returns
         if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
+        for (void* b : s->held_release) s->pool.push_back(b);
+        s->held_release.clear();
+    } else if (time_chunk > 0) {
+        // ONE long device-resident clip: cut in time.  The batched form is n successive process calls, so the chunks are the same
+        // calls in the same order; the warps of chunk c (on warp_stream) run under the alignment of chunk c + 1.  Frames still
+        // queued at a chunk boundary stay pointers into the caller's batch until the last chunk copies them out; buffers of
+        // earlier calls whose last reader is a warp on warp_stream return to the pool only after that stream's synchronisation.
+        vs_aligner* a = s->aligner;
+        r = 0;
+        hipError_t he = hipSetDevice(a->device);
+        if (he == hipSuccess && !s->warp_stream) he = hipStreamCreateWithFlags(&s->warp_stream, hipStreamNonBlocking);
+        if (he == hipSuccess && !s->warp_ev) he = hipEventCreateWithFlags(&s->warp_ev, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventRecord(s->warp_ev, a->stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(s->warp_stream, s->warp_ev, 0);
+        if (he != hipSuccess) r = set_error(VS_ERR_HIP, "stabilizer warp stream: %s", hipGetErrorString(he));
+        const int saved_mode = a->batch_mode;
+        a->batch_mode = VS_BATCH_SHARED;
+        s->overlap_warps = true;
+        const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
+        for (int f0 = 0; r >= 0 && f0 < n; f0 += time_chunk) {
+            const int m = std::min(time_chunk, n - f0);
+            s->defer_own = f0 + m < n;
+            const int rg = stab_run_impl(s, (const uint8_t*)frames + (size_t)f0 * frame_stride * esz, frame_stride, m, 0, w, h, stride, format, mem,
+                                         mem, -1, (uint8_t*)out + (size_t)f0 * out_frame_stride * esz, out_frame_stride, has_output + f0, out_w,
+                                         out_h);
+            r = rg < 0 ? rg : r + rg;
+        }
+        s->defer_own = false;
+        s->overlap_warps = false;
+        a->batch_mode = saved_mode;
+        const hipError_t we = hipStreamSynchronize(s->warp_stream);
+        if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
+        for (void* b : s->held_release) s->pool.push_back(b);
+        s->held_release.clear();
     } else
         r = stab_run_impl(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, mem, -1, out, out_frame_stride, has_output,
                           out_w, out_h);
@@ -1550,7 +1590,10 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
             j = e;
         }
         for (size_t j = 0; j < jobs.size(); j++)
-            if (jobs[j].release) s->pool.push_back(jobs[j].release);   // reused only by later work on this stream
+            if (jobs[j].release) {
+                if (s->overlap_warps && !to_host) s->held_release.push_back(jobs[j].release);   // read on warp_stream, refilled on st
+                else s->pool.push_back(jobs[j].release);                                        // reused only by later work on this stream
+            }
         if (to_host) {
             const bool dense_out = out_frame_stride * esz == obytes;
             if (!threaded_download) {
@@ -1594,7 +1637,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
     if (clip_len > 0) VS_TRY(vs_stabilizer_reset(s));   // nothing carries over from the last clip
     // frames of this batch that are still queued move into buffers of our own
     for (auto& f : s->frames) {
-        if (f.owned) continue;
+        if (f.owned || s->defer_own) continue;
         void* copy = nullptr;
         if (!s->pool.empty()) { copy = s->pool.back(); s->pool.pop_back(); }
         else VS_HIP(hipMalloc(&copy, fbytes));
