@@ -1,6 +1,8 @@
 // vs_latency: what one AlignNextFrame costs from C++ -- the reference's own call pattern (alignment.cpp:206: one frame per
 // call), frames already in device memory.  No Python, no bindings: the C ABI of include/vs_amd.h and the HIP runtime only.
-//   usage: vs_latency [width height frames levels_min_width]      (default 1920 1080 48 256)
+//   usage: vs_latency [width height frames levels_min_width passes]      (default 1920 1080 48 256 24)
+// The clip is walked `passes` times and the best pass is reported: the card's shader clock needs tens of milliseconds of work to
+// settle (with VS_LATENCY_VERBOSE=1 every pass is printed: ~0.24 ms per call in the first passes, flat after ~100 ms).
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -73,6 +75,8 @@ static void make_frame(std::vector<uint8_t>& f, const std::vector<float>& tex, i
 int main(int argc, char** argv) {
     const int w = argc > 1 ? atoi(argv[1]) : 1920, h = argc > 2 ? atoi(argv[2]) : 1080, n = argc > 3 ? atoi(argv[3]) : 48;
     const int min_w = argc > 4 ? atoi(argv[4]) : 256;
+    const int passes = argc > 5 ? atoi(argv[5]) : 24;
+    const bool verbose = getenv("VS_LATENCY_VERBOSE") != nullptr;
     if (vs_device_count() < 1) { std::fprintf(stderr, "Error: no HIP device\n"); return 1; }
     vs_aligner_params p;
     vs_aligner_params_default(&p);
@@ -93,7 +97,7 @@ int main(int argc, char** argv) {
     double best = 1e30;
     int good = 0;
     long iters = 0;
-    for (int rep = 0; rep < 3; rep++) {
+    for (int rep = 0; rep < passes; rep++) {
         vs_aligner_reset(a);
         good = 0;
         const auto t0 = std::chrono::steady_clock::now();
@@ -110,6 +114,7 @@ int main(int argc, char** argv) {
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
         if (ms < best) best = ms;
+        if (verbose) std::fprintf(stderr, "pass %d: %.4f ms per call\n", rep, ms);
     }
     std::printf("{\"w\": %d, \"h\": %d, \"frames\": %d, \"aligned\": %d, \"gn_iterations_per_frame\": %.2f, \"ms_per_call\": %.4f}\n", w, h, n, good,
                 (double)iters / (n > 1 ? n - 1 : 1), best);

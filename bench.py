@@ -215,17 +215,25 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         def run():
             capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
                                              max_value=255, stream=stream.cuda_stream)
+        # The card's shader clock takes ~40 ms of continuous work to settle (tools/exp13.py: 64 -> 56 -> 49 us per frame over the
+        # first 5 / 12 / 40 ms after an idle spell, flat from there on): launches back to back for >= 80 ms first, then `reps` more,
+        # still back to back, each between two events on the launch stream.
         run()
         torch.cuda.synchronize()
-        ms = []
-        for _ in range(reps):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.08:
+            for _ in range(4):
+                run()
+            torch.cuda.synchronize()
+        evs = []
+        for _ in range(4 + reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
             run()
             b.record(stream)
-            torch.cuda.synchronize()
-            ms.append(a.elapsed_time(b))
-        ms.sort()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs[4:])
         med = ms[len(ms) // 2]
         nbytes = W * H * 3 * 2 * frames
         ach = nbytes / (med * 1e-3) / 1e9

@@ -37,9 +37,17 @@ def main():
 
     def run():
         capi.bgr_image_warp_batch_device(src.data_ptr(), n, W, H, 3, args.bits, ts, dst.data_ptr(), mode, border, max_value=mv, stream=st.cuda_stream)
-    for _ in range(3):
-        run()
+    # the shader clock needs ~40 ms of continuous work to settle (tools/exp13.py): back-to-back launches for >= 80 ms first
+    import time
+    run()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.08:
+        for _ in range(4):
+            run()
+        torch.cuda.synchronize()
+    for _ in range(4):
+        run()
     evs = []
     for _ in range(args.reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -215,7 +215,10 @@ constexpr int kCoopGroup = 16;         // workgroups per pair in latency mode (1
 constexpr int kCoopMaxGroup = 16;
 constexpr int kCoopMaxPairs = 128;     // helpers for launches of at most this many pairs (16 per pair up to 16 pairs, then as many as keep the launch within one workgroup per CU)
 constexpr int kChipCUs = 256;
-constexpr int kCoopMinTiles = 4096;    // levels with at least this many tiles are shared
+#ifndef VS_COOP_MIN_TILES
+#define VS_COOP_MIN_TILES 4096
+#endif
+constexpr int kCoopMinTiles = VS_COOP_MIN_TILES;    // levels with at least this many tiles are shared
 struct CoopLevel {
     int t_ready, nslices, pad[2];
     int assign[kCoopMaxGroup];         // slice number of helper g at this level, -1: not taking part
