@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: VS_INGEST_WGS existed in the build this experiment ran on; the ingest kernel has since moved to a 2-D grid)
 # bounded ingest grid under the shared-mode c2 step: ms/step, warp launch, ingest stage time; and ingest alone
 run() { python bench.py --no-cpu-baseline --no-roofline-4k --no-host-fed --steps 20 --warmup 5 --no-c3 2>/dev/null | python -c "
 import sys, json

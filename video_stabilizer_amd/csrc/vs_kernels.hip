@@ -235,17 +235,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src_all, int w, int h, int src_stride,
                                                        int shift_to_8, uint8_t* __restrict__ g0_all, uint8_t* __restrict__ g1_all,
                                                        int ow, int oh, size_t src_frame_stride, size_t pyr_frame_stride,
-                                                       int tiles_x, int tiles_per_frame, int total_tiles, int chunk) {
+                                                       int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk) {
     __shared__ __attribute__((aligned(8))) uint8_t tile[PD_IH][PD_IWP];
     __shared__ __attribute__((aligned(8))) uint32_t hsum[PD_IH][PD_TW / 2];
-    // One workgroup per tile -- or, when the launch is given fewer workgroups than tiles (a multiple of 8: vsk::ingest_pyr's
-    // `max_workgroups`, for callers that share the GPU), each workgroup walks every gridDim.x-th tile id of its XCD's run.
-    for (int bid = (int)blockIdx.x; bid < 8 * chunk; bid += (int)gridDim.x) {
-    // XCD-aware order (see vs_warp.hip): each XCD walks a contiguous raster run of tiles
-    const int logical = (bid & 7) * chunk + (bid >> 3);
-    if (logical < total_tiles) {                                  // (uniform)
-    const int frame = logical / tiles_per_frame, tl = logical - frame * tiles_per_frame;
-    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    // One workgroup per tile, frame = blockIdx.y.  XCD-aware order inside a frame (see vs_warp.hip): gridDim.x is a multiple of 8,
+    // so each XCD walks one contiguous raster run of the frame's tiles.  The tile split is a multiply-high on the scalar unit
+    // (tl / tiles_x == (tl * magic) >> 32 while tl * tiles_x < 2^32; a vector-unit division here was a sixth of the kernel's
+    // vector instructions).
+    {
+    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tl < tiles_per_frame) {                                   // (uniform)
+    const int frame = blockIdx.y;
+    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);
+    const int txi = tl - tyi * tiles_x;
     const T* __restrict__ src = src_all + (size_t)frame * src_frame_stride;
     uint8_t* __restrict__ g0 = g0_all + (size_t)frame * pyr_frame_stride;
     uint8_t* __restrict__ g1 = g1_all + (size_t)frame * pyr_frame_stride;
@@ -256,7 +258,9 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
     // 12-byte group are three v_alignbyte away.  u16: {B,G} . {3735,19235} is one v_dot2_u32_u16, R one multiply-add.
     constexpr uint32_t kWLo = (3735u & 255u) | ((19235u & 255u) << 8) | ((9798u & 255u) << 16);
     constexpr uint32_t kWHi = (3735u >> 8) | ((19235u >> 8) << 8) | ((9798u >> 8) << 16);
-    const bool frame_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * sizeof(T))) & 3u) == 0;   // uniform
+    // (row offsets below are 24-bit x 24-bit multiplies: full rate, where a 32-bit multiply is a quarter-rate instruction)
+    const bool frame_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * sizeof(T))) & 3u) == 0 && src_stride < (1 << 24) &&
+                               h < (1 << 24) && w < (1 << 24);   // uniform
     const bool g0_aligned = ((((uintptr_t)g0) | (uintptr_t)w) & 3u) == 0;
     // gray of the four pixels of one 12- / 24-byte group (dword aligned)
     auto gray4 = [&](const uint32_t* q, uint32_t (&g)[4]) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
             return g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
         };
         auto load_group = [&](uint32_t (&q)[QW], int gy, int gxc) {
-            const uint32_t* gp = (const uint32_t*)((const uint8_t*)src + (uint32_t)((gy * src_stride + gxc * 3) * (int)sizeof(T)));   // (a frame is below 4 GB)
+            const uint32_t* gp = (const uint32_t*)((const uint8_t*)src + (__umul24((uint32_t)gy, (uint32_t)src_stride) + (uint32_t)(gxc * 3)) * (uint32_t)sizeof(T));   // (a frame is below 4 GB)
             if (sizeof(T) == 1) {
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 const u32x3 t = *(const u32x3*)gp;
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
             const int r = r_own + 8 * it, oy = iy0 + r;                                   // level-0 row 2 * y0 + (r - 2)
             tile_w[r * (PD_IWP / 4) + c_own] = v;
             if (oy < h && gx_own < w) {
-                uint8_t* dst = g0 + (uint32_t)(oy * w + gx_own);
+                uint8_t* dst = g0 + (__umul24((uint32_t)oy, (uint32_t)w) + (uint32_t)gx_own);
                 if (own_dword) *(uint32_t*)dst = v;
                 else for (int k = 0; k < 4 && gx_own + k < w; k++) dst[k] = (uint8_t)(v >> (8 * k));
             }
@@ -392,7 +396,6 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
     __syncthreads();
     pyr_passes(tile, hsum, x0, y0, g1, ow, oh, ow);
     }
-    if (bid + (int)gridDim.x < 8 * chunk) __syncthreads();       // the tile buffers are refilled by the next round
     }
 }
 
@@ -984,18 +987,22 @@ hipError_t ingest_pyr(const void* src, int w, int h, int src_stride, int bits, i
                       int n_frames, size_t src_fs, size_t pyr_fs, hipStream_t s) {
     const int ow = w / 2, oh = h / 2;
     const int tiles_x = cdiv(w, 2 * PD_TW), tiles_y = cdiv(h, 2 * PD_TH);
-    const long long total = (long long)tiles_x * tiles_y * n_frames;
-    if (total > 0x3fffffffLL) return hipErrorNotSupported;
-    const int chunk = (int)((total + 7) / 8);
-    // experiment knob (read once): cap the number of workgroups of this launch (a multiple of 8); 0 = one per tile
-    static const int wg_cap = []() { const char* e = getenv("VS_INGEST_WGS"); return e ? (atoi(e) & ~7) : 0; }();
-    const int grid = wg_cap > 0 ? std::min(wg_cap, chunk * 8) : chunk * 8;
-    if (bits == 8)
-        hipLaunchKernelGGL(vs_k_ingest_pyr<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)src, w, h, src_stride,
-                           shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
-    else
-        hipLaunchKernelGGL(vs_k_ingest_pyr<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)src, w, h, src_stride,
-                           shift_to_8, g0, g1, ow, oh, src_fs, pyr_fs, tiles_x, tiles_x * tiles_y, (int)total, chunk);
+    const long long tpf = (long long)tiles_x * tiles_y;
+    if (tpf > 0x3fffffLL || tiles_x > 1024) return hipErrorNotSupported;      // (tl * tiles_x < 2^32 for the multiply-high below)
+    const int chunk = (int)((tpf + 7) / 8);
+    const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;    // tiles_x >= 2; the kernel special-cases 1
+    const size_t esz = bits == 8 ? 1 : 2;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {          // gridDim.y limit
+        const int nf = std::min(65535, n_frames - f0);
+        const dim3 grid((unsigned)(chunk * 8), (unsigned)nf);
+        const uint8_t* sp = (const uint8_t*)src + (size_t)f0 * src_fs * esz;
+        if (bits == 8)
+            hipLaunchKernelGGL(vs_k_ingest_pyr<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)sp, w, h, src_stride, shift_to_8,
+                               g0 + (size_t)f0 * pyr_fs, g1 + (size_t)f0 * pyr_fs, ow, oh, src_fs, pyr_fs, tiles_x, magic, (int)tpf, chunk);
+        else
+            hipLaunchKernelGGL(vs_k_ingest_pyr<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)sp, w, h, src_stride, shift_to_8,
+                               g0 + (size_t)f0 * pyr_fs, g1 + (size_t)f0 * pyr_fs, ow, oh, src_fs, pyr_fs, tiles_x, magic, (int)tpf, chunk);
+    }
     return hipGetLastError();
 }
 
