@@ -56,6 +56,9 @@ namespace {
 #define VS_WARP_TILE_H 16                // output rows per workgroup (4 waves: VS_WARP_TILE_H / 4 rows per wave)
 #endif
 
+#ifndef VS_WARP_WHATIF
+#define VS_WARP_WHATIF 0                 // analysis builds only (wrong results): 1 one LDS read per pixel instead of 16, 2 no fill, 4 no division, 8 no store, 16 no weight chains
+#endif
 #ifndef VS_WARP_ROW_BLOCK
 #define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
 #endif
@@ -121,7 +124,7 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], fl
         for (int j = 0; j < 2; j++) { x2[j][c] = x[j][c] * x[j][c]; v[j][c] = f2{0.000858519f, 0.000858519f}; }
     const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
 #pragma unroll
-    for (int s = 0; s < 6; s++) {
+    for (int s = 0; s < ((VS_WARP_WHATIF & 16) ? 1 : 6); s++) {
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -140,6 +143,7 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], fl
         v[j][3].y = fabsf(x[j][3].y) >= 2.0f ? 0.0f : v[j][3].y;
     }
     f2 nbg[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}}, nrd[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
+    const f4 one_tap[2] = {t[0][0], t[1][0]};
 #pragma unroll
     for (int ry = 0; ry < 4; ry++) {
         f2 p01[2], p23[2];
@@ -154,7 +158,7 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], fl
             f2 mbg[2], mrd[2];
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const f4 val = t[j][ry * WS_RS + rx];
+                const f4 val = (VS_WARP_WHATIF & 1) ? one_tap[j] : t[j][ry * WS_RS + rx];
                 const f2 pp = rx < 2 ? p01[j] : p23[j];
                 const float w2d = (rx & 1) ? pp.y : pp.x;
                 const f2 ww = {w2d, w2d};
@@ -191,7 +195,7 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
         for (int j = 0; j < 2; j++) { x2[j][c] = x[j][c] * x[j][c]; v[j][c] = 0.000858519f; }
     const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
 #pragma unroll
-    for (int s = 0; s < 6; s++)
+    for (int s = 0; s < ((VS_WARP_WHATIF & 16) ? 1 : 6); s++)
 #pragma unroll
         for (int c = 0; c < 8; c++)
 #pragma unroll
@@ -205,13 +209,14 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
         v[j][7] = fabsf(x[j][7]) >= 2.0f ? 0.0f : v[j][7];
         num[j][0] = 0.0f; num[j][1] = 0.0f; num[j][2] = 0.0f; num[j][3] = 0.0f;
     }
+    const f4 one_tap[2] = {t[0][0], t[1][0]};
 #pragma unroll
     for (int ry = 0; ry < 4; ry++) {
 #pragma unroll
         for (int rx = 0; rx < 4; rx++) {
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const f4 val = t[j][ry * WS_RS + rx];
+                const f4 val = (VS_WARP_WHATIF & 1) ? one_tap[j] : t[j][ry * WS_RS + rx];
                 const float w2d = v[j][rx] * v[j][4 + ry];
                 num[j][0] = __builtin_fmaf(w2d, val.x, num[j][0]);
                 num[j][1] = __builtin_fmaf(w2d, val.y, num[j][1]);
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         fits = groups <= WS_W / 4 && rows <= WS_H;
     }
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (fits) {
+    if (fits && !(VS_WARP_WHATIF & 2)) {
         // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
         // (16 + 8) rows x 20 groups = 480 items = 2 per thread; all loads are issued before the first conversion.
         const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)((size_t)src_stride * sizeof(T))) & 3) == 0;   // uniform
@@ -384,14 +389,15 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         // tests per item, one offset from a uniform base
         const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform
         if (interior) {
-            const T* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
+            const T* base = (VS_WARP_WHATIF & 32) ? src : src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
 #pragma unroll
             for (int s = 0; s < FILL_SLOTS; s++) {
                 it[s] = fill_item(lane, wv + 4 * s);
                 live[s] = it[s].row < rows && it[s].g < groups;
                 direct[s] = live[s];
                 rowp[s] = base;
-                const uint32_t off = (uint32_t)it[s].row * (uint32_t)src_stride + 12u * (uint32_t)it[s].g;      // elements
+                uint32_t off = (uint32_t)it[s].row * (uint32_t)src_stride + 12u * (uint32_t)it[s].g;      // elements
+                if (VS_WARP_WHATIF & 32) off &= 0xffcu;                  // (analysis: every load hits the same few cache lines)
                 if (live[s]) {
                     q0[s] = *(const u32x3*)(base + off);
                     if (sizeof(T) == 2) q1[s] = *(const u32x3*)(base + off + 6);
@@ -522,14 +528,16 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
-                div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
+                if (VS_WARP_WHATIF & 4) { q[j][0] = num[kp + j][0]; q[j][1] = num[kp + j][1]; q[j][2] = num[kp + j][2] + num[kp + j][3]; }
+                else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else if (MODE == 2) {
             fast_pair(t, fr, &num[kp]);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
-                div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
+                if (VS_WARP_WHATIF & 4) { q[j][0] = num[kp + j][0]; q[j][1] = num[kp + j][1]; q[j][2] = num[kp + j][2] + num[kp + j][3]; }
+                else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else {
             sample_bilinear(t[0], fr[0], q[0]);
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         }
         if (MODE == 2 && VS_WARP_FAST_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // keeps the second pair's 32 LDS reads (128 VGPRs) behind the first pair
     }
-    if (MODE != 1 && __any(!all_ok)) {
+    if (MODE != 1 && !VS_WARP_WHATIF && __any(!all_ok)) {
         // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
         for (int k = 0; k < RB; k++) {
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
             if (y < roi.h) {                                 // wave-uniform
                 uint8_t* orow = (uint8_t*)dst + (size_t)y * dst_stride;
                 if (rows_aligned && quad_in) {
-                    if (m < 3) *(uint32_t*)(orow + loff) = d;
+                    if (m < 3 && (!(VS_WARP_WHATIF & 8) || d == 0x12345678u)) *(uint32_t*)(orow + loff) = d;
                 } else if (lane_in) {
                     orow[(size_t)x * 3] = (uint8_t)o[k][0];
                     orow[(size_t)x * 3 + 1] = (uint8_t)o[k][1];
