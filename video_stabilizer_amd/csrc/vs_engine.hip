@@ -648,6 +648,10 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
         // BGR -> gray level 0 and level 1 in one pass (levels >= 3 always, so level 1 exists)
         VS_HIP(vsk::ingest_pyr(dframes, W, H, stride, fbits > 8 ? 16 : 8, fbits - 8, slot1,
                                slot1 + L[1].img_off, n, frame_stride, pyr_frame, s));
+#ifdef VS_EXP_REPEAT
+        // analysis builds: a stage launched twice (idempotent) -- the step's growth is what the stage costs beside the warp
+        if (VS_EXP_REPEAT & 1) VS_HIP(vsk::ingest_pyr(dframes, W, H, stride, fbits > 8 ? 16 : 8, fbits - 8, slot1, slot1 + L[1].img_off, n, frame_stride, pyr_frame, s));
+#endif
     }
     t_end(1);
     t_begin(VS_STAGE_PYR_DOWN);
@@ -691,6 +695,9 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
                 // one launch for every level of every keyframe of the run
                 VS_HIP(vsk::keyframe_levels(pyr + so * pyr_frame, lm + so * lm_frame, jac + so * jac_frame, KL, n_odd, 2 * pyr_frame,
                                             2 * lm_frame, 2 * jac_frame, s));
+#ifdef VS_EXP_REPEAT
+                if (VS_EXP_REPEAT & 4) VS_HIP(vsk::keyframe_levels(pyr + so * pyr_frame, lm + so * lm_frame, jac + so * jac_frame, KL, n_odd, 2 * pyr_frame, 2 * lm_frame, 2 * jac_frame, s));
+#endif
                 kf_launches += 1;
             } else {
                 for (int l = 0; l < levels; l++) {
