@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
             gray4(q, g);
             return g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
         };
-        auto load_group = [&](uint32_t (&q)[QW], int gy, int gxc) {
-            const uint32_t* gp = (const uint32_t*)((const uint8_t*)src + (__umul24((uint32_t)gy, (uint32_t)src_stride) + (uint32_t)(gxc * 3)) * (uint32_t)sizeof(T));   // (a frame is below 4 GB)
+        auto load_group_at = [&](uint32_t (&q)[QW], uint32_t byte_off) {
+            const uint32_t* gp = (const uint32_t*)((const uint8_t*)src + byte_off);   // (a frame is below 4 GB)
             if (sizeof(T) == 1) {
                 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
                 const u32x3 t = *(const u32x3*)gp;
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
                 const u32x2 tb = *(const u32x2*)(gp + 4);
                 q[0] = ta.x; q[1] = ta.y; q[2] = ta.z; q[3] = ta.w; q[QW - 2] = tb.x; q[QW - 1] = tb.y;
             }
+        };
+        auto load_group = [&](uint32_t (&q)[QW], int gy, int gxc) {
+            load_group_at(q, (__umul24((uint32_t)gy, (uint32_t)src_stride) + (uint32_t)(gxc * 3)) * (uint32_t)sizeof(T));
         };
         // border group: pixel k = clamp(gx + k) of the row = byte clamp(gx + k) - gxc of the packed word
         auto border_sel = [&](int gx, int gxc) {
@@ -359,12 +362,31 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
         const bool has_halo = tid < N_ITEMS - 1024;
         const int gx_h = ix0 + 4 * c_h, gxc_h = clampi(gx_h, 0, w - 4);
         uint32_t q[5][QW];
+        uint32_t* const tile_w = (uint32_t*)&tile[0][0];
+        // Interior tiles (the whole 136 x 35 footprint inside the image, dword-aligned level 0: all but the frame's rim -- 82 % of the
+        // tiles at 1080p, 90 % at 4K): no clamps, no border selectors, no partial stores; the four own rows are uniform strides apart.
+        const bool interior = g0_aligned && ix0 >= 0 && ix0 + PD_IW <= w && iy0 >= 0 && iy0 + PD_IH <= h;   // uniform
+        if (interior) {
+            const uint32_t o_own = (__umul24((uint32_t)(iy0 + r_own), (uint32_t)src_stride) + (uint32_t)(gx_own * 3)) * (uint32_t)sizeof(T);
+            const uint32_t o_step = 8u * (uint32_t)src_stride * (uint32_t)sizeof(T);
+#pragma unroll
+            for (int it = 0; it < 4; it++) load_group_at(q[it], o_own + (uint32_t)it * o_step);
+            load_group_at(q[4], (__umul24((uint32_t)(iy0 + r_h), (uint32_t)src_stride) + (uint32_t)(gx_h * 3)) * (uint32_t)sizeof(T));
+            const uint32_t g_own = __umul24((uint32_t)(iy0 + r_own), (uint32_t)w) + (uint32_t)gx_own, g_step = 8u * (uint32_t)w;
+            const int t_own = r_own * (PD_IWP / 4) + c_own;
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const uint32_t v = gray_word(q[it]);
+                tile_w[t_own + 8 * it * (PD_IWP / 4)] = v;
+                *(uint32_t*)(g0 + (g_own + (uint32_t)it * g_step)) = v;
+            }
+            if (has_halo) tile_w[r_h * (PD_IWP / 4) + c_h] = gray_word(q[4]);
+        } else {
 #pragma unroll
         for (int it = 0; it < 4; it++) load_group(q[it], min(iy0 + r_own + 8 * it, h - 1), gxc_own);
         load_group(q[4], clampi(iy0 + r_h, 0, h - 1), gxc_h);
         const bool own_border = gx_own != gxc_own, own_dword = g0_aligned && gx_own + 3 < w;
         const uint32_t own_sel = border_sel(gx_own, gxc_own);
-        uint32_t* const tile_w = (uint32_t*)&tile[0][0];
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             uint32_t v = gray_word(q[it]);
@@ -381,6 +403,7 @@ __global__ __launch_bounds__(256) void vs_k_ingest_pyr(const T* __restrict__ src
             uint32_t v = gray_word(q[4]);
             if (gx_h != gxc_h) v = __builtin_amdgcn_perm(0u, v, border_sel(gx_h, gxc_h));
             tile_w[r_h * (PD_IWP / 4) + c_h] = v;
+        }
         }
     } else {
         for (int i = threadIdx.x; i < N_ITEMS; i += 256) {

@@ -59,6 +59,9 @@ namespace {
 #ifndef VS_WARP_WHATIF
 #define VS_WARP_WHATIF 0                 // analysis builds only (wrong results): 1 one LDS read per pixel instead of 16, 2 no fill, 4 no division, 8 no store, 16 no weight chains
 #endif
+#ifndef VS_WARP_TILES_PER_WG
+#define VS_WARP_TILES_PER_WG 1           // consecutive tiles of its XCD's run a workgroup walks; > 1: the next tile's source loads are in flight during the current tile's sampler blocks
+#endif
 #ifndef VS_WARP_ROW_BLOCK
 #define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
 #endif
@@ -331,15 +334,25 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id order and
     // gridDim.x is a multiple of 8, so workgroup b of a frame works on its tile (b % 8) * chunk + b / 8: every XCD walks
     // one contiguous run of tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
-    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (tl >= tiles_per_frame) return;
+    constexpr int NT = VS_WARP_TILES_PER_WG;
+    const int tl0 = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) * NT;         // this workgroup's first tile
+    const int tl_end = min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk);        // end of its XCD's run
+    if (tl0 >= tl_end) return;
     const int frame = blockIdx.y;
-    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);         // tl / tiles_x (scalar unit)
-    const int txi = tl - tyi * tiles_x;
     const float4 P = params[frame];
     src += (size_t)frame * src_fs;
     dst += (size_t)frame * dst_fs;
     const float A1 = 1.0f + P.x, B = P.y, TX = P.z, TY = P.w;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)((size_t)src_stride * sizeof(T))) & 3) == 0;   // uniform
+    float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (extents != nullptr) E = extents[frame];
+
+    // everything about a tile that the fill and the sampler blocks need; all of it wave-uniform
+    struct Geom { int x0, y0, sx_lo, sy_lo, rows, groups; bool fits, interior; };
+    auto geom = [&](int tl) -> Geom {
+    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);         // tl / tiles_x (scalar unit)
+    const int txi = tl - tyi * tiles_x;
     // output pixel (x, y) of the window is pixel (x + roi.x, y + roi.y) of the full frame: the sampling position is
     // computed from the full-frame coordinate, so a window equals the same rows / columns cut out of the whole warp
     const int x0 = txi * WT_W, y0 = tyi * WT_H;
@@ -354,7 +367,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     const float fx0 = (float)(x0 + roi.x), fx1 = (float)(x1 + roi.x), fy0 = (float)(y0 + roi.y), fy1 = (float)(y1 + roi.y);
     float mnx, mxx, mny, mxy;
     if (extents != nullptr) {                               // (uniform)
-        const float4 E = extents[frame];
         const float Wx00 = A1 * fx0 - B * fy0 + TX, Wy00 = B * fx0 + A1 * fy0 + TY;
         mnx = Wx00 + E.x; mxx = Wx00 + E.y; mny = Wy00 + E.z; mxy = Wy00 + E.w;
     } else {
@@ -376,32 +388,43 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         groups = (sx_hi - sx_lo + 4) >> 2;                 // column groups of 4 pixels
         fits = groups <= WS_W / 4 && rows <= WS_H;
     }
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (fits && !(VS_WARP_WHATIF & 2)) {
-        // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
-        // (16 + 8) rows x 20 groups = 480 items = 2 per thread; all loads are issued before the first conversion.
-        const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)((size_t)src_stride * sizeof(T))) & 3) == 0;   // uniform
+    // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
+    // tests per item, one offset from a uniform base
+    const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform
+    return Geom{x0, y0, sx_lo, sy_lo, rows, groups, fits, interior};
+    };
+
+    // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
+    // (16 + 8) rows x 20 groups = 480 items = 2 per thread; all loads are issued before the first conversion.
+    u32x3 q0[FILL_SLOTS], q1[FILL_SLOTS];
+    // the loads of an interior tile: into q0 / q1, which the fill converts -- right away, or (VS_WARP_TILES_PER_WG > 1) after the
+    // previous tile's sampler blocks, so that a tile's memory latency lies under the tile before it
+    auto issue = [&](const Geom& g) {
+        const T* base = (VS_WARP_WHATIF & 32) ? src : src + ((size_t)g.sy_lo * src_stride + (size_t)g.sx_lo * 3);
+#pragma unroll
+        for (int s = 0; s < FILL_SLOTS; s++) {
+            const FillItem it = fill_item(lane, wv + 4 * s);
+            uint32_t off = (uint32_t)it.row * (uint32_t)src_stride + 12u * (uint32_t)it.g;      // elements
+            if (VS_WARP_WHATIF & 32) off &= 0xffcu;                  // (analysis: every load hits the same few cache lines)
+            if (it.row < g.rows && it.g < g.groups) {
+                q0[s] = *(const u32x3*)(base + off);
+                if (sizeof(T) == 2) q1[s] = *(const u32x3*)(base + off + 6);
+            }
+        }
+    };
+    auto fill = [&](const Geom& g, bool loaded) {
+        const int sx_lo = g.sx_lo, sy_lo = g.sy_lo, rows = g.rows, groups = g.groups;
         FillItem it[FILL_SLOTS];
         bool live[FILL_SLOTS], direct[FILL_SLOTS];
         const T* rowp[FILL_SLOTS];
-        u32x3 q0[FILL_SLOTS], q1[FILL_SLOTS];
-        // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
-        // tests per item, one offset from a uniform base
-        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform
-        if (interior) {
-            const T* base = (VS_WARP_WHATIF & 32) ? src : src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
+        if (g.interior) {
+            if (!loaded) issue(g);
 #pragma unroll
             for (int s = 0; s < FILL_SLOTS; s++) {
                 it[s] = fill_item(lane, wv + 4 * s);
                 live[s] = it[s].row < rows && it[s].g < groups;
                 direct[s] = live[s];
-                rowp[s] = base;
-                uint32_t off = (uint32_t)it[s].row * (uint32_t)src_stride + 12u * (uint32_t)it[s].g;      // elements
-                if (VS_WARP_WHATIF & 32) off &= 0xffcu;                  // (analysis: every load hits the same few cache lines)
-                if (live[s]) {
-                    q0[s] = *(const u32x3*)(base + off);
-                    if (sizeof(T) == 2) q1[s] = *(const u32x3*)(base + off + 6);
-                }
+                rowp[s] = src;
             }
         } else {
 #pragma unroll
@@ -456,9 +479,12 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                 }
             }
         }
-    }
-    __syncthreads();
+    };
 
+    // the sampler blocks and stores of one tile (LDS filled, barrier passed)
+    auto sample_tile = [&](const Geom& g) {
+    const int x0 = g.x0, y0 = g.y0, sx_lo = g.sx_lo, sy_lo = g.sy_lo;
+    const bool fits = g.fits;
     const int x = x0 + lane;
     const int yw = y0 + wv * RPW;                            // first row of this wave
     if (yw >= roi.h) return;                                 // wave-uniform
@@ -609,6 +635,27 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         }
     }
     }   // row blocks
+    };
+
+    Geom g = geom(tl0);
+    bool loaded = false;
+    if (NT > 1 && g.interior) { issue(g); loaded = true; }
+#pragma unroll 1
+    for (int i = 0; i < NT; i++) {
+        if (g.fits && !(VS_WARP_WHATIF & 2)) fill(g, loaded);
+        __syncthreads();
+        const bool more = i + 1 < NT && tl0 + i + 1 < tl_end;        // (uniform)
+        Geom gn = g;
+        bool loaded_n = false;
+        if (more) {
+            gn = geom(tl0 + i + 1);
+            if (gn.interior) { issue(gn); loaded_n = true; }          // in flight during this tile's sampler blocks
+        }
+        sample_tile(g);
+        if (!more) break;
+        __syncthreads();                                               // every wave has read its taps: the tile buffer is free
+        g = gn; loaded = loaded_n;
+    }
 }
 
 }  // namespace
@@ -630,7 +677,7 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
         T* dp = dst + (size_t)f0 * dst_fs;
         const float4* pp = params_dev + f0;
         const float4* ep = extents_dev ? extents_dev + f0 : nullptr;
-        dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
+        dim3 grid((unsigned)((chunk + VS_WARP_TILES_PER_WG - 1) / VS_WARP_TILES_PER_WG * 8), (unsigned)nf), block(256);
 #define VS_LAUNCH(M, Bd) \
         hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
                            tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
