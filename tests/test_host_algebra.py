@@ -71,6 +71,19 @@ def test_tvl1_and_smoother_identical_to_oracle(vs, oracle):
         assert okg == okc and tg.tup() == tc.tup()
 
 
+@pytest.mark.parametrize("lag,memory", [(1, 0), (3, 7), (10, 5), (30, 33), (50, 40)])
+def test_smoother_window_sizes(vs, oracle, lag, memory):
+    """the four parameters are swept interleaved (windows up to 64 samples) or one after the other (longer windows): both must be
+    the oracle's scalar sweep bit for bit, through the warm-up (growing window) and in the steady state, for jumps beyond lambda too"""
+    rng = np.random.default_rng(100 * lag + memory)
+    g, c = vs.Smoother(lag, memory, 4.0), oracle.Smoother(lag, memory, 4.0)
+    for i in range(2 * (lag + memory) + 20):
+        m = rng.normal(scale=(0.01, 3.0, 40.0)[i % 3], size=4)
+        okg, tg = g.update(vs.Transform.of(*m))
+        okc, tc = c.update(oracle.Transform.of(*m))
+        assert okg == okc and tg.tup() == tc.tup()
+
+
 def test_format_bits(vs, oracle):
     """16-bit containers carry their sample depth in the format (luma shift = bits - 8, warp saturation = vs_format_max_value)"""
     want = {vs.FMT_GRAY8: 8, vs.FMT_BGR8: 8, vs.FMT_BGR10: 10, vs.FMT_BGR12: 12, vs.FMT_BGR16_FULL: 16, 6: 0, -1: 0}
