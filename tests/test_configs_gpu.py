@@ -213,18 +213,20 @@ def test_overlapped_clip_groups_equal_clip_by_clip(gpu_vs, bits, mode):
     assert torch.equal(out2, out)
 
 
-@pytest.mark.parametrize("n,bits", [(120, 8), (101, 10)])
-def test_long_device_clip_in_time_chunks_equals_frame_by_frame(gpu_vs, n, bits):
+@pytest.mark.parametrize("n,bits,n2", [(120, 8, 30), (101, 10, 30), (100, 8, 97)])
+def test_long_device_clip_in_time_chunks_equals_frame_by_frame(gpu_vs, n, bits, n2):
     """vs_stabilizer_process_batch on ONE long dense device-resident clip is cut in time (chunks of >= 48 frames): the warps of
     chunk c run on their own stream under the alignment of chunk c + 1, frames queued across a chunk boundary stay pointers into
     the caller's batch.  Must equal n successive process() calls bit for bit -- and a second batch on the same handle (frames of
-    the first batch still queued in buffers of the handle's own) must continue the sequence exactly as the calls do."""
+    the first batch still queued in buffers of the handle's own) must continue the sequence exactly as the calls do, whether that
+    second batch is one piece (30 frames) or cut in time itself (97 frames: its first warps read the handle's own buffers on the
+    second stream)."""
     torch = pytest.importorskip("torch")
     from video_stabilizer_amd import synth
     dev = torch.device("cuda", 0)
     w, h = 480, 270
     dt = torch.uint8 if bits == 8 else torch.int16
-    clip, _ = synth.TorchClipFactory(w, h, 4200, dev, channels=3, bits=bits).make(n + 30, 4201)
+    clip, _ = synth.TorchClipFactory(w, h, 4200, dev, channels=3, bits=bits).make(n + n2, 4201)
     torch.cuda.synchronize()
     fmt = gpu_vs.FMT_BGR8 if bits == 8 else gpu_vs.FMT_BGR10
     kw = dict(lag=5, smoother_memory=3, crop_pixels=8, warp_mode=gpu_vs.WARP_LANCZOS2)
@@ -234,10 +236,10 @@ def test_long_device_clip_in_time_chunks_equals_frame_by_frame(gpu_vs, n, bits):
     seq = gpu_vs.Stabilizer(device=0, **kw)
     want = [seq.process(f, fmt=fmt) for f in host]
     bat = gpu_vs.Stabilizer(device=0, **kw)
-    out = torch.zeros((n + 30, h - 16, w - 16, 3), dtype=dt, device=dev)
+    out = torch.zeros((n + n2, h - 16, w - 16, 3), dtype=dt, device=dev)
     r1, has1 = bat.process_batch_device(clip[0].data_ptr(), n, w, h, fmt, out.data_ptr())                    # time chunks
-    r2, has2 = bat.process_batch_device(clip[n].data_ptr(), 30, w, h, fmt, out[n].data_ptr())                 # one piece, continues the clip
-    assert r1 == n - 5 and r2 == 30
+    r2, has2 = bat.process_batch_device(clip[n].data_ptr(), n2, w, h, fmt, out[n].data_ptr())                 # continues the clip
+    assert r1 == n - 5 and r2 == n2
     got = out.cpu().numpy()
     if bits != 8:
         got = got.view(np.uint16)
