@@ -449,13 +449,14 @@ def main():
         local_rank = args.device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, backend_used, backend_note = None, None, None
     if world > 1 or args.force_dist:
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
-        dist = vsdist.init(args.dist_backend, rank, world, device_id=dev if args.dist_backend == "nccl" else None)
+        dist, backend_used, backend_note = vsdist.init_with_fallback(args.dist_backend, rank, world,
+                                                                      device_id=dev if args.dist_backend == "nccl" else None)
         assert dist.get_world_size() == world, "process group has %d ranks, launcher says %d" % (dist.get_world_size(), world)
         assert world == args.gpus or args.force_dist, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
-    red_dev = dev if args.dist_backend == "nccl" else None     # where the three report scalars are reduced
+    red_dev = dev if (dist is not None and backend_used == "nccl") else None     # where the three report scalars are reduced
 
     wl = WORKLOADS[args.workload]
     W, H, bits = wl["w"], wl["h"], wl["bits"]
@@ -561,7 +562,7 @@ def main():
         out = {
             "metric": "aligned frames/sec", "value": round((total_good if not wl["stabilizer"] else total_frames) / dt, 2), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
-            "dist_backend": (args.dist_backend if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
+            "dist_backend": (backend_used if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8" if bits == 8 else "u16", "data": "synthetic",
             "config": {"workload": wl["name"] if not args.default_levels else
@@ -582,6 +583,8 @@ def main():
             "value_counts": ("stabilized output frames + the lag frames that produce none" if wl["stabilizer"] else
                              "aligned frames only (AlignNextFrame true): the first frame of a clip has no predecessor"),
         }
+        if backend_note:
+            out["dist_backend_note"] = "RCCL could not be initialised (%s): the report scalars were reduced over gloo on the host" % backend_note
         if tm:
             out["stages"] = stage_table(tm, args.steps)
             out["gn_iterations_per_frame"] = round(tm["gn_iterations"] / max(1, tm["frames"]), 2)

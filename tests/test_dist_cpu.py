@@ -55,6 +55,42 @@ def test_two_rank_gloo_shard_and_aggregate(tmp_path):
         assert o["per_rank"] == [outs[0]["own"], outs[1]["own"]] and max(o["per_rank"]) == o["secs"]
 
 
+FALLBACK_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+from video_stabilizer_amd import dist as D
+world, rank, local = D.env_world()
+# no GPU in this process: RCCL cannot come up, on either rank -- the group must come back on gloo, with the reason
+d, used, why = D.init_with_fallback("nccl", rank, world, device_id=torch.device("cuda", 0), probe_seconds=30)
+secs, f, a = D.aggregate(1.0 + rank, 10, 9)
+print(json.dumps({"rank": rank, "used": used, "why": why, "secs": secs, "frames": f, "aligned": a, "world": d.get_world_size()}))
+d.destroy_process_group()
+'''
+
+
+def test_rccl_init_failure_falls_back_to_gloo(tmp_path):
+    """SURVEY 8(e): if RCCL cannot be initialised the report scalars are aggregated on the host and the line says so"""
+    import json
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: RCCL comes up")
+    script = tmp_path / "f.py"
+    script.write_text(FALLBACK_WORKER % ROOT)
+    port = str(29950 + os.getpid() % 40)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        j = json.loads(o.strip().splitlines()[-1])
+        assert j["used"] == "gloo" and j["why"] and j["world"] == 2
+        assert j["secs"] == 2.0 and j["frames"] == 20 and j["aligned"] == 18
+
+
 def test_gather_seconds_without_a_process_group():
     from video_stabilizer_amd import dist as D
     assert D.gather_seconds(1.25) == [1.25]

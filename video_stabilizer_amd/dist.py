@@ -25,6 +25,40 @@ def init(backend, rank, world, device_id=None):
     return dist
 
 
+def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=180):
+    """"if RCCL init fails on the box, fall back to host-side aggregation and say so".  Initialises `backend`
+    and proves it with one tiny all-reduce (communicator creation and the first collective are where a broken RCCL setup shows,
+    on every rank alike); if either raises, the group is torn down and re-created on gloo (CPU tensors, next port), and the
+    reason is returned for the report.  -> (dist, backend in use, None or the reason)"""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    if backend != "nccl":
+        return init(backend, rank, world, device_id), backend, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    why = None
+    try:
+        kw = {"device_id": device_id} if device_id is not None else {}
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=probe_seconds), **kw)
+        t = torch.ones(1, dtype=torch.int64, device=device_id)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError("probe all-reduce returned %d for %d ranks" % (int(t.item()), world))
+        return dist, "nccl", None
+    except Exception as e:          # noqa: BLE001 -- whatever RCCL raises
+        why = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:           # noqa: BLE001
+            pass
+    os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)      # the first store may still hold its port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, "gloo", why
+
+
 def aggregate(seconds, frames, aligned, device=None):
     """whole-job numbers: (max seconds over ranks, total frames, total aligned).  Works on any backend."""
     import torch
