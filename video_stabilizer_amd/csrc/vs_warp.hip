@@ -458,10 +458,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                     t[3] = f4{ub(q.z, 1), ub(q.z, 2), ub(q.z, 3), ub(one, 0)};
                 } else {
                     const u32x3 a = q0[s], b = q1[s];        // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3 (16 bits each)
-                    t[0] = f4{(float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), 1.f};
-                    t[1] = f4{(float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), 1.f};
-                    t[2] = f4{(float)(b.x & 0xffffu), (float)(b.x >> 16), (float)(b.y & 0xffffu), 1.f};
-                    t[3] = f4{(float)(b.y >> 16), (float)(b.z & 0xffffu), (float)(b.z >> 16), 1.f};
+                    // (the 1.0 converted from a register like its neighbours, as above: no vector-building moves)
+                    t[0] = f4{(float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu), ub(one, 0)};
+                    t[1] = f4{(float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), ub(one, 0)};
+                    t[2] = f4{(float)(b.x & 0xffffu), (float)(b.x >> 16), (float)(b.y & 0xffffu), ub(one, 0)};
+                    t[3] = f4{(float)(b.y >> 16), (float)(b.z & 0xffffu), (float)(b.z >> 16), ub(one, 0)};
                 }
             } else {
                 // frame border, an unaligned frame, or (constant border) a row outside the frame: pixel by pixel
