@@ -25,7 +25,7 @@ def init(backend, rank, world, device_id=None):
     return dist
 
 
-def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=180):
+def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300):
     """"if RCCL init fails on the box, fall back to host-side aggregation and say so".  Initialises `backend`
     and proves it with one tiny all-reduce (communicator creation and the first collective are where a broken RCCL setup shows,
     on every rank alike); if either raises, the group is torn down and re-created on gloo (CPU tensors, next port), and the
