@@ -89,7 +89,7 @@ def usable_threads():
     return avail, total
 
 
-def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0, record=None):
+def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0, record=None, select_rule=0):
     """oracle (CPU restatement of the reference) on the host cores: one independent clip copy per thread, kernels
     single-threaded -- the reference's own multi-clip regime (grid_search_align.cpp:105-210).  `record` (a list) receives
     thread 0's per-frame results (ok, transform, iterations, fail_reason): the parity gate reads them, no extra CPU work."""
@@ -106,7 +106,7 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0, record
                 if done is not None:
                     done[k] += 1
         else:
-            a = O.Aligner(**params_kw)
+            a = O.Aligner(select_rule=select_rule, **params_kw)
             for i in range(count):
                 ok, t = a.align_next(frames_host[i])
                 if rec is not None:
@@ -310,7 +310,8 @@ class AlignWarp:
         self.N = n_clips * n
         self.stream = torch.cuda.current_stream()
         self.aligner = capi.Aligner(device=dev.index,
-                                    select_mode=capi.SELECT_DEVICE if args.select == "device" else capi.SELECT_STL_HOST, **params_kw)
+                                    select_mode={"device": capi.SELECT_DEVICE, "stable": capi.SELECT_STABLE, "host": capi.SELECT_STL_HOST}[args.select],
+                                    **params_kw)
         self.warped = None if args.no_warp else torch.empty_like(self.frames)
         self.ev = []
         self.shared(True)
@@ -410,7 +411,9 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override the clip length")
     ap.add_argument("--clips-per-gpu", type=int, default=0)
-    ap.add_argument("--select", default="device", choices=["host", "device"])
+    ap.add_argument("--select", default="device", choices=["host", "device", "stable"],
+                    help="device = on-device replica of libstdc++'s nth_element (default, and `value`); stable = VS_SELECT_STABLE, the "
+                         "documented STL-independent rule (oracle select rule 1); host = D2H + std::nth_element")
     ap.add_argument("--no-warp", action="store_true", help="alignment only (c2/c3/c4)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the parity gate that rides on it")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -556,6 +559,17 @@ def main():
         dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
         contracted = (dt_f, good_f)
 
+    stable = None
+    if aw and not args.no_warp and args.warp_mode == "exact" and args.select == "device":
+        # fourth figure: the same step with the selection under the documented STL-independent rule (VS_SELECT_STABLE, SURVEY 8(f)
+        # rank 1; bit-identical to the oracle's select rule 1: tests/test_select_stable_gpu.py) -- beside `value`, never as `value`
+        aw.aligner.set_select_mode(capi.SELECT_STABLE)
+        aw.step(False)
+        dt_s, good_s = timed_loop(lambda: aw.step(False), args.steps)
+        dt_s, _, good_s = vsdist.aggregate(dt_s, n * n_clips * args.steps, int(good_s) * args.steps, device=red_dev)
+        aw.aligner.set_select_mode(capi.SELECT_DEVICE)
+        stable = (dt_s, good_s)
+
     rc = 0
     out = None
     if rank == 0:
@@ -570,7 +584,8 @@ def main():
                        "frames_per_clip": n, "clips_per_gpu": n_clips, "width": W, "height": H,
                        "bits": bits, "clip_seeds": "clip i -> rank i mod N; path seed %d + 1000 i" % wl["seed"],
                        "selection": "std::nth_element on the host" if args.select == "host"
-                       else "on-device replica of libstdc++ nth_element (same survivors, same order)",
+                       else ("VS_SELECT_STABLE: smallest by (abs_delta, tile index), survivors in tile order (oracle select rule 1)" if args.select == "stable"
+                             else "on-device replica of libstdc++ nth_element (same survivors, same order)"),
                        "solver": "clip groups overlapped inside vs_stabilizer_process_clips: the warps of group g run under the alignment of group "
                                  "g + 1 (small-footprint solver build)" if wl["stabilizer"] else
                        "exclusive (512-thread workgroup per pair)" if (args.exclusive_solver or args.no_warp)
@@ -600,6 +615,11 @@ def main():
                                       "note": "same step with bgr_image_warp in VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as "
                                               "the reference's own target allows (CMakeLists.txt:151 fma, no strict_float); np.array_equal with the "
                                               "oracle's VSO_WARP_LANCZOS2_CONTRACTED (tests/test_warp_fast_gpu.py, `parity` below)"}
+        if stable:
+            out["stable_select"] = {"value": round(stable[1] / stable[0], 2), "unit": "frames/s", "ms_per_step": round(1e3 * stable[0] / args.steps, 4),
+                                    "note": "same step with VS_SELECT_STABLE: the keep-best-80 % step under a documented STL-independent rule (smallest "
+                                            "by (abs_delta, tile index), survivors in tile order) instead of the replica of libstdc++'s nth_element order; "
+                                            "bit-identical to the oracle's select rule 1"}
         if aw and aw.ev:
             out["roofline"] = roofline_of(aw, n * n_clips)
 
@@ -609,7 +629,7 @@ def main():
         if bits != 8:
             fh = fh.view("uint16")
         rec = []
-        out["cpu_baseline"] = cpu_baseline(fh, params_kw, wl["stabilizer"], record=rec)
+        out["cpu_baseline"] = cpu_baseline(fh, params_kw, wl["stabilizer"], record=rec, select_rule=1 if args.select == "stable" else 0)
         out["cpu_baseline"]["cpu_model"] = cpu_model()
         if aw is not None and rec:
             try:

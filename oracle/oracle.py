@@ -52,6 +52,7 @@ class AlignDebug(C.Structure):
 
 
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED = 0, 1, 2
+SELECT_STL, SELECT_STABLE = 0, 1
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4
@@ -98,6 +99,8 @@ def lib():
         "vso_transform_warp_center": (Point, [TP, Point, f64, f64]),
         "vso_transform_max_corner_displacement": (f64, [TP, f64, f64]),
         "vso_select_smallest": (i32, [vp, i32, i32, f32, vp]),
+        "vso_select_smallest_stable": (i32, [vp, i32, i32, f32, vp]),
+        "vso_aligner_set_select_rule": (i32, [vp, i32]),
         "vso_nth_element_killer": (i32, [i32, i32, f32, vp]),
         "vso_nth_element_hits_depth_limit": (i32, [vp, i32, f32]),
         "vso_hessian": (None, [vp, i32, vp, i32, vp]),
@@ -341,6 +344,15 @@ def select_smallest(warpdiff, fraction=0.8):
     return idx[:n].copy()
 
 
+def select_smallest_stable(warpdiff, fraction=0.8):
+    """the documented STL-independent rule: smallest by (abs_delta, tile index), survivors in ascending tile order"""
+    wd = _c(warpdiff, np.uint16)
+    ty, tx = wd.shape
+    idx = np.empty(tx * ty, np.int32)
+    n = lib().vso_select_smallest_stable(_p(wd), tx, ty, fraction, _p(idx))
+    return idx[:n].copy()
+
+
 def nth_element_killer(tx, ty, fraction=0.8):
     """(ty, tx) uint16 table on which std::nth_element(begin, begin + n*fraction, end) runs out of its depth budget"""
     out = np.empty((ty, tx), np.uint16)
@@ -456,9 +468,16 @@ def _fmt_of(frame):
 class Aligner:
     """VideoAligner restatement (alignment.cpp)"""
 
-    def __init__(self, **params):
+    def __init__(self, select_rule=0, **params):
         self.h = lib().vso_aligner_create()
         self.params = aligner_params(**params)
+        if select_rule:
+            self.set_select_rule(select_rule)
+
+    def set_select_rule(self, rule):
+        """0: std::nth_element as the reference; 1 (SELECT_STABLE): smallest by (abs_delta, tile index), survivors in tile order"""
+        if lib().vso_aligner_set_select_rule(self.h, int(rule)) != 0:
+            raise ValueError("select rule %r" % (rule,))
 
     def align_next(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)

@@ -529,6 +529,26 @@ int vso_select_smallest(const uint16_t* warpdiff, int tx, int ty, float fraction
     return (int)selected_count;
 }
 
+/* The same keep-best-fraction step under a documented, STL-independent rule: keep the selected_count
+ * tiles that are smallest by (abs_delta, tile index) -- ties on abs_delta go to the lower tile index -- and hand them out in
+ * ascending tile order.  Any conforming std::nth_element may produce this set (its comparator sees abs_delta only, so which of
+ * the tied elements land in front of nth is unspecified); the order of the survivors, which the reference leaves to the STL,
+ * is fixed here.  The product's VS_SELECT_STABLE mode is compared with this bit for bit. */
+int vso_select_smallest_stable(const uint16_t* warpdiff, int tx, int ty, float fraction, int32_t* out_idx) {
+    const size_t n = (size_t)tx * ty;
+    const size_t selected_count = static_cast<size_t>(n * fraction);
+    if (selected_count == 0) return 0;
+    std::vector<uint32_t> key(n);
+    for (size_t i = 0; i < n; i++) key[i] = ((uint32_t)warpdiff[i] << 16) | (uint32_t)(i & 0xffffu);   /* i < 65536 tiles per level */
+    std::vector<uint32_t> sorted(key);
+    std::sort(sorted.begin(), sorted.end());
+    const uint32_t cut = sorted[selected_count - 1];
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++)
+        if (key[i] <= cut) out_idx[m++] = (int32_t)i;
+    return (int)m;      /* == selected_count: the keys are distinct */
+}
+
 /* Test-input generator: a warpdiff table on which std::nth_element(begin, begin + n*fraction, end) -- this libstdc++'s, the
  * call above -- runs out of its introselect depth budget (2 * lg n partitions) and falls back to heap-select.  McIlroy's
  * adversary ("A Killer Adversary for Quicksort", 1999): the algorithm runs on item ids whose values are decided lazily --
@@ -717,6 +737,7 @@ struct vso_aligner {
     std::vector<Level> L;
     std::vector<int32_t> idx;
     vso_align_debug dbg;
+    int select_rule = 0;      /* 0: std::nth_element as the reference (this libstdc++'s order); 1: vso_select_smallest_stable */
 
     bool ComputePyramid(const void* frame, int width, int height, int stride, int format, const vso_aligner_params& params);
     bool ComputeKeyFrame();
@@ -826,13 +847,14 @@ int vso_aligner::Align(const void* frame, int w, int h, int stride, int format, 
 
         /* :435-546 selection + gather */
         idx.resize(ntiles);
-        int nx = vso_select_smallest(l.wdx.data(), l.tx, l.ty, params.smallest_fraction, idx.data());
+        int (*const select)(const uint16_t*, int, int, float, int32_t*) = select_rule ? vso_select_smallest_stable : vso_select_smallest;
+        int nx = select(l.wdx.data(), l.tx, l.ty, params.smallest_fraction, idx.data());
         l.selx.resize((size_t)nx * 2); l.seljx.resize((size_t)nx * 4);
         for (int j = 0; j < nx; j++) {
             l.selx[j] = l.amx[idx[j]]; l.selx[(size_t)nx + j] = l.amx[ntiles + idx[j]];
             for (int k = 0; k < 4; k++) l.seljx[(size_t)k * nx + j] = l.jx[(size_t)k * ntiles + idx[j]];
         }
-        int ny = vso_select_smallest(l.wdy.data(), l.tx, l.ty, params.smallest_fraction, idx.data());
+        int ny = select(l.wdy.data(), l.tx, l.ty, params.smallest_fraction, idx.data());
         l.sely.resize((size_t)ny * 2); l.seljy.resize((size_t)ny * 4);
         for (int j = 0; j < ny; j++) {
             l.sely[j] = l.amy[idx[j]]; l.sely[(size_t)ny + j] = l.amy[ntiles + idx[j]];
@@ -888,6 +910,11 @@ int vso_aligner::Align(const void* frame, int w, int h, int stride, int format, 
 
 extern "C" {
 vso_aligner* vso_aligner_create(void) { return new vso_aligner(); }
+int vso_aligner_set_select_rule(vso_aligner* a, int rule) {
+    if (!a || (rule != 0 && rule != 1)) return -1;
+    a->select_rule = rule;
+    return 0;
+}
 void vso_aligner_destroy(vso_aligner* a) { delete a; }
 int vso_aligner_align_next(vso_aligner* a, const void* frame, int w, int h, int stride, int format,
                            const vso_aligner_params* params, vso_transform* out) {

@@ -124,6 +124,8 @@ double        vso_transform_max_corner_displacement(const vso_transform* t, doub
 /* std::nth_element on {abs_delta,tile_x,tile_y} exactly as alignment.cpp:438-486 (libstdc++).
  * Writes the kept tile indices (tile_y*tx+tile_x) in the post-nth_element order. Returns count. */
 int  vso_select_smallest(const uint16_t* warpdiff, int tx, int ty, float fraction, int32_t* out_idx);
+/* the same step under the documented STL-independent rule: smallest by (abs_delta, tile index), survivors in tile order */
+int  vso_select_smallest_stable(const uint16_t* warpdiff, int tx, int ty, float fraction, int32_t* out_idx);
 /* test inputs for the selection: a table on which this libstdc++'s std::nth_element exhausts its introselect depth budget
  * (McIlroy's adversary run against the very call above), and a literal restatement of __introselect's control flow that says
  * whether a table does so */
@@ -165,6 +167,7 @@ typedef struct vso_align_debug {
 } vso_align_debug;
 
 vso_aligner* vso_aligner_create(void);
+int  vso_aligner_set_select_rule(vso_aligner*, int rule);   /* 0 = std::nth_element (default), 1 = vso_select_smallest_stable */
 void vso_aligner_destroy(vso_aligner*);
 /* returns 1 aligned, 0 not aligned (first frame / no convergence / over displacement), <0 bad args */
 int  vso_aligner_align_next(vso_aligner*, const void* frame, int w, int h, int stride_elems, int format,

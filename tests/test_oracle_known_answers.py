@@ -608,3 +608,18 @@ def test_row_parallel_mode_changes_nothing(oracle):
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
     for s in (0, 1):
         assert np.array_equal(am1[s], am5[s]) and np.array_equal(j1[s], j5[s])
+
+
+def test_stable_selection_rule(oracle):
+    """vso_select_smallest_stable: the documented STL-independent rule against a literal restatement, and
+    against std::nth_element's outcome as a multiset of abs_delta values (any conforming nth_element keeps the same VALUES)"""
+    rng = np.random.default_rng(8)
+    for (ty, tx, hi, frac) in ((9, 16, 12, 0.8), (27, 48, 4, 0.8), (5, 7, 60000, 0.8), (12, 12, 300, 0.5), (3, 3, 2, 1.0), (4, 4, 9, 0.01)):
+        wd = rng.integers(0, hi, size=(ty, tx)).astype(np.uint16)
+        flat = wd.ravel()
+        k = int(np.float32(flat.size) * np.float32(frac)) if frac < 1.0 else flat.size
+        got = oracle.select_smallest_stable(wd, frac)
+        want = sorted(sorted(range(flat.size), key=lambda i: (int(flat[i]), i))[:len(got)])
+        assert list(got) == want and np.all(np.diff(got) > 0)
+        stl = oracle.select_smallest(wd, frac)
+        assert len(stl) == len(got) and sorted(flat[stl].tolist()) == sorted(flat[got].tolist())

@@ -1,0 +1,105 @@
+"""VS_SELECT_STABLE: the keep-best-fraction step under a documented, STL-independent rule -- smallest by
+(abs_delta, tile index), survivors in ascending tile order -- against its oracle twin (select rule 1), bit for bit in everything
+that is integer and to the usual 1e-12-grade agreement in the transforms (same survivors in the same order => the same sums)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+def _d(tg, tc):
+    return float(np.abs(np.array(tg.tup()) - np.array(tc.tup())).max())
+
+
+def _check(res):
+    for i, (ok_g, t_g, inf, ok_c, t_c, dbg) in enumerate(res):
+        assert ok_g == ok_c and inf.fail_reason == dbg.fail_reason, (i, ok_g, ok_c, inf.fail_reason, dbg.fail_reason)
+        if ok_c or dbg.fail_reason in (2, 3):
+            assert list(inf.iterations[:dbg.levels]) == list(dbg.iterations[:dbg.levels]), i
+            for l in range(dbg.levels):
+                if dbg.iterations[l]:
+                    assert abs(inf.condition[l] - dbg.condition[l]) <= 1e-9 * dbg.condition[l]
+                assert (inf.selected_x[l], inf.selected_y[l]) == (dbg.selected_x[l], dbg.selected_y[l]), (i, l)
+                assert _d(inf.level_transform[l], dbg.level_transform[l]) < TIGHT, (i, l)
+        assert _d(t_g, t_c) < TIGHT, (i, t_g.tup(), t_c.tup())
+
+
+@pytest.mark.parametrize("w,h,ch,kw", [(640, 480, 1, {}), (1920, 1080, 3, dict(pyramid_min_width=256)), (322, 246, 3, {}),
+                                       (3840, 2160, 1, dict(pyramid_min_width=256))])
+def test_stable_rule_one_frame_at_a_time(gpu_vs, oracle, w, h, ch, kw):
+    """AlignNextFrame pattern (latency mode: helper workgroups, pipelined loop) in VS_SELECT_STABLE against the oracle's rule 1"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(w, h, 5, seed=71, channels=ch)
+    gpu = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **kw)
+    res = []
+    for f in frames:
+        ok_g, t_g = gpu.align_next(f)
+        ok_c, t_c = cpu.align_next(f)
+        res.append((ok_g, t_g, gpu.info(0), ok_c, t_c, cpu.debug()))
+    assert sum(r[3] for r in res) >= 3
+    _check(res)
+
+
+def test_stable_rule_is_a_different_member_of_the_family(gpu_vs, oracle):
+    """the rule changes which tied tiles survive and the order of the sums: the transforms agree with the libstdc++-order modes to
+    sub-pixel accuracy, not bit for bit -- and the three device builds of the stable mode agree with each other exactly"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(960, 540, 40, seed=72, channels=3)
+    kw = dict(pyramid_min_width=100)
+    ref = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_DEVICE, **kw)
+    s_ref, t_ref = ref.align_batch(frames)
+    outs = []
+    for shared in (0, 1):
+        a = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+        if shared:
+            a.set_batch_mode(gpu_vs.BATCH_SHARED)               # >= 32 pairs: the small-footprint build (virtual threads)
+        outs.append(a.align_batch(frames))
+    seq = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    one = [seq.align_next(f) for f in frames]                   # latency mode
+    assert outs[0][0] == outs[1][0] == [int(o[0]) for o in one] == s_ref
+    for i in range(len(frames)):
+        assert outs[0][1][i].tup() == outs[1][1][i].tup() == one[i][1].tup(), i
+        assert _d(outs[0][1][i], t_ref[i]) < 0.05, i
+    assert any(outs[0][1][i].tup() != t_ref[i].tup() for i in range(1, len(frames)))
+    cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **kw)
+    for i, f in enumerate(frames[:6]):
+        ok_c, t_c = cpu.align_next(f)
+        assert ok_c == bool(outs[0][0][i]) and _d(outs[0][1][i], t_c) < TIGHT, i
+
+
+def test_stable_rule_4k_shared_build_selects_on_global_scratch(gpu_vs, oracle):
+    """4K level 0 (20736 tiles per set) in the small-footprint build: the histogram passes and the placement run on the pair's
+    global scratch; same results as the exclusive build, and as the oracle"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(3840, 2160, 34, seed=73, channels=1)
+    kw = dict(pyramid_min_width=256)
+    a = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    b = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    b.set_batch_mode(gpu_vs.BATCH_SHARED)
+    sa, ta = a.align_batch(frames)
+    sb, tb = b.align_batch(frames)
+    assert sa == sb and sum(sa) >= 30
+    assert [t.tup() for t in ta] == [t.tup() for t in tb]
+    cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **kw)
+    for i, f in enumerate(frames[:3]):
+        ok_c, t_c = cpu.align_next(f)
+        assert ok_c == bool(sa[i]) and _d(ta[i], t_c) < TIGHT, i
+
+
+def test_stable_rule_failures_and_16bit_deltas(gpu_vs, oracle):
+    """failure protocol under the stable rule, and sources whose abs_delta exceeds 255 (the general three-pass cut): 16-bit gray
+    is not an input format, so large deltas come from a high-contrast 8-bit pair that does not align at the coarsest level"""
+    from video_stabilizer_amd import synth
+    path = [(0, 0, 0, 0), (0, 0, 60.0, -45.0), (0, 0, 0, 0), (0.0, 0.3, 0, 0), (0, 0, 1, 1)]
+    frames, _ = synth.make_clip(320, 240, 5, seed=51, path=path, margin=160)
+    for kw in ({}, dict(max_iters=2)):
+        gpu = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+        cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **kw)
+        res = []
+        for f in frames:
+            ok_g, t_g = gpu.align_next(f)
+            ok_c, t_c = cpu.align_next(f)
+            res.append((ok_g, t_g, gpu.info(0), ok_c, t_c, cpu.debug()))
+        _check(res)

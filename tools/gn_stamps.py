@@ -12,7 +12,8 @@ W, H, n = 1920, 1080, 6
 batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 0     # --batch 240: pair 0 of a full launch
 frames, _ = synth.make_clip_torch(W, H, max(n, batch), seed=5, device=torch.device("cuda", 0))
 torch.cuda.synchronize()
-al = capi.Aligner(device=0, pyramid_min_width=256)
+al = capi.Aligner(device=0, pyramid_min_width=256,
+                  select_mode=capi.SELECT_STABLE if "--stable" in sys.argv else capi.SELECT_DEVICE)
 if batch:
     for r in range(2):
         sys.stderr.write(f"--- batch of {batch}, pass {r}\n"); sys.stderr.flush()

@@ -20,7 +20,7 @@ FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the s
 FMT_BGR16 = 5                                       # first-release format: 10-bit luma (gray >> 2), warp output saturates at 65535
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
-SELECT_STL_HOST, SELECT_DEVICE = 0, 1
+SELECT_STL_HOST, SELECT_DEVICE, SELECT_STABLE = 0, 1, 2
 BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1
 
 
@@ -485,6 +485,11 @@ class Aligner:
         if not self.h:
             raise VsError("vs_aligner_create failed: %s" % lib().vs_last_error().decode())
         _check(lib().vs_aligner_set_select_mode(self.h, select_mode))
+
+    def set_select_mode(self, mode):
+        """SELECT_DEVICE (default: libstdc++'s nth_element order, replicated on the device), SELECT_STABLE (the documented
+        STL-independent rule: smallest by (abs_delta, tile index), survivors in tile order) or SELECT_STL_HOST"""
+        _check(lib().vs_aligner_set_select_mode(self.h, mode))
 
     def set_batch_mode(self, mode):
         """BATCH_SHARED: full batches run through the small-footprint solver kernel (same bits; for callers that overlap

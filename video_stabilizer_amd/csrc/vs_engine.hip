@@ -82,6 +82,7 @@ struct GnParams {
     int stall_helpers;   // test hook (VS_GN_STALL_HELPERS=1): helpers never report back, the leader's bounded wait must expire
     int sel_depth_cap;   // test hook (VS_GN_SELECT_DEPTH=k > 0): the on-device introselect gets k partition rounds instead of 2 lg n, so
                          // ordinary frames take the "libstdc++ would have heap-selected" exit (fail_reason 100 -> host redo)
+    int sel_stable;      // VS_SELECT_STABLE: smallest by (abs_delta, tile index), survivors in tile order (stable_select)
 };
 
 // ---- phase-correlation start value (alignment.cpp:376-387) -----------------------------------------
@@ -579,6 +580,21 @@ int vs_aligner::select_host(int n_pairs, const LevelDims& l) {
             const int p = job >> 1, set = job & 1;
             if (h_states[p].status != 1) continue;
             const uint16_t* src = h_wd + (size_t)p * wd_pair + (size_t)set * nt;
+            if (select_mode == VS_SELECT_STABLE) {
+                // (levels beyond the on-device capacity in VS_SELECT_STABLE mode: the same rule on the host --
+                // smallest by (abs_delta, tile index), survivors in tile order)
+                std::vector<uint64_t> key((size_t)nt);
+                for (int i = 0; i < nt; i++) key[i] = ((uint64_t)src[i] << 32) | (uint32_t)i;
+                std::vector<uint64_t> sorted(key);
+                int32_t* dst = h_idx + (size_t)p * wd_pair + (size_t)set * nt;
+                if (nsel > 0) {
+                    std::nth_element(sorted.begin(), sorted.begin() + (nsel - 1), sorted.end());     // (distinct keys: the cut is unique)
+                    const uint64_t cut = sorted[nsel - 1];
+                    int m = 0;
+                    for (int i = 0; i < nt; i++) if (key[i] <= cut) dst[m++] = i;
+                }
+                continue;
+            }
             v.clear();
             v.reserve(nt);
             for (int j = 0; j < l.ty; j++)
@@ -785,7 +801,7 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
         const int pipeline = pipe_env >= 0 ? pipe_env : (n_pairs <= kPipelineMaxPairs ? 1 : 0);
         static const int stall_env = []() { const char* e = getenv("VS_GN_STALL_HELPERS"); return e ? atoi(e) : 0; }();
         static const int depth_env = []() { const char* e = getenv("VS_GN_SELECT_DEPTH"); return e ? atoi(e) : 0; }();
-        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env, depth_env};
+        GnParams gp{p.threshold, p.max_displacement, p.max_iters, pipeline, stall_env, depth_env, select_mode == VS_SELECT_STABLE ? 1 : 0};
         ck.gp = gp;
         const bool use_host = select_mode == VS_SELECT_STL_HOST || nt_max > kSelectCap;
         ck.use_host = use_host;
@@ -1071,7 +1087,7 @@ void vs_aligner_destroy(vs_aligner* a) {
 }
 
 int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
-    VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE));
+    VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE || mode == VS_SELECT_STABLE));
     a->select_mode = mode;
     return VS_OK;
 }
