@@ -339,6 +339,8 @@ int  vs_stabilizer_reset(vs_stabilizer* s);   /* start a new clip; device buffer
 /* stream ordering for VS_MEM_DEVICE frames: see vs_aligner_wait_stream */
 void* vs_stabilizer_stream(const vs_stabilizer* s);
 int   vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream);
+/* the selection rule of the stabilizer's aligner (VS_SELECT_*, see vs_aligner_set_select_mode); takes effect with the next frame */
+int   vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode);
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 
 #ifdef __cplusplus

@@ -101,6 +101,7 @@ def lib():
         "vso_select_smallest": (i32, [vp, i32, i32, f32, vp]),
         "vso_select_smallest_stable": (i32, [vp, i32, i32, f32, vp]),
         "vso_aligner_set_select_rule": (i32, [vp, i32]),
+        "vso_stabilizer_set_select_rule": (i32, [vp, i32]),
         "vso_nth_element_killer": (i32, [i32, i32, f32, vp]),
         "vso_nth_element_hits_depth_limit": (i32, [vp, i32, f32]),
         "vso_hessian": (None, [vp, i32, vp, i32, vp]),
@@ -521,9 +522,11 @@ class Aligner:
 class Stabilizer:
     """VideoStabilizer restatement (stabilizer.cpp)"""
 
-    def __init__(self, **params):
+    def __init__(self, select_rule=0, **params):
         self.params = stabilizer_params(**params)
         self.h = lib().vso_stabilizer_create(C.byref(self.params))
+        if select_rule and lib().vso_stabilizer_set_select_rule(self.h, int(select_rule)) != 0:
+            raise ValueError("select rule %r" % (select_rule,))
 
     def process(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)

@@ -953,6 +953,7 @@ struct vso_stabilizer {
 };
 
 extern "C" {
+int vso_stabilizer_set_select_rule(vso_stabilizer* s, int rule) { return s ? vso_aligner_set_select_rule(&s->aligner, rule) : -1; }
 vso_stabilizer* vso_stabilizer_create(const vso_stabilizer_params* p) {
     vso_stabilizer_params d;
     if (p) d = *p; else vso_stabilizer_params_default(&d);

@@ -182,6 +182,7 @@ const float*    vso_aligner_level_jacobian(const vso_aligner*, int level, int se
 /* ---- VideoStabilizer (stabilizer.cpp) ---------------------------------------------------- */
 typedef struct vso_stabilizer vso_stabilizer;
 vso_stabilizer* vso_stabilizer_create(const vso_stabilizer_params*);
+int  vso_stabilizer_set_select_rule(vso_stabilizer*, int rule);   /* the stabilizer's aligner: see vso_aligner_set_select_rule */
 void vso_stabilizer_destroy(vso_stabilizer*);
 /* frame: interleaved BGR u8 (format BGR8) or u16 (BGR16).  out must hold (w-2c)*(h-2c)*3 elements.
  * returns 1 if an output frame was produced, 0 if not yet, <0 error. */

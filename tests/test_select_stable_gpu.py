@@ -103,3 +103,20 @@ def test_stable_rule_failures_and_16bit_deltas(gpu_vs, oracle):
             ok_c, t_c = cpu.align_next(f)
             res.append((ok_g, t_g, gpu.info(0), ok_c, t_c, cpu.debug()))
         _check(res)
+
+
+def test_stabilizer_in_stable_mode_matches_the_oracle_with_rule_1(gpu_vs, oracle):
+    """VideoStabilizer frame by frame with the stable selection on both sides: same has-output pattern, same pixels"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 14, seed=77, channels=3)
+    kw = dict(lag=3, smoother_memory=2, crop_pixels=8, warp_mode=gpu_vs.WARP_LANCZOS2)
+    g = gpu_vs.Stabilizer(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    c = oracle.Stabilizer(select_rule=oracle.SELECT_STABLE, **kw)
+    n_out = 0
+    for f in frames:
+        og, oc = g.process(f), c.process(f)
+        assert (og is None) == (oc is None)
+        if og is not None:
+            assert np.array_equal(og, oc)
+            n_out += 1
+    assert n_out == len(frames) - 3

@@ -123,6 +123,7 @@ SIGNATURES = {
     "vs_aligner_create": (_vp, [C.POINTER(AlignerParams), _i32]),
     "vs_aligner_destroy": (None, [_vp]),
     "vs_aligner_set_select_mode": (_i32, [_vp, _i32]),
+    "vs_stabilizer_set_select_mode": (_i32, [_vp, _i32]),
     "vs_aligner_set_batch_mode": (_i32, [_vp, _i32]),
     "vs_aligner_reset": (_i32, [_vp]),
     "vs_aligner_align_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP]),
@@ -607,11 +608,17 @@ class Aligner:
 class Stabilizer:
     """VideoStabilizer (stabilizer.hpp:32-56) on the GPU engine."""
 
-    def __init__(self, device=0, **params):
+    def __init__(self, device=0, select_mode=None, **params):
         self.params = stabilizer_params(**params)
         self.h = lib().vs_stabilizer_create(C.byref(self.params), device)
         if not self.h:
             raise VsError("vs_stabilizer_create failed: %s" % lib().vs_last_error().decode())
+        if select_mode is not None:
+            self.set_select_mode(select_mode)
+
+    def set_select_mode(self, mode):
+        """the selection rule of the stabilizer's aligner (SELECT_DEVICE by default, SELECT_STABLE, SELECT_STL_HOST)"""
+        _check(lib().vs_stabilizer_set_select_mode(self.h, mode))
 
     def process(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)

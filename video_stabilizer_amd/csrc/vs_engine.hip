@@ -1836,6 +1836,10 @@ int vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t fra
 
 // forget the clip: the next frame starts a new sequence (device buffers are kept)
 void* vs_stabilizer_stream(const vs_stabilizer* s) { return s && s->aligner ? (void*)s->aligner->stream : nullptr; }
+int vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode) {
+    VS_ARG(s && s->aligner);
+    return vs_aligner_set_select_mode(s->aligner, mode);
+}
 int vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream) {
     VS_ARG(s && s->aligner);
     return vs_aligner_wait_stream(s->aligner, producer_stream);
