@@ -47,7 +47,7 @@ def test_bench_line_contract(gpu_vs):
         assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
         assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
     assert j["roofline_4k"]["contracted"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
-    assert j["contracted_warp"]["value"] > 0
+    assert j["contracted_warp"]["value"] > 0 and j["stable_select"]["value"] > 0
     # the 4K half of the metric (BASELINE configs[2]) in the same line
     c3 = j["c3"]
     assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
