@@ -169,6 +169,10 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
  * heap-select fallback for array a (not replicated; callers then use the host).  Returns count. */
 int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction,
                        int32_t* out_idx, int32_t* status, int mem, void* stream);
+/* The same step under VS_SELECT_STABLE's rule: the first `count` entries of each row are the tiles that are
+ * smallest by (abs_delta, tile index), in ascending tile order -- the oracle's vso_select_smallest_stable.  Returns count. */
+int vs_select_smallest_stable(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction,
+                              int32_t* out_idx, int mem, void* stream);
 /* cv::phaseCorrelate(a, b, cv::noArray(), &response) as VideoAligner calls it (alignment.cpp:372-374) on the CV_32F copy
  * of pyramid level 2 (alignment.cpp:225-229): two w x h u8 images -> result[3] = {shift.x, shift.y, response} in host
  * memory (the call synchronises).  Images are zero-padded to vs_optimal_dft_size (cv::getOptimalDFTSize: 2^a 3^b 5^c);

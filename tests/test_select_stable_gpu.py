@@ -120,3 +120,21 @@ def test_stabilizer_in_stable_mode_matches_the_oracle_with_rule_1(gpu_vs, oracle
             assert np.array_equal(og, oc)
             n_out += 1
     assert n_out == len(frames) - 3
+
+
+@pytest.mark.parametrize("ty,tx,hi,frac", [(27, 48, 12, 0.8), (27, 48, 3, 0.8), (54, 96, 40, 0.8), (9, 16, 65536, 0.8), (54, 96, 65536, 0.8),
+                                           (54, 96, 1000, 0.5), (3, 3, 2, 1.0), (4, 4, 9, 0.01), (1, 1, 5, 0.8), (2, 97, 300, 0.8),
+                                           (108, 240, 7, 0.8), (108, 240, 65536, 0.8), (7, 37, 256, 0.99)])
+def test_stable_selection_kernel_against_the_oracle(gpu_vs, oracle, ty, tx, hi, frac):
+    """vs_select_smallest_stable on arbitrary u16 tables: 8-bit deltas (one histogram pass), deltas up to 65535 (the byte-by-byte
+    cut, which the engine's 8-bit luma never reaches), heavy ties, levels too small for the lane-sliced histogram copies, every
+    element kept / none kept, several arrays per launch"""
+    rng = np.random.default_rng(1000 * ty + tx + hi)
+    wd = rng.integers(0, hi, size=(3, ty, tx)).astype(np.uint16)
+    wd[1, :, : tx // 2] = wd[1, 0, 0]                       # half of array 1 is one value
+    if hi > 256:
+        wd[2] = (wd[2] & 0xff00) | 7                        # array 2: the low byte never decides
+    got = gpu_vs.select_smallest_stable(wd, frac)
+    for k in range(3):
+        want = oracle.select_smallest_stable(wd[k], frac)
+        assert np.array_equal(got[k], want), k

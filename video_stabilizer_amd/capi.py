@@ -111,6 +111,7 @@ SIGNATURES = {
     "vs_sparse_warpdiff": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "vs_sparse_ica": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
     "vs_select_smallest": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "vs_select_smallest_stable": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _i32, _vp]),
     "vs_phase_correlate": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vs_optimal_dft_size": (_i32, [_i32]),
     "vs_image_warp": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _i32, _i32, _vp]),
@@ -371,6 +372,17 @@ def select_smallest(warpdiff, fraction=0.8):
     status = np.empty(n, np.int32)
     cnt = _check(lib().vs_select_smallest(_p(wd), n, tx, ty, fraction, _p(idx), _p(status), MEM_HOST, None))
     return [idx[i, :cnt].copy() for i in range(n)], status
+
+
+def select_smallest_stable(warpdiff, fraction=0.8):
+    """the same step under VS_SELECT_STABLE's rule.  warpdiff: (ty,tx) or (n,ty,tx) u16.  returns a list of idx arrays"""
+    wd = _c(warpdiff, np.uint16)
+    if wd.ndim == 2:
+        wd = wd[None]
+    n, ty, tx = wd.shape
+    idx = np.empty((n, ty * tx), np.int32)
+    cnt = _check(lib().vs_select_smallest_stable(_p(wd), n, tx, ty, fraction, _p(idx), MEM_HOST, None))
+    return [idx[i, :cnt].copy() for i in range(n)]
 
 
 def optimal_dft_size(n):

@@ -825,6 +825,7 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
                 const size_t both = ((img_bytes + 15) & ~(size_t)15) + (size_t)L[levels - 1].nt * 12;
                 if (both <= 150 * 1024) dyn = std::max(dyn, (both + 15) & ~(size_t)15);
             }
+            dyn = std::max<size_t>(dyn, 512);       // (tiny levels: the wave-level selection rounds use 128 bytes behind the keys as scratch)
             const bool small_wg = nt_max <= kSmallWgTiles;
             // latency mode: helper workgroups for the large levels of a pair (see CoopCtrl)
             static const int coop_env = []() { const char* e = getenv("VS_GN_HELPERS"); return e ? atoi(e) : -1; }();
@@ -848,6 +849,7 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
                     const size_t need = ((nt <= 32 * (nt256v::kGnThreads / 2) && nt * 12 <= kCoResidentDynMax ? nt * 12 : nt * 6) + 15) & ~(size_t)15;
                     if (need <= kCoResidentDynMax) dyn = std::max(dyn, need); else need_global = true;
                 }
+                dyn = std::max<size_t>(dyn, 512);
                 // (the kernel takes a non-null scratch pointer as "LDS block sized per level": always passed in this mode)
                 const size_t want = need_global ? selbuf_pair * (size_t)std::max(cap, n_pairs) : 256;
                 if (selbuf_bytes < want) {
@@ -1029,9 +1031,21 @@ extern "C" {
 
 // Kernel-level form of the keep-best-fraction step (alignment.cpp:435-492) for n_arrays independent
 // warpdiff tables: out_idx[a*tx*ty + 0..count) = tile_y*tx+tile_x of the survivors in std::nth_element's order.
+static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
+                                int32_t* status, int mem, void* stream, int rule);
 int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
                        int32_t* status, int mem, void* stream) {
-    VS_ARG(warpdiff && out_idx && status && n_arrays >= 1 && tx >= 1 && ty >= 1 && fraction > 0.0f && fraction <= 1.0f);
+    VS_ARG(status);
+    return select_smallest_impl(warpdiff, n_arrays, tx, ty, fraction, out_idx, status, mem, stream, 0);
+}
+// ... under VS_SELECT_STABLE's rule: smallest by (abs_delta, tile index), the survivors in ascending tile order
+int vs_select_smallest_stable(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx, int mem,
+                              void* stream) {
+    return select_smallest_impl(warpdiff, n_arrays, tx, ty, fraction, out_idx, nullptr, mem, stream, 1);
+}
+static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
+                                int32_t* status, int mem, void* stream, int rule) {
+    VS_ARG(warpdiff && out_idx && (status || rule) && n_arrays >= 1 && tx >= 1 && ty >= 1 && fraction > 0.0f && fraction <= 1.0f);
     const int nt = tx * ty;
     if (nt > kSelectCap) return set_error(VS_ERR_UNSUPPORTED, "%d tiles exceed the on-device selection capacity %d", nt, kSelectCap);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -1040,16 +1054,17 @@ int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, f
     vsi::Staged a, o, st;
     VS_TRY(a.in(warpdiff, (size_t)n_arrays * nt * 2, mem, s));
     VS_TRY(o.out(out_idx, (size_t)n_arrays * nt * 4, mem));
-    VS_TRY(st.out(status, (size_t)n_arrays * 4, mem));
-    const size_t dyn = (((size_t)nt * 6 + 15) & ~(size_t)15);
+    if (status) VS_TRY(st.out(status, (size_t)n_arrays * 4, mem));
+    // (a | posR; the wave-level rounds use the first 128 bytes of posR as scratch whatever the array length)
+    const size_t dyn = std::max<size_t>((((size_t)nt * 6 + 15) & ~(size_t)15), (((size_t)nt * 4 + 128 + 15) & ~(size_t)15));
     const bool small_wg = nt <= kSmallWgTiles;
     const auto kernel = small_wg ? nt512::vs_k_select : nt1024::vs_k_select;
     VS_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     hipLaunchKernelGGL(kernel, dim3(n_arrays), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, a.as<uint16_t>(), nt,
-                       nsel, o.as<int32_t>(), st.as<int32_t>());
+                       nsel, o.as<int32_t>(), status ? st.as<int32_t>() : (int32_t*)nullptr, rule);
     VS_HIP(hipGetLastError());
     VS_TRY(o.finish(s));
-    VS_TRY(st.finish(s));
+    if (status) VS_TRY(st.finish(s));
     if (mem == VS_MEM_HOST) VS_HIP(hipStreamSynchronize(s));
     return nsel;
 }
