@@ -34,7 +34,7 @@ python3 tools/host_fed_bench.py > $O/host_fed_1080p.json 2>/dev/null
 python3 tools/host_fed_bench.py 4k > $O/host_fed_4k.json 2>/dev/null
 python3 tools/latency_stages.py > $O/latency_1080p.json 2>/dev/null
 python3 tools/latency_stages.py 4k > $O/latency_4k.json 2>/dev/null
-{ apps/bin/vs_latency; apps/bin/vs_latency 3840 2160 24; } > $O/latency_cpp.txt 2>&1
+{ apps/bin/vs_latency; apps/bin/vs_latency 3840 2160 24; apps/bin/vs_latency 1920 1080 48 256 24 2; apps/bin/vs_latency 3840 2160 24 256 24 2; } > $O/latency_cpp.txt 2>&1
 # keep the merged scratch small: the raw traces are tens of MB
 find $O -name "*kernel_trace.csv" -size +20M -delete
 ls $O
