@@ -138,3 +138,35 @@ def test_stable_selection_kernel_against_the_oracle(gpu_vs, oracle, ty, tx, hi, 
     for k in range(3):
         want = oracle.select_smallest_stable(wd[k], frac)
         assert np.array_equal(got[k], want), k
+
+
+def test_environment_default_selects_the_stable_rule(gpu_vs):
+    """VS_SELECT_MODE=2: handles created without a call to vs_aligner_set_select_mode (facade classes, harness programs) start in
+    VS_SELECT_STABLE; checked in a child process (the variable is read once) against this process's explicit mode"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from video_stabilizer_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    frames, _ = synth.make_clip(320, 240, 4, seed=79, channels=3)
+    want = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE).align_batch(frames)
+    other = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_DEVICE).align_batch(frames)
+    code = (
+        "import sys, json, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch, numpy as np\n"
+        "from video_stabilizer_amd import capi, synth\n"
+        "frames, _ = synth.make_clip(320, 240, 4, seed=79, channels=3)\n"
+        "a = capi.Aligner.__new__(capi.Aligner)\n"
+        "a.params = capi.aligner_params()\n"
+        "a.h = capi.lib().vs_aligner_create(C.byref(a.params), 0)\n"          # no set_select_mode: the environment decides
+        "st, ts = a.align_batch(frames)\n"
+        "print(json.dumps([list(map(int, st)), [t.tup() for t in ts]]))\n" % root)
+    env = dict(os.environ, VS_SELECT_MODE="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-1500:]
+    st, ts = json.loads(out.stdout.strip().splitlines()[-1])
+    assert st == [int(x) for x in want[0]]
+    assert [tuple(t) for t in ts] == [t.tup() for t in want[1]]
+    assert [tuple(t) for t in ts] != [t.tup() for t in other[1]]

@@ -1087,6 +1087,11 @@ vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
         }
     }
     if (params) a->params = *params; else vs_aligner_params_default(&a->params);
+    {   // VS_SELECT_MODE=0|1|2 (read once): the selection mode new handles start in -- for callers that cannot reach
+        // vs_aligner_set_select_mode (the facade classes, the harness programs); an explicit set_select_mode still wins
+        static const int env_mode = []() { const char* e = getenv("VS_SELECT_MODE"); return e ? atoi(e) : -1; }();
+        if (env_mode == VS_SELECT_STL_HOST || env_mode == VS_SELECT_DEVICE || env_mode == VS_SELECT_STABLE) a->select_mode = env_mode;
+    }
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error(VS_ERR_HIP, "hipStreamCreate failed");
         delete a;
