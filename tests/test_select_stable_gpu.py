@@ -170,3 +170,36 @@ def test_environment_default_selects_the_stable_rule(gpu_vs):
     assert st == [int(x) for x in want[0]]
     assert [tuple(t) for t in ts] == [t.tup() for t in want[1]]
     assert [tuple(t) for t in ts] != [t.tup() for t in other[1]]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_stable_rule_random_sizes_and_fractions(gpu_vs, oracle, seed):
+    """odd sizes, 3 ... 6 pyramid levels, smallest_fraction from 0.05 to 1.0 (every tile kept), gray and BGR: stable mode against
+    the oracle's rule 1, one frame at a time and as one batch"""
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(900 + seed)
+    w, h = int(rng.integers(90, 700)), int(rng.integers(70, 500))
+    ch = int(rng.choice([1, 3]))
+    frac = float(rng.choice([0.05, 0.33, 0.8, 0.97, 1.0]))
+    pmw = int(rng.choice([20, 40]))
+    frames, _ = synth.make_clip(w, h, 5, seed=1000 + seed, channels=ch)
+    kw = dict(smallest_fraction=frac, pyramid_min_width=pmw, pyramid_min_height=pmw)
+    lv, ww, hh = 0, w, h
+    while True:
+        lv += 1; ww //= 2; hh //= 2
+        if not (ww >= pmw and hh >= pmw):
+            break
+    if lv < 3:
+        pytest.skip("%dx%d gives %d levels" % (w, h, lv))
+    gpu = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **kw)
+    res = []
+    for f in frames:
+        ok_g, t_g = gpu.align_next(f)
+        ok_c, t_c = cpu.align_next(f)
+        res.append((ok_g, t_g, gpu.info(0), ok_c, t_c, cpu.debug()))
+    _check(res)
+    bat = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw)
+    sb, tb = bat.align_batch(frames)
+    assert [int(x) for x in sb] == [int(r[0]) for r in res]
+    assert [t.tup() for t in tb] == [r[1].tup() for r in res]
