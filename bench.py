@@ -100,7 +100,7 @@ def cpu_baseline(frames_host, params_kw, stabilizer, seconds_budget=20.0, record
 
     def run(count, k=None, done=None, rec=None):
         if stabilizer:
-            st = O.Stabilizer(warp_mode=O.WARP_LANCZOS2, **params_kw)
+            st = O.Stabilizer(select_rule=select_rule, warp_mode=O.WARP_LANCZOS2, **params_kw)
             for i in range(count):
                 st.process(frames_host[i])
                 if done is not None:
@@ -514,7 +514,9 @@ def main():
         all_frames = torch.empty((n_clips * n, H, W, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
         clips = [factory.make(n, seeds[j], out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
         torch.cuda.synchronize()
-        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2, **params_kw)   # the library default is the reference's bilinear
+        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2,             # the library default is the reference's bilinear
+                               select_mode={"device": capi.SELECT_DEVICE, "stable": capi.SELECT_STABLE, "host": capi.SELECT_STL_HOST}[args.select],
+                               **params_kw)
         out_buf = torch.empty((n_clips * n, H - 2 * crop, W - 2 * crop, 3), dtype=clips[0].dtype, device=dev)
         aw = None
 
