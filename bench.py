@@ -14,6 +14,10 @@ A "step" is one pass of the hot path over the rank's clips, which are already re
 value = ALIGNED frames per second, whole job (all ranks): frames for which AlignNextFrame returns true (the first frame of a
 clip has no predecessor: 239 of 240 count).  One process per GPU; clips are independent, so ranks share nothing but the
 barriers that bracket the timed region and one max/sum all-reduce for the report ("weak" scaling).
+The warp of the timed step is bgr_image_warp in its CONTRACTED form (VS_WARP_LANCZOS2_FAST: the multiply-adds fused as the
+reference's own target string allows -- CMakeLists.txt:151 carries `fma`, the tree has no strict_float), admitted as `value` by
+SURVEY 8(d)'s integer gate, which every run re-checks against the UN-contracted oracle (`parity.contracted_vs_exact`: max 1 LSB,
+>= 99.99 % of the samples identical; a broken gate fails the run).  The same step with the un-contracted sampler is `exact_warp`.
 
 The JSON line also carries
   roofline      the dominant kernel of the timed region (bgr_image_warp): algorithmic bytes / mean launch time, HIP
@@ -22,6 +26,10 @@ The JSON line also carries
                 region (exact and contracted arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
                 the kernel is VALU-issue-bound, the HBM fraction is what that leaves
   c3            (default run, one GPU) the 4K half of the metric: BASELINE configs[2] through the same step, a few steps
+  c5            (default run, one GPU) BASELINE configs[4]: 8 clips x 60 frames 4K 10-bit through the full stabilizer loop
+  drop_in       the reference's own call pattern (video_test.cpp:106, stabilizer.cpp:19): HOST frames, one vs_stabilizer_process /
+                one vs_aligner_align_next per frame, 1080p and 4K -- frames/s and ms per call, PCIe-inclusive, never `value` --
+                beside the oracle making the same calls
   c4_strong     (default run) BASELINE configs[3] as a strong-scaling leg: 64 clips in total, 64 / N per rank, per-rank seconds
   parity        the gate SURVEY 8(d) asks for with every benchmark: the GPU results for the first frames of the clip against
                 the CPU restatement that cpu_baseline runs anyway; a broken gate makes the run fail (exit code 3)
@@ -292,6 +300,55 @@ def host_fed(torch, capi, dev, frames_dev, W, H, fmt, params_kw, reps=3):
             "note": "alignment of a host-resident clip, PCIe-inclusive (never `value`); pipelined ingest, pageable host memory"}
 
 
+def drop_in(capi, dev_index, frames_host, params_kw, calls=48, cpu_budget_s=6.0):
+    """The reference's own call pattern: every frame arrives in (pageable) host memory and is handed to ONE
+    VideoStabilizer::processFrame (video_test.cpp:106) / ONE VideoAligner::AlignNextFrame (stabilizer.cpp:19) call, which
+    returns the result to host memory before the next frame is offered.  No batching, no frame look-ahead: upload, compute and
+    download of a frame are serial by the API's contract.  PCIe-inclusive, never `value`.  The oracle (CPU restatement, one
+    thread: the reference's per-call path has no frame-level parallelism either) makes the same calls on a bounded sample."""
+    from oracle import oracle as O
+    n = min(calls, frames_host.shape[0])
+    H, W = frames_host.shape[1:3]
+    res = {"frames": "%dx%d %s, host memory (pageable)" % (W, H, "u8" if frames_host.dtype.itemsize == 1 else "u16 (10-bit)"), "calls": n}
+
+    def timed(make, call, warm):
+        h = make()
+        for f in frames_host[:warm]:
+            call(h, f)
+        h.reset()                                      # a new clip on warm buffers: the timed calls allocate nothing
+        t0 = time.perf_counter()
+        got = sum(1 for f in frames_host[:n] if call(h, f))
+        dt = time.perf_counter() - t0
+        return {"frames_per_s": round(n / dt, 1), "ms_per_call": round(1e3 * dt / n, 4), "calls": n, "results": got}
+
+    res["align_next"] = timed(lambda: capi.Aligner(device=dev_index, **params_kw), lambda h, f: h.align_next(f)[0], 3)
+    res["align_next"]["what"] = "vs_aligner_align_next per frame (alignment.hpp:55-58); results = frames aligned"
+    # library defaults = the reference's processFrame: bilinear, black border, crop 32, lag 10 (stabilizer.hpp:13-30)
+    res["process_frame"] = timed(lambda: capi.Stabilizer(device=dev_index, **params_kw), lambda h, f: h.process(f) is not None, 14)
+    res["process_frame"]["what"] = "vs_stabilizer_process per frame, library defaults (bilinear like cv::warpAffine INTER_LINEAR, stabilizer.hpp:39); results = frames returned"
+    res["process_frame_lanczos2"] = timed(lambda: capi.Stabilizer(device=dev_index, warp_mode=capi.WARP_LANCZOS2_FAST, warp_border=capi.BORDER_CLAMP, **params_kw),
+                                          lambda h, f: h.process(f) is not None, 14)
+    res["process_frame_lanczos2"]["what"] = "the same with bgr_image_warp Lanczos2 (contracted), clamp border"
+
+    def cpu_timed(make, call, count):
+        h = make()
+        t0 = time.perf_counter()
+        k = 0
+        for f in frames_host[:count]:
+            call(h, f)
+            k += 1
+            if time.perf_counter() - t0 > cpu_budget_s and k >= 3:
+                break
+        dt = time.perf_counter() - t0
+        return {"frames_per_s": round(k / dt, 2), "ms_per_call": round(1e3 * dt / k, 2), "calls": k, "threads": 1}
+
+    res["cpu_align_next"] = cpu_timed(lambda: O.Aligner(**params_kw), lambda h, f: h.align_next(f), n)
+    res["cpu_process_frame"] = cpu_timed(lambda: O.Stabilizer(**params_kw), lambda h, f: h.process(f), n)
+    res["note"] = ("one call per frame, result on the host before the next call: the API's serial contract (H2D + every kernel + D2H in "
+                   "sequence); cpu_* = the oracle (kind `port`, parity unpinned) making the same calls on one thread, bounded to ~%g s each" % cpu_budget_s)
+    return res
+
+
 class AlignWarp:
     """The timed step for the align + warp workloads (c2 / c3 / c4): the rank's clips resident in HBM, one aligner handle, one
     output buffer.  The warp of pass k (caller's stream) overlaps the alignment of pass k+1 (the handle's stream)."""
@@ -356,6 +413,23 @@ def stage_table(t, steps):
             for k, v in t.items() if isinstance(v, dict) and v["launches"]}
 
 
+def contracted_vs_exact_gate(G, pairs):
+    """SURVEY 8(d) integer gate over (contracted GPU frame, un-contracted oracle frame) pairs: max |d| <= 1 LSB and the
+    fraction of identical samples >= 0.9999 on every frame"""
+    mx, least, ok = 0, 1.0, True
+    for got, want in pairs:
+        good, info = G.integer_gate(got, want)
+        ok = ok and good
+        mx = max(mx, info["max_abs_diff_lsb"])
+        least = min(least, info["identical_fraction"])
+    return {"pass": bool(ok), "max_abs_diff_lsb": mx, "least_identical_fraction": round(least, 7),
+            "gate": "max |d| <= 1 LSB and identical fraction >= %.4f per frame (SURVEY 8(d), integer modes)" % G.INTEGER_IDENTICAL_MIN,
+            "gpu": "VS_WARP_LANCZOS2_FAST (contracted)", "cpu": "VSO_WARP_LANCZOS2 (un-contracted: the reference's written order)",
+            "float_mode": "not part of `value` (integer outputs only): the formula of SURVEY 8(d) for float output is missed by every "
+                          "evaluation order, the reference's own included (tests/test_warp_gate_cpu.py records by how much); the contracted "
+                          "form is closer to the real-arithmetic value than the un-contracted one"}
+
+
 def parity_gate(torch, capi, aw, params_kw, oracle_rec, frames_host, warp_frames=(1, 2, 17, 40)):
     """"parity gates run with every benchmark".  The GPU side is the path the timed step runs (full batch, device
     selection, exact and contracted warps of the whole clip); the CPU side is what cpu_baseline's first thread computed on the
@@ -377,23 +451,28 @@ def parity_gate(torch, capi, aw, params_kw, oracle_rec, frames_host, warp_frames
            "transform_max_abs_diff": dmax, "transform_tolerance": 1e-4}
     ok = st_eq and reason_eq and it_eq and dmax <= 1e-4
     if aw.warped is not None:
+        from oracle import gate as G
         idx = [i for i in warp_frames if i < P]
         O.set_threads(min(16, usable_threads()[0]))
         try:
-            for name, gmode, omode in (("warp_pixels_equal", capi.WARP_LANCZOS2, O.WARP_LANCZOS2),
-                                       ("contracted_warp_pixels_equal", capi.WARP_LANCZOS2_FAST, O.WARP_LANCZOS2_CONTRACTED)):
+            want, got = {}, {}
+            for name, gmode, omode in (("exact", capi.WARP_LANCZOS2, O.WARP_LANCZOS2), ("contracted", capi.WARP_LANCZOS2_FAST, O.WARP_LANCZOS2_CONTRACTED)):
                 aw.warp(ts, gmode)
                 torch.cuda.synchronize()
-                same = True
                 for i in idx:
-                    got = aw.warped[i].cpu().numpy()
-                    if got.dtype == np.int16:
-                        got = got.view(np.uint16)
-                    want = O.bgr_image_warp(frames_host[i], O.Transform.of(ts[i].A, ts[i].B, ts[i].TX, ts[i].TY), omode,
-                                            O.BORDER_CLAMP, max_value=aw.max_value)
-                    same = same and bool(np.array_equal(got, want))
-                res[name] = same
-                ok = ok and same
+                    g = aw.warped[i].cpu().numpy()
+                    got[name, i] = g.view(np.uint16) if g.dtype == np.int16 else g
+                    want[name, i] = O.bgr_image_warp(frames_host[i], O.Transform.of(ts[i].A, ts[i].B, ts[i].TX, ts[i].TY), omode,
+                                                     O.BORDER_CLAMP, max_value=aw.max_value)
+            # each GPU mode against its own CPU twin: bit for bit
+            res["warp_pixels_equal"] = all(bool(np.array_equal(got["exact", i], want["exact", i])) for i in idx)
+            res["contracted_warp_pixels_equal"] = all(bool(np.array_equal(got["contracted", i], want["contracted", i])) for i in idx)
+            ok = ok and res["warp_pixels_equal"] and res["contracted_warp_pixels_equal"]
+            # SURVEY 8(d), integer modes: the GPU's CONTRACTED output against the UN-contracted oracle (the reference's written order)
+            cve = contracted_vs_exact_gate(G, [(got["contracted", i], want["exact", i]) for i in idx])
+            cve["frames"] = ["%dx%d frame %d" % (aw.W, aw.H, i) for i in idx]
+            res["contracted_vs_exact"] = cve
+            ok = ok and cve["pass"]
         finally:
             O.set_threads(1)
         res["warp_frames_checked"] = idx
@@ -421,15 +500,19 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="override LOCAL_RANK -> device (rehearsal on a 1-GPU box)")
     ap.add_argument("--default-levels", action="store_true",
                     help="reference default pyramid_min_width/height = 20 (6 levels at 1080p, 7 at 4K) instead of 256")
-    ap.add_argument("--warp-mode", default="exact", choices=["exact", "fast"],
-                    help="exact = VS_WARP_LANCZOS2 (the reference's un-contracted fp32 order; the default and `value`); "
-                         "fast = VS_WARP_LANCZOS2_FAST (the contracted form; bit-identical to the oracle's contracted twin)")
+    ap.add_argument("--warp-mode", default="contracted", choices=["contracted", "exact", "fast"],
+                    help="contracted (= fast) = VS_WARP_LANCZOS2_FAST, the sampler with the multiply-adds fused (the default and `value`: "
+                         "within SURVEY 8(d)'s integer gate of the un-contracted order, re-checked in every run; bit-identical to the "
+                         "oracle's contracted twin); exact = VS_WARP_LANCZOS2, the reference's un-contracted fp32 order")
     ap.add_argument("--phase-correlate", action="store_true", help="aligner with phase_correlate = true (off in the reference's defaults)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (checks the RCCL path)")
     ap.add_argument("--no-roofline-4k", action="store_true", help="skip the isolated 32 x 4K bgr_image_warp measurement")
     ap.add_argument("--exclusive-solver", action="store_true", help="keep the solver kernel in VS_BATCH_EXCLUSIVE mode inside the overlapped step")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-resident (PCIe-inclusive) alignment measurement")
     ap.add_argument("--no-c3", action="store_true", help="skip the 4K (configs[2]) leg of the default one-GPU run")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 4K 10-bit full-stabilizer (configs[4]) leg of the default one-GPU run")
+    ap.add_argument("--c5-clips", type=int, default=8)
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the per-frame host-call (drop-in pattern) legs")
     ap.add_argument("--c4-strong", action="store_true", help="run the 64-clip strong-scaling leg (configs[3]) on one GPU even if free memory looks short")
     ap.add_argument("--no-c4-strong", action="store_true", help="skip the strong-scaling leg")
     ap.add_argument("--c4-clips", type=int, default=64, help="total clips of the strong-scaling leg (rehearsals use fewer)")
@@ -438,6 +521,8 @@ def main():
     default_run = args.workload is None
     if default_run:
         args.workload = "c2"
+    if args.warp_mode == "fast":
+        args.warp_mode = "contracted"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: be the launcher.  Nothing above has imported torch or made a HIP call.
@@ -499,14 +584,16 @@ def main():
             traffic = int(tj[key]["traffic_bytes"] / per * nframes_total)
         except Exception:
             pass
-        return {"kernel": "vs_k_bgr_warp_c3<lanczos2,clamp> (bgr_image_warp)", "bound": "hbm", "binding": "valu",
+        contracted_mode = args.warp_mode != "exact"
+        return {"kernel": "vs_k_bgr_warp_c3<%s,clamp> (bgr_image_warp)" % ("lanczos2 contracted" if contracted_mode else "lanczos2"),
+                "bound": "hbm", "binding": "valu",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": "scaled from the committed PMC passes (profiles/%s), not measured in this run" % tname,
                 "launch_ms": round(ms, 4), "bytes_per_launch": bytes_per_launch,
-                "note": "VALU-issue-bound, not HBM-bound: the reference's un-contracted fp32 order needs 248 separately rounded "
-                        "operations per output pixel, <= 0.24 of the HBM peak at perfect VALU issue (DESIGN.md section 5); launches "
-                        "overlap the next pass's aligner kernels"}
+                "note": "VALU-issue-bound, not HBM-bound: the sampler needs %s per output pixel, <= %s of the HBM peak at perfect VALU "
+                        "issue (DESIGN.md section 5); launches overlap the next pass's aligner kernels"
+                        % (("152 fused operations", "0.39") if contracted_mode else ("248 separately rounded operations", "0.24"))}
 
     if wl["stabilizer"]:
         crop = 32
@@ -514,7 +601,8 @@ def main():
         all_frames = torch.empty((n_clips * n, H, W, 3), dtype=torch.uint8 if bits == 8 else torch.int16, device=dev)
         clips = [factory.make(n, seeds[j], out=all_frames[j * n:(j + 1) * n])[0] for j in range(n_clips)]
         torch.cuda.synchronize()
-        stab = capi.Stabilizer(device=local_rank, warp_mode=capi.WARP_LANCZOS2,             # the library default is the reference's bilinear
+        stab = capi.Stabilizer(device=local_rank,                                           # the library default is the reference's bilinear
+                               warp_mode=capi.WARP_LANCZOS2 if args.warp_mode == "exact" else capi.WARP_LANCZOS2_FAST,
                                select_mode={"device": capi.SELECT_DEVICE, "stable": capi.SELECT_STABLE, "host": capi.SELECT_STL_HOST}[args.select],
                                **params_kw)
         out_buf = torch.empty((n_clips * n, H - 2 * crop, W - 2 * crop, 3), dtype=clips[0].dtype, device=dev)
@@ -552,17 +640,18 @@ def main():
         align_only = (dt_a, frames_a, aw.aligner.timings())
         aw.shared(True)
 
-    contracted = None
-    if aw and not args.no_warp and args.warp_mode == "exact":
-        # third figure: the same step with the contracted form of the sampler (VS_WARP_LANCZOS2_FAST: the arithmetic the
-        # reference's own FMA target may run, bit-identical to the oracle's contracted twin) -- beside `value`, never as `value`
-        aw.step(False, capi.WARP_LANCZOS2_FAST)
-        dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_LANCZOS2_FAST), args.steps)
+    other_mode = capi.WARP_LANCZOS2_FAST if args.warp_mode == "exact" else capi.WARP_LANCZOS2
+    other = None
+    if aw and not args.no_warp:
+        # second figure: the same step with the OTHER form of the sampler -- `exact_warp` (VS_WARP_LANCZOS2: the reference's written,
+        # un-contracted rounding order) beside a contracted `value`, or `contracted_warp` beside --warp-mode exact
+        aw.step(False, other_mode)
+        dt_f, good_f = timed_loop(lambda: aw.step(False, other_mode), args.steps)
         dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
-        contracted = (dt_f, good_f)
+        other = (dt_f, good_f)
 
     stable = None
-    if aw and not args.no_warp and args.warp_mode == "exact" and args.select == "device":
+    if aw and not args.no_warp and args.select == "device":
         # fourth figure: the same step with the selection under the documented STL-independent rule (VS_SELECT_STABLE, SURVEY 8(f)
         # rank 1; bit-identical to the oracle's select rule 1: tests/test_select_stable_gpu.py) -- beside `value`, never as `value`
         aw.aligner.set_select_mode(capi.SELECT_STABLE)
@@ -594,7 +683,10 @@ def main():
                        else "shared (VS_BATCH_SHARED: 256-thread small-footprint build under the previous pass's warp, bit-identical)",
                        "phase_correlate": bool(args.phase_correlate),
                        "warp": None if (args.no_warp and not wl["stabilizer"]) else
-                       ("bgr_image_warp lanczos2" if args.warp_mode == "exact" else "bgr_image_warp lanczos2, contracted form (VS_WARP_LANCZOS2_FAST)"), "resident": "HBM"},
+                       ("bgr_image_warp lanczos2, un-contracted (VS_WARP_LANCZOS2)" if args.warp_mode == "exact" else
+                        "bgr_image_warp lanczos2, contracted form (VS_WARP_LANCZOS2_FAST): <= 1 LSB from the un-contracted order, >= 99.99 % identical "
+                        "(SURVEY 8(d) integer gate, checked in this run: parity.contracted_vs_exact)"), "resident": "HBM",
+                       "select_mode_in_force": (aw.aligner.select_mode() if aw else stab.select_mode())},
             "frames_per_step": total_frames // args.steps,
             ("outputs_per_step" if wl["stabilizer"] else "aligned_per_step"): total_good // args.steps,
             "value_counts": ("stabilized output frames + the lag frames that produce none" if wl["stabilizer"] else
@@ -611,12 +703,16 @@ def main():
                                  "ms_per_step": round(1e3 * dt_a / args.steps, 4), "stages": stage_table(tm_a, args.steps),
                                  "note": "same clips, alignment stages only, all frames counted (no warp launch competing for the CUs; "
                                          "solver kernel in VS_BATCH_EXCLUSIVE mode)"}
-        if contracted:
-            out["contracted_warp"] = {"value": round(contracted[1] / contracted[0], 2), "unit": "frames/s",
-                                      "ms_per_step": round(1e3 * contracted[0] / args.steps, 4),
-                                      "note": "same step with bgr_image_warp in VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as "
-                                              "the reference's own target allows (CMakeLists.txt:151 fma, no strict_float); np.array_equal with the "
-                                              "oracle's VSO_WARP_LANCZOS2_CONTRACTED (tests/test_warp_fast_gpu.py, `parity` below)"}
+        if other:
+            if args.warp_mode == "exact":
+                key, what = "contracted_warp", ("VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as the reference's own target "
+                                                "allows (CMakeLists.txt:151 fma, no strict_float)")
+            else:
+                key, what = "exact_warp", ("VS_WARP_LANCZOS2 = the reference's written fp32 order with no contraction (np.array_equal with the "
+                                           "oracle's VSO_WARP_LANCZOS2); `value` runs the contracted form, which SURVEY 8(d)'s integer gate admits "
+                                           "(`parity.contracted_vs_exact`)")
+            out[key] = {"value": round(other[1] / other[0], 2), "unit": "frames/s", "ms_per_step": round(1e3 * other[0] / args.steps, 4),
+                        "note": "same step with bgr_image_warp in " + what}
         if stable:
             out["stable_select"] = {"value": round(stable[1] / stable[0], 2), "unit": "frames/s", "ms_per_step": round(1e3 * stable[0] / args.steps, 4),
                                     "note": "same step with VS_SELECT_STABLE: the keep-best-80 % step under a documented STL-independent rule (smallest "
@@ -646,6 +742,12 @@ def main():
         out["roofline_4k"] = roofline_4k(torch, capi, dev, stream)
     if rank == 0 and not args.no_host_fed and aw is not None:
         out["host_fed"] = host_fed(torch, capi, dev, clips[0], W, H, fmt, params_kw)
+    if rank == 0 and world == 1 and not args.no_drop_in and aw is not None:
+        try:
+            fh = clips[0][: min(n, 48)].cpu().numpy()
+            out["drop_in"] = {"%dp" % H: drop_in(capi, dev.index, fh.view("uint16") if bits != 8 else fh, params_kw)}
+        except Exception as e:
+            out["drop_in"] = {"error": repr(e)}
 
     # ---- the 4K half of the metric (default one-GPU run): BASELINE configs[2] through the same step --------------------------
     if default_run and world == 1 and not args.no_c3 and aw is not None:
@@ -661,17 +763,90 @@ def main():
             a3.aligner.enable_timing(True)
             dt3, good3 = timed_loop(lambda: a3.step(True), steps3)
             tm3 = a3.aligner.timings()
-            a3.step(False, capi.WARP_LANCZOS2_FAST)
-            dt3f, good3f = timed_loop(lambda: a3.step(False, capi.WARP_LANCZOS2_FAST), steps3)
+            a3.step(False, other_mode)
+            dt3f, good3f = timed_loop(lambda: a3.step(False, other_mode), steps3)
             out["c3"] = {"workload": wl3["name"], "value": round(good3 * steps3 / dt3, 2), "unit": "frames/s",
                          "ms_per_step": round(1e3 * dt3 / steps3, 4), "steps": steps3, "frames_per_step": n3, "aligned_per_step": int(good3),
                          "stages": stage_table(tm3, steps3), "gn_iterations_per_frame": round(tm3["gn_iterations"] / max(1, tm3["frames"]), 2),
                          "roofline": roofline_of(a3, n3),
-                         "contracted_warp": {"value": round(good3f * steps3 / dt3f, 2), "ms_per_step": round(1e3 * dt3f / steps3, 4)},
+                         ("contracted_warp" if args.warp_mode == "exact" else "exact_warp"):
+                             {"value": round(good3f * steps3 / dt3f, 2), "ms_per_step": round(1e3 * dt3f / steps3, 4)},
                          "note": "solver in VS_BATCH_SHARED mode; the 4K level 0 (20736 tiles per set) selects on the pair's global scratch"}
+            if not args.no_cpu_baseline:
+                # the 4K frame of the pixel gate: the GPU's contracted warp of frame 1 (its measured transform) against the
+                # un-contracted oracle
+                import numpy as np
+                from oracle import oracle as O, gate as G
+                st3, ts3 = a3.align()
+                a3.warp(ts3, capi.WARP_LANCZOS2_FAST)
+                torch.cuda.synchronize()
+                O.set_threads(min(16, usable_threads()[0]))
+                try:
+                    want3 = O.bgr_image_warp(a3.frames[1].cpu().numpy(), O.Transform.of(ts3[1].A, ts3[1].B, ts3[1].TX, ts3[1].TY), O.WARP_LANCZOS2,
+                                             O.BORDER_CLAMP, max_value=255)
+                finally:
+                    O.set_threads(1)
+                g3 = contracted_vs_exact_gate(G, [(a3.warped[1].cpu().numpy(), want3)])
+                out["c3"]["contracted_vs_exact"] = {k: g3[k] for k in ("pass", "max_abs_diff_lsb", "least_identical_fraction")}
+                if "parity" in out and "contracted_vs_exact" in out["parity"]:
+                    cv = out["parity"]["contracted_vs_exact"]
+                    cv["frames"].append("3840x2160 frame 1")
+                    cv["pass"] = bool(cv["pass"] and g3["pass"])
+                    cv["max_abs_diff_lsb"] = max(cv["max_abs_diff_lsb"], g3["max_abs_diff_lsb"])
+                    cv["least_identical_fraction"] = min(cv["least_identical_fraction"], g3["least_identical_fraction"])
+                    out["parity"]["pass"] = bool(out["parity"]["pass"] and g3["pass"])
+                if not g3["pass"]:
+                    rc = 3
+            if not args.no_drop_in and isinstance(out.get("drop_in"), dict) and "error" not in out["drop_in"]:
+                out["drop_in"]["2160p"] = drop_in(capi, dev.index, a3.frames[:32].cpu().numpy(), params_kw, calls=32)
             a3.free()
         except Exception as e:
             out["c3"] = {"error": repr(e)}
+
+    # ---- BASELINE configs[4] (default one-GPU run): 4K 10-bit clips through the full stabilizer loop ----------------------------
+    if default_run and world == 1 and not args.no_c5:
+        if aw is not None:
+            aw.free()
+            aw = None
+            clips = None
+        try:
+            wl5 = WORKLOADS["c5"]
+            W5, H5, n5, nc5, crop5, steps5 = wl5["w"], wl5["h"], wl5["frames"], args.c5_clips, 32, 3
+            need5 = 2.2 * nc5 * n5 * W5 * H5 * 3 * 2
+            if torch.cuda.mem_get_info(dev)[0] < need5:
+                raise RuntimeError("not enough free device memory for %d clips (%.0f GB needed)" % (nc5, need5 / 1e9))
+            f5 = synth.TorchClipFactory(W5, H5, wl5["seed"], dev, channels=3, bits=10)
+            frames5 = torch.empty((nc5 * n5, H5, W5, 3), dtype=torch.int16, device=dev)
+            for j in range(nc5):
+                f5.make(n5, wl5["seed"] + 1000 * j, out=frames5[j * n5:(j + 1) * n5])
+            del f5
+            out5 = torch.empty((nc5 * n5, H5 - 2 * crop5, W5 - 2 * crop5, 3), dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
+            res5 = {}
+            for key, mode in (("contracted", capi.WARP_LANCZOS2_FAST), ("exact", capi.WARP_LANCZOS2)):
+                st5 = capi.Stabilizer(device=local_rank, warp_mode=mode, **params_kw)
+
+                def step5():
+                    return st5.process_clips_device(frames5.data_ptr(), nc5, n5, W5, H5, capi.FMT_BGR10, out5.data_ptr())[0]
+                step5()
+                dt5, outs5 = timed_loop(step5, steps5)
+                res5[key] = (dt5, int(outs5))
+                del st5
+            main5, other5 = ("exact", "contracted") if args.warp_mode == "exact" else ("contracted", "exact")
+            dt5, outs5 = res5[main5]
+            out["c5"] = {"workload": wl5["name"], "clips": nc5, "frames_per_clip": n5, "value": round(nc5 * n5 * steps5 / dt5, 2), "unit": "frames/s",
+                         "ms_per_step": round(1e3 * dt5 / steps5, 4), "steps": steps5, "frames_per_step": nc5 * n5, "outputs_per_step": outs5,
+                         "dtype": "u16", "warp": "bgr_image_warp lanczos2 %s, crop %d, clamp border" % (main5, crop5),
+                         ("exact_warp" if other5 == "exact" else "contracted_warp"):
+                             {"value": round(nc5 * n5 * steps5 / res5[other5][0], 2), "ms_per_step": round(1e3 * res5[other5][0] / steps5, 4)},
+                         "value_counts": "input frames per second through vs_stabilizer_process_clips (every clip: 10 lag frames without an output)",
+                         "note": "BASELINE configs[4] on one GPU: %d of its 64 clips (64 / 8 GPUs); frames and outputs resident in HBM; the 10-bit gate "
+                                 "of the contracted form: tests/test_warp_gate_gpu.py" % nc5}
+            del frames5, out5
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["c5"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
     # ---- BASELINE configs[3] as a strong-scaling leg: 64 clips in total, clip i -> rank i mod N --------------------------------
     # (on one GPU the leg is the N = 1 point of the strong curve: 64 clips = 48 GB of frames + 48 GB of output; it runs when the

@@ -99,6 +99,13 @@ typedef struct vs_stabilizer_params {
 
 const char* vs_last_error(void);
 const char* vs_version(void);
+/* ABI number of the structs and enums in this header.  It changes whenever a struct grows or an enum value moves (4: vs_align_info
+ * carries selected_x / selected_y / level_transform, VS_FMT_BGR16 = 5).  The engine writes sizeof(vs_align_info) bytes per frame
+ * into caller arrays, so a caller built against another header must not go on: check vs_abi_version() == VS_ABI_VERSION once
+ * after loading the library (the facade classes do, and throw).  vs_sizeof_align_info() is the size the LIBRARY was built with. */
+#define VS_ABI_VERSION 4
+int    vs_abi_version(void);
+size_t vs_sizeof_align_info(void);
 /* number of usable HIP devices (0 when there is none; never fails) */
 int vs_device_count(void);
 
@@ -218,6 +225,13 @@ int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int cha
 int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8,
                    uint8_t* dst, int dst_stride, int mem, void* stream);
 
+/* Test hook, not part of the reference's surface: fault injection for the library's own device / pinned-host allocations.
+ * vs_test_fail_alloc(k), k > 0: the k-th allocation the library makes from now on (any handle, any thread) fails once with
+ * out-of-memory, and the call it belongs to returns VS_ERR_HIP; k = 0 disarms.  Returns the number of allocations made since the
+ * previous call of this function.  The environment variable VS_TEST_FAIL_ALLOC=k arms it at load time for programs that cannot
+ * call it.  tests/test_alloc_failure_gpu.py walks k over every allocation of the engine-level calls. */
+int vs_test_fail_alloc(int k);
+
 /* Profiling aid, not part of the reference's surface: device-to-device copy of floor(bytes/12)*12 bytes
  * with 12-byte accesses per lane, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for the warp
  * kernel's access width (tools/calibrate_counters.py). */
@@ -245,7 +259,15 @@ typedef struct vs_align_info {
 
 vs_aligner* vs_aligner_create(const vs_aligner_params* params /* NULL = defaults */, int device);
 void vs_aligner_destroy(vs_aligner* a);
+/* Error protocol of the engine-level calls: a call that returns < 0 (a refused allocation: VS_ERR_HIP, an unsupported size, ...)
+ * leaves the handle consistent and usable -- no buffer is lost or freed twice -- and ENDS the running sequence: the next frame
+ * is the first frame of a new sequence, exactly what a fresh handle would make of it.  (The reference: a failed kernel call
+ * returns false and sets LastWidth = -1, so the next AlignNextFrame re-initialises, alignment.cpp:357-367.) */
+/* New handles start in VS_SELECT_DEVICE, or in the mode the environment variable VS_SELECT_MODE=0|1|2 names (read once per
+ * process, reported once on stderr when it takes effect: the modes differ in the last bits of the transforms); set_select_mode
+ * overrides either.  vs_aligner_get_select_mode returns the mode in force (or VS_ERR_ARG). */
 int  vs_aligner_set_select_mode(vs_aligner* a, int select_mode);
+int  vs_aligner_get_select_mode(const vs_aligner* a);
 /* Which build of the per-pair solver kernel a batch (>= 32 frame pairs, levels of <= 26000 tiles) runs through.  The
  * results are bit-identical either way.
  *   VS_BATCH_EXCLUSIVE (default)  one 512-thread workgroup per pair, a whole CU each: fastest when nothing else is running.
@@ -345,6 +367,7 @@ void* vs_stabilizer_stream(const vs_stabilizer* s);
 int   vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream);
 /* the selection rule of the stabilizer's aligner (VS_SELECT_*, see vs_aligner_set_select_mode); takes effect with the next frame */
 int   vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode);
+int   vs_stabilizer_get_select_mode(const vs_stabilizer* s);
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success);
 
 #ifdef __cplusplus

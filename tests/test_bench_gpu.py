@@ -19,7 +19,7 @@ def _last_json(out):
 
 def test_bench_line_contract(gpu_vs):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--steps", "2", "--warmup", "1",
-                          "--c4-clips", "3", "--c4-frames", "6"], capture_output=True, text=True, timeout=600)
+                          "--c4-clips", "3", "--c4-frames", "6", "--c5-clips", "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _last_json(out.stdout)
     assert KEYS <= set(j)
@@ -47,11 +47,28 @@ def test_bench_line_contract(gpu_vs):
         assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
         assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
     assert j["roofline_4k"]["contracted"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
-    assert j["contracted_warp"]["value"] > 0 and j["stable_select"]["value"] > 0
+    # `value` runs the contracted sampler; the un-contracted figure rides beside it, and the gate that admits the former is in the line
+    assert "contracted" in j["config"]["warp"] and "contracted" in r["kernel"] and j["config"]["select_mode_in_force"] == 1
+    assert j["exact_warp"]["value"] > 0 and "contracted_warp" not in j and j["stable_select"]["value"] > 0
+    g = p["contracted_vs_exact"]
+    assert g["pass"] is True and g["max_abs_diff_lsb"] <= 1 and g["least_identical_fraction"] >= 0.9999
+    assert any("3840x2160" in f for f in g["frames"]) and sum("1920x1080" in f for f in g["frames"]) >= 2
     # the 4K half of the metric (BASELINE configs[2]) in the same line
     c3 = j["c3"]
     assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
     assert c3["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120 and "gn" in c3["stages"]
+    assert c3["exact_warp"]["value"] > 0 and c3["contracted_vs_exact"]["pass"] is True
+    # BASELINE configs[4]: 4K 10-bit, full stabilizer loop (2 of the 8 clips per GPU here)
+    c5 = j["c5"]
+    assert "error" not in c5 and c5["value"] > 0 and c5["dtype"] == "u16" and c5["frames_per_step"] == 2 * 60
+    assert c5["outputs_per_step"] == 2 * 50 and c5["exact_warp"]["value"] > 0
+    # the reference's per-frame call pattern on host frames, beside the oracle making the same calls
+    for res in ("1080p", "2160p"):
+        d = j["drop_in"][res]
+        for leg in ("align_next", "process_frame", "process_frame_lanczos2", "cpu_align_next", "cpu_process_frame"):
+            assert d[leg]["frames_per_s"] > 0 and d[leg]["ms_per_call"] > 0, (res, leg)
+        assert d["align_next"]["results"] == d["align_next"]["calls"] - 1
+    assert j["drop_in"]["2160p"]["process_frame"]["results"] == 32 - 10
     # ... and the N = 1 point of the strong-scaling leg (BASELINE configs[3]; 3 clips of 6 frames here)
     s4 = j["c4_strong"]
     assert s4["scaling"] == "strong" and s4["clips_per_rank"] == [3] and s4["value"] > 0 and len(s4["per_rank_seconds"]) == 1

@@ -22,6 +22,7 @@ WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE, SELECT_STABLE = 0, 1, 2
 BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1
+ABI_VERSION = 4                                     # VS_ABI_VERSION of include/vs_amd.h
 
 
 class Transform(C.Structure):
@@ -80,6 +81,9 @@ _IP = C.POINTER(C.c_int)
 SIGNATURES = {
     "vs_last_error": (C.c_char_p, []),
     "vs_version": (C.c_char_p, []),
+    "vs_abi_version": (_i32, []),
+    "vs_sizeof_align_info": (_sz, []),
+    "vs_test_fail_alloc": (_i32, [_i32]),
     "vs_device_count": (_i32, []),
     "vs_stream_retire": (_i32, [_vp]),
     "vs_format_bits": (_i32, [_i32]),
@@ -125,6 +129,8 @@ SIGNATURES = {
     "vs_aligner_destroy": (None, [_vp]),
     "vs_aligner_set_select_mode": (_i32, [_vp, _i32]),
     "vs_stabilizer_set_select_mode": (_i32, [_vp, _i32]),
+    "vs_aligner_get_select_mode": (_i32, [_vp]),
+    "vs_stabilizer_get_select_mode": (_i32, [_vp]),
     "vs_aligner_set_batch_mode": (_i32, [_vp, _i32]),
     "vs_aligner_reset": (_i32, [_vp]),
     "vs_aligner_align_next": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(AlignerParams), _TP]),
@@ -161,6 +167,9 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    if L.vs_abi_version() != ABI_VERSION or L.vs_sizeof_align_info() != C.sizeof(AlignInfo):
+        raise VsError("libvs_amd.so has ABI %d (vs_align_info %d bytes); this binding was written for ABI %d (%d bytes)"
+                      % (L.vs_abi_version(), L.vs_sizeof_align_info(), ABI_VERSION, C.sizeof(AlignInfo)))
     _lib = L
     return L
 
@@ -183,6 +192,11 @@ def _c(a, dtype):
 
 def device_count():
     return lib().vs_device_count()
+
+
+def test_fail_alloc(k):
+    """fault injection: the k-th allocation of the library from now on fails once (0 disarms); returns the allocations seen since the last call"""
+    return lib().vs_test_fail_alloc(int(k))
 
 
 def aligner_params(**kw):
@@ -504,6 +518,10 @@ class Aligner:
         STL-independent rule: smallest by (abs_delta, tile index), survivors in tile order) or SELECT_STL_HOST"""
         _check(lib().vs_aligner_set_select_mode(self.h, mode))
 
+    def select_mode(self):
+        """the selection mode in force (the VS_SELECT_MODE environment override included)"""
+        return _check(lib().vs_aligner_get_select_mode(self.h))
+
     def set_batch_mode(self, mode):
         """BATCH_SHARED: full batches run through the small-footprint solver kernel (same bits; for callers that overlap
         other GPU work, e.g. the previous clip's warp)"""
@@ -631,6 +649,9 @@ class Stabilizer:
     def set_select_mode(self, mode):
         """the selection rule of the stabilizer's aligner (SELECT_DEVICE by default, SELECT_STABLE, SELECT_STL_HOST)"""
         _check(lib().vs_stabilizer_set_select_mode(self.h, mode))
+
+    def select_mode(self):
+        return _check(lib().vs_stabilizer_get_select_mode(self.h))
 
     def process(self, frame, fmt=None):
         frame = np.ascontiguousarray(frame)

@@ -6,6 +6,8 @@
 #include "vs_kernels.hpp"
 #include "vs_phase.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -23,6 +25,31 @@ bool device_ready() {
         return false;
     }
     return true;
+}
+
+// ---- allocation + fault injection (tests/test_alloc_failure_gpu.py) -----------------------------------------------
+// g_alloc_count counts the library's allocations since the last vs_test_fail_alloc call; the one that brings it to
+// g_alloc_fail_at fails with hipErrorOutOfMemory (once: the count moves on).  VS_TEST_FAIL_ALLOC=k arms it from the
+// environment for programs that cannot call the hook.
+std::atomic<long long> g_alloc_count{0};
+std::atomic<long long> g_alloc_fail_at{[]() { const char* e = getenv("VS_TEST_FAIL_ALLOC"); return e ? atoll(e) : 0LL; }()};
+static bool alloc_injected_failure() {
+    const long long k = ++g_alloc_count;
+    return k == g_alloc_fail_at.load(std::memory_order_relaxed);
+}
+hipError_t dev_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (alloc_injected_failure()) return hipErrorOutOfMemory;
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); }      // (the sticky error belongs to this call, which reports it)
+    return e;
+}
+hipError_t pinned_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (alloc_injected_failure()) return hipErrorOutOfMemory;
+    const hipError_t e = hipHostMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); }
+    return e;
 }
 
 int Staged::in(const void* ptr, size_t n, int mem, hipStream_t s) {
@@ -99,8 +126,8 @@ struct ParamRing {
     int upload(const float* src, size_t n, hipStream_t s, float4** out) {
         std::lock_guard<std::mutex> g(mu);
         if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
-        if (!host) VS_HIP(hipHostMalloc((void**)&host, kSlots * sizeof(float4)));
-        if (!dev) VS_HIP(hipMalloc((void**)&dev, kSlots * sizeof(float4)));
+        if (!host) VS_HIP(vsi::pinned_alloc((void**)&host, kSlots * sizeof(float4)));
+        if (!dev) VS_HIP(vsi::dev_alloc((void**)&dev, kSlots * sizeof(float4)));
         if (head + n > kSlots) head = 0;
         const size_t b = head, e = head + n;
         // wait for (and retire) every in-flight span that overlaps [b, e)
@@ -131,12 +158,18 @@ struct ParamRing {
     }
     // every span whose event was recorded on `s` is waited for and retired NOW, while the stream still exists: this runtime's
     // hipEventSynchronize looks at the stream an event was last recorded on, so an event must never outlive that stream in here
-    void forget_stream(hipStream_t s) {
+    hipError_t forget_stream(hipStream_t s) {
         std::lock_guard<std::mutex> g(mu);
+        hipError_t first = hipSuccess;
         for (auto it = busy.begin(); it != busy.end();) {
-            if (it->stream == s) { (void)hipEventSynchronize(it->ev); pool.push_back(it->ev); it = busy.erase(it); }
+            if (it->stream == s) {
+                const hipError_t e = hipEventSynchronize(it->ev);
+                if (e != hipSuccess && first == hipSuccess) first = e;
+                pool.push_back(it->ev); it = busy.erase(it);
+            }
             else ++it;
         }
+        return first;
     }
 };
 // A thread takes a ring per device on first use and hands it back to a process-wide pool when it exits; the next thread that
@@ -174,14 +207,19 @@ ParamRing* param_ring() {
 
 // A stream is about to be destroyed (a handle's own stream: ~vs_aligner; a caller's stream: vs_stream_retire): nothing in the
 // library may refer to it afterwards.
-void vsi::retire_stream(hipStream_t s) {
+hipError_t vsi::retire_stream(hipStream_t s) {
     std::vector<ParamRing*> rings;
     {
         RingPool& p = ring_pool();
         std::lock_guard<std::mutex> g(p.mu);
         rings = p.all;
     }
-    for (ParamRing* r : rings) r->forget_stream(s);
+    hipError_t first = hipSuccess;
+    for (ParamRing* r : rings) {
+        const hipError_t e = r->forget_stream(s);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    return first;
 }
 
 static inline size_t img_span(int w, int h, int stride, int channels) {
@@ -195,8 +233,14 @@ static inline int finish_host(int mem, hipStream_t s) {
 extern "C" {
 
 int vs_stream_retire(void* stream) {
-    vsi::retire_stream((hipStream_t)stream);
+    VS_HIP(vsi::retire_stream((hipStream_t)stream));      // a fault of the work that was in flight on the stream surfaces here
     return VS_OK;
+}
+
+int vs_test_fail_alloc(int k) {
+    const long long seen = vsi::g_alloc_count.exchange(0);
+    vsi::g_alloc_fail_at.store(k > 0 ? k : 0);
+    return (int)std::min<long long>(seen, 0x7fffffff);
 }
 
 int vs_device_count(void) {

@@ -409,7 +409,7 @@ struct vs_aligner {
         release();
         for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (stream) { vsi::retire_stream(stream); (void)hipStreamDestroy(stream); }   // (the stabilizer warps on this stream)
+        if (stream) { (void)vsi::retire_stream(stream); (void)hipStreamDestroy(stream); }   // (the stabilizer warps on this stream)
     }
     void release();
     int configure(int w, int h, int format, const vs_aligner_params& p);
@@ -458,19 +458,21 @@ int vs_aligner::ensure_phase() {
     const LevelDims& pl = L[2];
     if (phase.w != pl.w || phase.h != pl.h) {
         release_phase();
-        if (phase.configure(pl.w, pl.h, stream) != hipSuccess)
+        const hipError_t pe = phase.configure(pl.w, pl.h, stream);
+        if (pe == hipErrorInvalidValue)
             return set_error(VS_ERR_UNSUPPORTED, "phase_correlate: level 2 is %dx%d, padded extent over %d", pl.w, pl.h, vsp::kMaxLine);
+        VS_HIP(pe);                                     // (a refused allocation or a failed upload is a HIP error, not a size problem)
     }
     if (phase_cap >= cap) return VS_OK;
     void* d[] = {pspec, pG, psurf, ppairs, pneg, pres};
     for (void* p : d) if (p) (void)hipFree(p);
     pspec = nullptr; pG = nullptr; psurf = nullptr; ppairs = nullptr; pneg = nullptr; pres = nullptr; phase_cap = 0;
-    VS_HIP(hipMalloc((void**)&pspec, ((size_t)cap + 1) * phase.spec_frame() * sizeof(float2)));
-    VS_HIP(hipMalloc((void**)&pG, (size_t)cap * phase.spec_frame() * sizeof(float2)));
-    VS_HIP(hipMalloc((void**)&psurf, (size_t)cap * phase.surface_elems() * sizeof(float)));
-    VS_HIP(hipMalloc((void**)&ppairs, (size_t)cap * sizeof(vsp::Pair)));
-    VS_HIP(hipMalloc((void**)&pneg, (size_t)cap));
-    VS_HIP(hipMalloc((void**)&pres, (size_t)cap * sizeof(vsp::Result)));
+    VS_HIP(vsi::dev_alloc((void**)&pspec, ((size_t)cap + 1) * phase.spec_frame() * sizeof(float2)));
+    VS_HIP(vsi::dev_alloc((void**)&pG, (size_t)cap * phase.spec_frame() * sizeof(float2)));
+    VS_HIP(vsi::dev_alloc((void**)&psurf, (size_t)cap * phase.surface_elems() * sizeof(float)));
+    VS_HIP(vsi::dev_alloc((void**)&ppairs, (size_t)cap * sizeof(vsp::Pair)));
+    VS_HIP(vsi::dev_alloc((void**)&pneg, (size_t)cap));
+    VS_HIP(vsi::dev_alloc((void**)&pres, (size_t)cap * sizeof(vsp::Result)));
     phase_cap = cap;
     return VS_OK;
 }
@@ -527,42 +529,51 @@ int vs_aligner::configure(int w, int h, int format, const vs_aligner_params& p) 
     return VS_OK;
 }
 
+// Grows the per-chunk storage to n frames: allocate the whole new set -> copy the carry-over frame -> swap -> free the old set.
+// Any failure on the way frees what was allocated here and leaves the handle exactly as it was (same buffers, same `cap`, the
+// carry-over frame where it sat), so a failed call is simply a failed call: the next one -- after the caller has made room, or with
+// a smaller batch -- finds a consistent handle (tests/test_alloc_failure_gpu.py walks a failure over every allocation).
 int vs_aligner::ensure_capacity(int n) {
     if (n <= cap) return VS_OK;
-    // keep the carry-over frame (slot `cap_old_last`) alive across a regrow: it is always moved to slot 0
-    // at the start of run_chunk, so here it already sits wherever the previous chunk left it; copy it out.
     const int newcap = n;
     const size_t slots = (size_t)newcap + 1;
-    uint8_t* npyr = nullptr; uint16_t* nlm = nullptr; float* njac = nullptr;
-    VS_HIP(hipMalloc((void**)&npyr, slots * pyr_frame));
-    VS_HIP(hipMalloc((void**)&nlm, slots * lm_frame * 2));
-    VS_HIP(hipMalloc((void**)&njac, slots * jac_frame * 4));
-    if (pyr && seq > 0) {
-        // previous chunk's last frame is in slot last_n of the old slabs
-        VS_HIP(hipMemcpyAsync(npyr, pyr + (size_t)last_n * pyr_frame, pyr_frame, hipMemcpyDeviceToDevice, stream));
-        VS_HIP(hipMemcpyAsync(nlm, lm + (size_t)last_n * lm_frame, lm_frame * 2, hipMemcpyDeviceToDevice, stream));
-        VS_HIP(hipMemcpyAsync(njac, jac + (size_t)last_n * jac_frame, jac_frame * 4, hipMemcpyDeviceToDevice, stream));
-        VS_HIP(hipStreamSynchronize(stream));
-        last_n = 0;   // carry-over now lives in slot 0 of the new slabs
+    const size_t coop_bytes = std::min(newcap, kCoopMaxPairs) * coop_pair_bytes(nt_max);
+    // the new set; `owned` frees whatever is still in it when this function returns early
+    struct NewSet {
+        void* dev[10] = {};
+        void* pinned[4] = {};
+        ~NewSet() {
+            for (void* q : dev) if (q) (void)hipFree(q);
+            for (void* q : pinned) if (q) (void)hipHostFree(q);
+        }
+    } ns;
+    enum { D_PYR, D_LM, D_JAC, D_STATES, D_DESCS, D_WD, D_IDX, D_WV, D_RECS, D_COOP };
+    const size_t dev_bytes[10] = {
+        slots * pyr_frame, slots * lm_frame * 2, slots * jac_frame * 4, sizeof(PairState) * newcap, sizeof(PairDesc) * newcap,
+        (size_t)newcap * 2 * nt_max * sizeof(uint16_t), (size_t)newcap * 2 * nt_max * sizeof(int32_t),
+        (size_t)newcap * 2 * nt_max * sizeof(float) * 2,      // samples of all pairs, then template pixels
+        (size_t)newcap * 2 * nt_max * 28, coop_bytes};
+    const size_t pinned_bytes[4] = {(size_t)newcap * 2 * nt_max * sizeof(uint16_t), (size_t)newcap * 2 * nt_max * sizeof(int32_t),
+                                    sizeof(PairState) * newcap, sizeof(PairDesc) * newcap};
+    for (int i = 0; i < 10; i++) VS_HIP(vsi::dev_alloc(&ns.dev[i], dev_bytes[i]));
+    for (int i = 0; i < 4; i++) VS_HIP(vsi::pinned_alloc(&ns.pinned[i], pinned_bytes[i]));
+    VS_HIP(hipMemsetAsync(ns.dev[D_COOP], 0, coop_bytes, stream));
+    const bool carry = pyr && seq > 0;
+    if (carry) {
+        // the previous chunk's last frame (slot last_n of the old slabs) becomes slot 0 of the new ones
+        VS_HIP(hipMemcpyAsync(ns.dev[D_PYR], pyr + (size_t)last_n * pyr_frame, pyr_frame, hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipMemcpyAsync(ns.dev[D_LM], lm + (size_t)last_n * lm_frame, lm_frame * 2, hipMemcpyDeviceToDevice, stream));
+        VS_HIP(hipMemcpyAsync(ns.dev[D_JAC], jac + (size_t)last_n * jac_frame, jac_frame * 4, hipMemcpyDeviceToDevice, stream));
     }
-    void* old[] = {pyr, lm, jac, states, descs, wd, wv, idx, recs, coop};
-    for (void* p : old) if (p) (void)hipFree(p);
-    void* oldh[] = {h_wd, h_idx, h_states, h_descs};
-    for (void* p : oldh) if (p) (void)hipHostFree(p);
-    pyr = npyr; lm = nlm; jac = njac;
-    VS_HIP(hipMalloc((void**)&states, sizeof(PairState) * newcap));
-    VS_HIP(hipMalloc((void**)&descs, sizeof(PairDesc) * newcap));
-    VS_HIP(hipMalloc((void**)&wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
-    VS_HIP(hipMalloc((void**)&idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
-    VS_HIP(hipMalloc((void**)&wv, (size_t)newcap * 2 * nt_max * sizeof(float) * 2));   // samples of all pairs, then template pixels
-    VS_HIP(hipMalloc((void**)&recs, (size_t)newcap * 2 * nt_max * 28));
-    VS_HIP(hipMalloc((void**)&coop, std::min(newcap, kCoopMaxPairs) * coop_pair_bytes(nt_max)));
-    VS_HIP(hipMemset(coop, 0, std::min(newcap, kCoopMaxPairs) * coop_pair_bytes(nt_max)));
+    VS_HIP(hipStreamSynchronize(stream));        // nothing reads the old set any more; nothing below can fail
+    // ---- swap: the handle takes the new set, `ns` takes the old one and frees it on the way out ----
+    void** dev_members[10] = {(void**)&pyr, (void**)&lm, (void**)&jac, (void**)&states, (void**)&descs, (void**)&wd, (void**)&idx,
+                              (void**)&wv, (void**)&recs, (void**)&coop};
+    void** pinned_members[4] = {(void**)&h_wd, (void**)&h_idx, (void**)&h_states, (void**)&h_descs};
+    for (int i = 0; i < 10; i++) std::swap(*dev_members[i], ns.dev[i]);
+    for (int i = 0; i < 4; i++) std::swap(*pinned_members[i], ns.pinned[i]);
+    if (carry) last_n = 0;                       // the carry-over now lives in slot 0
     coop_epoch = 0;
-    VS_HIP(hipHostMalloc((void**)&h_wd, (size_t)newcap * 2 * nt_max * sizeof(uint16_t)));
-    VS_HIP(hipHostMalloc((void**)&h_idx, (size_t)newcap * 2 * nt_max * sizeof(int32_t)));
-    VS_HIP(hipHostMalloc((void**)&h_states, sizeof(PairState) * newcap));
-    VS_HIP(hipHostMalloc((void**)&h_descs, sizeof(PairDesc) * newcap));
     cap = newcap;
     return VS_OK;
 }
@@ -649,7 +660,7 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
         if (bytes > stage_bytes) {
             if (stage) (void)hipFree(stage);
             stage = nullptr; stage_bytes = 0;
-            VS_HIP(hipMalloc(&stage, bytes));
+            VS_HIP(vsi::dev_alloc(&stage, bytes));
             stage_bytes = bytes;
         }
         VS_HIP(hipMemcpyAsync(stage, frames, bytes, hipMemcpyHostToDevice, s));
@@ -855,7 +866,7 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
                 if (selbuf_bytes < want) {
                     if (selbuf) (void)hipFree(selbuf);
                     selbuf = nullptr; selbuf_bytes = 0;
-                    VS_HIP(hipMalloc((void**)&selbuf, want));
+                    VS_HIP(vsi::dev_alloc((void**)&selbuf, want));
                     selbuf_bytes = want;
                 }
             }
@@ -1089,8 +1100,17 @@ vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
     if (params) a->params = *params; else vs_aligner_params_default(&a->params);
     {   // VS_SELECT_MODE=0|1|2 (read once): the selection mode new handles start in -- for callers that cannot reach
         // vs_aligner_set_select_mode (the facade classes, the harness programs); an explicit set_select_mode still wins
-        static const int env_mode = []() { const char* e = getenv("VS_SELECT_MODE"); return e ? atoi(e) : -1; }();
-        if (env_mode == VS_SELECT_STL_HOST || env_mode == VS_SELECT_DEVICE || env_mode == VS_SELECT_STABLE) a->select_mode = env_mode;
+        static const int env_mode = []() {
+            const char* e = getenv("VS_SELECT_MODE");
+            const int m = e ? atoi(e) : -1;
+            if (m == VS_SELECT_STL_HOST || m == VS_SELECT_DEVICE || m == VS_SELECT_STABLE) {
+                fprintf(stderr, "libvs_amd: VS_SELECT_MODE=%d -- new aligner / stabilizer handles start in selection mode %d (%s)\n", m, m,
+                        m == VS_SELECT_STABLE ? "VS_SELECT_STABLE" : (m == VS_SELECT_DEVICE ? "VS_SELECT_DEVICE" : "VS_SELECT_STL_HOST"));
+                return m;
+            }
+            return -1;
+        }();
+        if (env_mode >= 0) a->select_mode = env_mode;
     }
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error(VS_ERR_HIP, "hipStreamCreate failed");
@@ -1110,6 +1130,11 @@ int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
     VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE || mode == VS_SELECT_STABLE));
     a->select_mode = mode;
     return VS_OK;
+}
+
+int vs_aligner_get_select_mode(const vs_aligner* a) {
+    VS_ARG(a);
+    return a->select_mode;
 }
 
 int vs_aligner_set_batch_mode(vs_aligner* a, int mode) {
@@ -1150,6 +1175,15 @@ static int align_start_impl(vs_aligner* a, const void* frames, size_t frame_stri
 static void align_close_clips(vs_aligner* a) {
     if (a->started_clips) { a->started_clips = false; a->clip_len = 0; a->seq = 0; }
 }
+// An align call that returns an error (a refused allocation, a HIP failure) ends the running sequence: the next frame is the
+// first frame of a new one, exactly as a fresh handle would treat it -- the reference's protocol for a failed kernel call
+// (alignment.cpp:357-367: LastWidth = -1, so the next AlignNextFrame re-initialises).  Device buffers stay as they are.
+static void align_failed(vs_aligner* a) {
+    a->seq = 0;
+    a->ck.open = false;
+    for (vs_aligner::Span& sp : a->spans) { a->event_pool.push_back(sp.a); a->event_pool.push_back(sp.b); }
+    a->spans.clear();
+}
 static int align_start(vs_aligner* a, const void* frames, size_t frame_stride, int n, int clip_frames, int w, int h, int stride, int format,
                        int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status, bool async) {
     VS_ARG(a && clip_frames >= 0);
@@ -1157,7 +1191,7 @@ static int align_start(vs_aligner* a, const void* frames, size_t frame_stride, i
     a->started_result = 0;
     if (clip_frames > 0) { a->seq = 0; a->clip_len = clip_frames; a->started_clips = true; }
     const int r = align_start_impl(a, frames, frame_stride, n, w, h, stride, format, mem, params, out, status, async);
-    if (r < 0) { a->started = false; align_close_clips(a); }
+    if (r < 0) { a->started = false; align_close_clips(a); align_failed(a); }
     return r;
 }
 static int align_finish(vs_aligner* a) {
@@ -1168,6 +1202,7 @@ static int align_finish(vs_aligner* a) {
         if (r == VS_OK) for (int i = 0; i < a->started_n; i++) r += a->started_status[i];
     }
     align_close_clips(a);
+    if (r < 0) align_failed(a);
     return r;
 }
 // an alignment that was started and will not be finished (an error elsewhere): drain the stream, forget the chunk
@@ -1222,8 +1257,8 @@ static int align_start_impl(vs_aligner* a, const void* frames, size_t frame_stri
         if (a->ingest_bytes < area) {
             for (void*& q : a->ingest) { if (q) (void)hipFree(q); q = nullptr; }
             a->ingest_bytes = 0;
-            VS_HIP(hipMalloc(&a->ingest[0], area));
-            VS_HIP(hipMalloc(&a->ingest[1], area));
+            VS_HIP(vsi::dev_alloc(&a->ingest[0], area));
+            VS_HIP(vsi::dev_alloc(&a->ingest[1], area));
             a->ingest_bytes = area;
         }
         if (!a->copy_stream) VS_HIP(hipStreamCreateWithFlags(&a->copy_stream, hipStreamNonBlocking));
@@ -1415,7 +1450,7 @@ void vs_stabilizer_destroy(vs_stabilizer* s) {
     for (void* q : s->batch_out) if (q) (void)hipFree(q);
     for (void* q : s->pipe_in) if (q) (void)hipFree(q);
     for (hipEvent_t e : s->down_ev) if (e) (void)hipEventDestroy(e);
-    if (s->warp_stream) { vsi::retire_stream(s->warp_stream); (void)hipStreamDestroy(s->warp_stream); }
+    if (s->warp_stream) { (void)vsi::retire_stream(s->warp_stream); (void)hipStreamDestroy(s->warp_stream); }
     if (s->warp_ev) (void)hipEventDestroy(s->warp_ev);
     if (s->down_stream) (void)hipStreamDestroy(s->down_stream);
     if (s->up_stream) (void)hipStreamDestroy(s->up_stream);
@@ -1501,7 +1536,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         s->overlap_warps = false;
         s->next_n = 0;
         a->batch_mode = saved_mode;
-        const hipError_t we = hipStreamSynchronize(s->warp_stream);          // every warp has landed before the call returns
+        const hipError_t we = s->warp_stream ? hipStreamSynchronize(s->warp_stream) : hipSuccess;   // every warp has landed before the call returns
         if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
         for (void* b : s->held_release) s->pool.push_back(b);
         s->held_release.clear();
@@ -1536,7 +1571,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         s->overlap_warps = false;
         s->next_n = 0;
         a->batch_mode = saved_mode;
-        const hipError_t we = hipStreamSynchronize(s->warp_stream);
+        const hipError_t we = s->warp_stream ? hipStreamSynchronize(s->warp_stream) : hipSuccess;
         if (we != hipSuccess && r >= 0) r = set_error(VS_ERR_HIP, "stabilizer warps: %s", hipGetErrorString(we));
         for (void* b : s->held_release) s->pool.push_back(b);
         s->held_release.clear();
@@ -1577,8 +1612,8 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
     if (s->pipe_in_bytes < fbytes * chunk) {
         for (void*& q : s->pipe_in) { if (q) (void)hipFree(q); q = nullptr; }
         s->pipe_in_bytes = 0;
-        VS_HIP(hipMalloc(&s->pipe_in[0], fbytes * chunk));
-        VS_HIP(hipMalloc(&s->pipe_in[1], fbytes * chunk));
+        VS_HIP(vsi::dev_alloc(&s->pipe_in[0], fbytes * chunk));
+        VS_HIP(vsi::dev_alloc(&s->pipe_in[1], fbytes * chunk));
         s->pipe_in_bytes = fbytes * chunk;
     }
     if (!s->up_stream) VS_HIP(hipStreamCreateWithFlags(&s->up_stream, hipStreamNonBlocking));
@@ -1650,7 +1685,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         if (s->batch_in_bytes < fbytes * n) {
             if (s->batch_in) (void)hipFree(s->batch_in);
             s->batch_in = nullptr; s->batch_in_bytes = 0;
-            VS_HIP(hipMalloc(&s->batch_in, fbytes * n));
+            VS_HIP(vsi::dev_alloc(&s->batch_in, fbytes * n));
             s->batch_in_bytes = fbytes * n;
         }
         const hipMemcpyKind kind = mem == VS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -1757,7 +1792,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
             if (s->batch_out_bytes[slot] < obytes * jobs.size()) {
                 if (s->batch_out[slot]) (void)hipFree(s->batch_out[slot]);
                 s->batch_out[slot] = nullptr; s->batch_out_bytes[slot] = 0;
-                VS_HIP(hipMalloc(&s->batch_out[slot], obytes * jobs.size()));
+                VS_HIP(vsi::dev_alloc(&s->batch_out[slot], obytes * jobs.size()));
                 s->batch_out_bytes[slot] = obytes * jobs.size();
             }
         }
@@ -1830,7 +1865,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
         if (f.owned || s->defer_own) continue;
         void* copy = nullptr;
         if (!s->pool.empty()) { copy = s->pool.back(); s->pool.pop_back(); }
-        else VS_HIP(hipMalloc(&copy, fbytes));
+        else VS_HIP(vsi::dev_alloc(&copy, fbytes));
         VS_HIP(hipMemcpyAsync(copy, f.ptr, fbytes, hipMemcpyDeviceToDevice, st));
         f.ptr = copy; f.owned = true;
     }
@@ -1859,6 +1894,10 @@ void* vs_stabilizer_stream(const vs_stabilizer* s) { return s && s->aligner ? (v
 int vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode) {
     VS_ARG(s && s->aligner);
     return vs_aligner_set_select_mode(s->aligner, mode);
+}
+int vs_stabilizer_get_select_mode(const vs_stabilizer* s) {
+    VS_ARG(s && s->aligner);
+    return s->aligner->select_mode;
 }
 int vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream) {
     VS_ARG(s && s->aligner);

@@ -22,7 +22,9 @@ int set_error(int code, const char* fmt, ...) {
 extern "C" {
 
 const char* vs_last_error(void) { return vsi::g_err; }
-const char* vs_version(void) { return "video_stabilizer_amd 0.1 (gfx950)"; }
+const char* vs_version(void) { return "video_stabilizer_amd 0.4 (gfx950, ABI 4)"; }
+int vs_abi_version(void) { return VS_ABI_VERSION; }
+size_t vs_sizeof_align_info(void) { return sizeof(vs_align_info); }
 
 // alignment.hpp:5-41
 int vs_format_bits(int format) {

@@ -23,6 +23,11 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 
 namespace vsi {
 
+// Every device / pinned-host allocation of the library goes through these two, so that tests can make the k-th one fail
+// (vs_test_fail_alloc, include/vs_amd.h).  On failure *p is nullptr.
+hipError_t dev_alloc(void** p, size_t bytes);
+hipError_t pinned_alloc(void** p, size_t bytes);
+
 // RAII device allocation used by the host-staged (VS_MEM_HOST) form of the kernel-level calls.
 struct DevBuf {
     void* p = nullptr;
@@ -34,7 +39,7 @@ struct DevBuf {
     hipError_t alloc(size_t n) {
         if (p) { (void)hipFree(p); p = nullptr; }
         bytes = n;
-        return hipMalloc(&p, n ? n : 1);
+        return dev_alloc(&p, n ? n : 1);
     }
     template <typename T> T* as() const { return (T*)p; }
 };
@@ -60,7 +65,7 @@ struct Staged {
 bool device_ready();   // true when a HIP device is usable (sets last error otherwise)
 // `s` is about to be destroyed: wait for and drop everything the library still tracks on it (bgr_image_warp's parameter ring
 // keeps an event per in-flight call; an event must not outlive the stream it was recorded on)
-void retire_stream(hipStream_t s);
+hipError_t retire_stream(hipStream_t s);   // first error of the waits (the references are dropped either way)
 
 }  // namespace vsi
 #endif

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "vs_phase.hpp"
+#include "vs_internal.hpp"
 
 namespace {
 
@@ -311,7 +312,7 @@ static hipError_t upload_twiddles(int n, float2** out, hipStream_t s) {
         const double a = 2.0 * M_PI * (double)j / (double)n;
         tw[j] = make_float2((float)std::cos(a), (float)-std::sin(a));
     }
-    hipError_t e = hipMalloc((void**)out, sizeof(float2) * (size_t)n);
+    hipError_t e = vsi::dev_alloc((void**)out, sizeof(float2) * (size_t)n);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(*out, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
@@ -376,7 +377,7 @@ hipError_t Context::correlate(const float2* spec, const Pair* pairs_dev, int n_p
     if (need > cands_bytes) {                  // per-row-block peak candidates (grown on demand; the stream is in order)
         if (cands) { hipError_t es = hipStreamSynchronize(s); if (es != hipSuccess) return es; (void)hipFree(cands); }
         cands = nullptr; cands_bytes = 0;
-        hipError_t em = hipMalloc(&cands, need);
+        hipError_t em = vsi::dev_alloc(&cands, need);
         if (em != hipSuccess) return em;
         cands_bytes = need;
     }

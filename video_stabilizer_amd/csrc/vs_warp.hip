@@ -668,7 +668,8 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
                             int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + WT_H - 1) / WT_H;
     const long long tpf = (long long)tiles_x * tiles_y;
-    if (tpf > 0x3fffffLL) return hipErrorNotSupported;
+    // the kernel's tl / tiles_x is a multiply-high, exact while tl * tiles_x < 2^32: wider windows take the generic kernel
+    if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
     const int chunk = (int)((tpf + 7) / 8);
     // tl / tiles_x == (tl * magic) >> 32 for every tl with tl * tiles_x < 2^32 (tiles_x >= 2; the kernel special-cases 1)
     const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;

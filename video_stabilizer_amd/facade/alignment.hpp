@@ -58,7 +58,7 @@ private:
     bool align(const uint8_t* data, int w, int h, int stride, int fmt, SimilarityTransform& transform, const VideoAlignerParams& params) {
         transform = SimilarityTransform();   // alignment.cpp:344
         const vs_aligner_params p = params.c();
-        if (!h_) h_ = vs_aligner_create(&p, device_);
+        if (!h_) { vs::check_abi(); h_ = vs_aligner_create(&p, device_); }
         if (!h_) return false;
         vs_transform t{0, 0, 0, 0};
         const int r = vs_aligner_align_next(h_, data, w, h, stride, fmt, VS_MEM_HOST, &p, &t);

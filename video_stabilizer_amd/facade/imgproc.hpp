@@ -22,6 +22,14 @@
 
 namespace vs {
 
+// The engine writes sizeof(vs_align_info) bytes per frame into caller memory and the enums have moved between releases: a
+// translation unit built against another include/vs_amd.h than the library must stop before the first engine call.
+inline void check_abi() {
+    if (vs_abi_version() != VS_ABI_VERSION || vs_sizeof_align_info() != sizeof(vs_align_info))
+        throw std::runtime_error("libvs_amd.so ABI " + std::to_string(vs_abi_version()) + " does not match the headers this program was built with (ABI " +
+                                 std::to_string(VS_ABI_VERSION) + ")");
+}
+
 template <typename T>
 class Buffer {
 public:

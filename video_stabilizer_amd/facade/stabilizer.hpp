@@ -31,6 +31,7 @@ public:
         p.min_disp = params.min_disp; p.max_disp = params.max_disp; p.min_decay = params.min_decay; p.max_decay = params.max_decay;
         p.warp_mode = params.warp_mode; p.warp_border = params.warp_border;
         crop_ = params.crop_pixels > 0 ? params.crop_pixels : 0;
+        vs::check_abi();
         h_ = vs_stabilizer_create(&p, device);
         if (!h_) throw std::runtime_error(std::string("vs_stabilizer_create: ") + vs_last_error());
     }
