@@ -540,6 +540,8 @@ def main():
     dist, backend_used, backend_note = None, None, None
     if world > 1 or args.force_dist:
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
+        # (every rank joins a gloo group first and the ranks AGREE over it whether RCCL is up: all of them report over RCCL, or all
+        # of them over gloo with the first failing rank's reason -- video_stabilizer_amd/dist.py)
         dist, backend_used, backend_note = vsdist.init_with_fallback(args.dist_backend, rank, world,
                                                                       device_id=dev if args.dist_backend == "nccl" else None)
         assert dist.get_world_size() == world, "process group has %d ranks, launcher says %d" % (dist.get_world_size(), world)
@@ -561,14 +563,14 @@ def main():
     def timed_loop(fn, k):
         """k calls of fn between barrier + synchronize on both sides; seconds on this rank, last return value"""
         if dist is not None:
-            dist.barrier()
+            vsdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k):
             r = fn()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            vsdist.barrier()
         return time.perf_counter() - t0, r
 
     def roofline_of(aw, nframes_total):
@@ -888,7 +890,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        vsdist.barrier()
         dist.destroy_process_group()
     if rc:
         sys.exit(rc)

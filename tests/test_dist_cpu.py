@@ -91,6 +91,58 @@ def test_rccl_init_failure_falls_back_to_gloo(tmp_path):
         assert j["secs"] == 2.0 and j["frames"] == 20 and j["aligned"] == 18
 
 
+DISAGREE_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch
+from video_stabilizer_amd import dist as D
+world, rank, local = D.env_world()
+fail = os.environ.get("FAIL_RANK")
+# the "RCCL" probe group is a second gloo group here (no GPU in the container): it works on every rank unless a failure is injected
+d, used, why = D.init_with_fallback("nccl", rank, world, probe_seconds=30, _probe_backend="gloo",
+                                    _fail_probe_on_rank=int(fail) if fail else None)
+D.barrier()
+secs, f, a = D.aggregate(1.0 + rank, 10, 9, device=D.report_device())
+per = D.gather_seconds(1.0 + rank, device=D.report_device())
+print(json.dumps({"rank": rank, "used": used, "why": why, "secs": secs, "frames": f, "per": per}))
+d.destroy_process_group()
+'''
+
+
+def _run_ranks(script, world, port, extra_env=None):
+    import json
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return sorted(outs, key=lambda j: j["rank"])
+
+
+def test_ranks_agree_on_the_backend_when_the_probe_fails_on_one_rank_only(tmp_path):
+    """the advisor's case: RCCL comes up on some ranks and not on others.  No rank may go on alone: every rank ends on gloo, with
+    the failing rank's reason -- on the ONE rendezvous port the launcher gave (no port + 1)."""
+    script = tmp_path / "d.py"
+    script.write_text(DISAGREE_WORKER % ROOT)
+    outs = _run_ranks(script, 3, str(29800 + os.getpid() % 100), {"FAIL_RANK": "1"})
+    for j in outs:
+        assert j["used"] == "gloo" and "rank 1" in j["why"] and "injected" in j["why"]
+        assert j["secs"] == 3.0 and j["frames"] == 30 and j["per"] == [1.0, 2.0, 3.0]
+
+
+def test_ranks_agree_on_the_probed_backend_when_it_works_everywhere(tmp_path):
+    script = tmp_path / "d.py"
+    script.write_text(DISAGREE_WORKER % ROOT)
+    outs = _run_ranks(script, 2, str(29900 + os.getpid() % 40))
+    for j in outs:
+        assert j["used"] == "nccl" and j["why"] is None          # (the name of the requested backend: the probe group stood in for it)
+        assert j["secs"] == 2.0 and j["frames"] == 20 and j["per"] == [1.0, 2.0]
+
+
 def test_gather_seconds_without_a_process_group():
     from video_stabilizer_amd import dist as D
     assert D.gather_seconds(1.25) == [1.25]

@@ -25,38 +25,76 @@ def init(backend, rank, world, device_id=None):
     return dist
 
 
-def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300):
-    """"if RCCL init fails on the box, fall back to host-side aggregation and say so".  Initialises `backend`
-    and proves it with one tiny all-reduce (communicator creation and the first collective are where a broken RCCL setup shows,
-    on every rank alike); if either raises, the group is torn down and re-created on gloo (CPU tensors, next port), and the
-    reason is returned for the report.  -> (dist, backend in use, None or the reason)"""
+# the process group (and device) the report collectives run on: None = the default group.  Set by init_with_fallback when RCCL
+# came up on EVERY rank: the default group stays gloo (the side channel the ranks agree over), RCCL is a sub-group beside it.
+_REPORT_GROUP = None
+_REPORT_DEVICE = None
+
+
+def report_device():
+    """where aggregate() / gather_seconds() / barrier() place their tensors (the rank's GPU when they run over RCCL, else None)"""
+    return _REPORT_DEVICE
+
+
+def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, _probe_backend=None, _fail_probe_on_rank=None):
+    """"if RCCL init fails on the box, fall back to host-side aggregation and say so" -- decided by ALL ranks
+    together, never by each rank for itself.
+
+    1. Every rank joins a gloo group on the launcher's MASTER_PORT: the host-side channel, which needs no GPU and is what the
+       report falls back to.  It is the default group for the rest of the run (no second rendezvous, no second port).
+    2. Every rank tries RCCL as a sub-group (dist.new_group("nccl")) and proves it with one tiny all-reduce -- communicator creation
+       and the first collective are where a broken RCCL setup shows.  Whatever happens is caught, per rank.
+    3. The ranks all-reduce (MIN) their "RCCL ok" flags over gloo.  All ones: the report collectives (aggregate, gather_seconds,
+       barrier) run over RCCL on every rank.  Anything else: over gloo on every rank, and every rank gets every failing rank's
+       reason for the report line.  A rank whose probe hangs is cut off by the probe's own timeout; the others wait for it at the
+       flag all-reduce, so the outcome is still common to all.
+    -> (dist, backend in use: "nccl" | "gloo", None or the reason).  (_probe_backend / _fail_probe_on_rank: test hooks.)"""
+    global _REPORT_GROUP, _REPORT_DEVICE
     import datetime
     import torch
     import torch.distributed as dist
+    _REPORT_GROUP, _REPORT_DEVICE = None, None
     if backend != "nccl":
         return init(backend, rank, world, device_id), backend, None
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    why = None
+    init("gloo", rank, world)
+    why, group = None, None
     try:
-        kw = {"device_id": device_id} if device_id is not None else {}
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=probe_seconds), **kw)
-        t = torch.ones(1, dtype=torch.int64, device=device_id)
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
+        group = dist.new_group(backend=_probe_backend or "nccl", timeout=datetime.timedelta(seconds=probe_seconds))
+        if _fail_probe_on_rank is not None and rank == _fail_probe_on_rank:
+            raise RuntimeError("probe failure injected on rank %d" % rank)
+        t = torch.ones(1, dtype=torch.int64, device=device_id if _probe_backend is None else None)
+        dist.all_reduce(t, group=group)
+        if t.is_cuda:
+            torch.cuda.synchronize()
         if int(t.item()) != world:
             raise RuntimeError("probe all-reduce returned %d for %d ranks" % (int(t.item()), world))
-        return dist, "nccl", None
     except Exception as e:          # noqa: BLE001 -- whatever RCCL raises
-        why = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
-        try:
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:           # noqa: BLE001
-            pass
-    os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)      # the first store may still hold its port
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    return dist, "gloo", why
+        why = "rank %d: %s: %s" % (rank, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+    # ---- agreement over the host-side channel ----
+    flag = torch.tensor([0 if why else 1], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        _REPORT_GROUP, _REPORT_DEVICE = group, (device_id if _probe_backend is None else None)
+        return dist, "nccl", None
+    reasons = [None] * world
+    dist.all_gather_object(reasons, why)
+    # every failing rank's reason (a rank that merely timed out waiting for a failed peer says so too)
+    return dist, "gloo", "; ".join(r for r in reasons if r) or "unknown"
+
+
+def barrier():
+    """all ranks, over the report group (RCCL when it is up on every rank: a one-element all-reduce, then a device synchronise)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if _REPORT_GROUP is None:
+        dist.barrier()
+        return
+    t = torch.zeros(1, dtype=torch.int32, device=_REPORT_DEVICE)
+    dist.all_reduce(t, group=_REPORT_GROUP)
+    if t.is_cuda:
+        torch.cuda.synchronize()
 
 
 def aggregate(seconds, frames, aligned, device=None):
@@ -67,8 +105,9 @@ def aggregate(seconds, frames, aligned, device=None):
         return float(seconds), int(frames), int(aligned)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     c = torch.tensor([int(frames), int(aligned)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    grp = _REPORT_GROUP if device is not None else None          # CPU tensors always travel over the default (gloo) group
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=grp)
     return float(t.item()), int(c[0].item()), int(c[1].item())
 
 
@@ -80,5 +119,5 @@ def gather_seconds(seconds, device=None):
         return [float(seconds)]
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
+    dist.all_gather(out, t, group=_REPORT_GROUP if device is not None else None)
     return [float(x.item()) for x in out]
