@@ -2,9 +2,15 @@
 // grid_search_smoother.cpp:190-262): every parameter combination stabilizes the whole clip with a fresh stabilizer and
 // is scored by output jitter / input jitter.  Here the clip, the stabilized output and the scoring all stay on the GPU;
 // a worker thread owns its stabilizer, its scoring aligner and its output buffer (handles are independent).
+// Several GPUs (--devices a,b,...|all): the clip is uploaded once per device slot, worker t works on slot t mod G with handles
+// created on that slot's device -- the reference's independence model (grid_search_align.cpp:159-210: one stabilizer per worker,
+// halide_set_num_threads(1); here one stream per handle), no exchange between devices, one shared work counter on the host.
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <memory>
 #include <iostream>
 #include <mutex>
 #include <thread>
@@ -20,10 +26,18 @@ struct GridResult {
     int best = -1;
     double best_ratio = 1e9;
     size_t evaluated = 0, skipped = 0;
+    std::vector<double> ratios;          // per combination (NaN: skipped) -- the same whatever the device split
+    std::vector<double> slot_seconds;    // per device slot: the time its workers spent inside combinations (summed over its workers)
+    std::vector<size_t> slot_done;       // per device slot: combinations evaluated
 };
 
-inline GridResult run_grid(const DeviceClip& clip, double input_jitter, const std::vector<GridCombo>& combos, int jobs, int device) {
+inline GridResult run_grid(const std::vector<std::unique_ptr<DeviceClip>>& clips, double input_jitter, const std::vector<GridCombo>& combos, int jobs) {
     GridResult res;
+    const int G = (int)clips.size();
+    res.ratios.assign(combos.size(), std::nan(""));
+    res.slot_seconds.assign((size_t)G, 0.0);
+    res.slot_done.assign((size_t)G, 0);
+    const DeviceClip& clip = *clips[0];
     const size_t total = combos.size();
     std::atomic<size_t> next{0}, done{0}, skipped{0};
     std::mutex mu;
@@ -32,7 +46,10 @@ inline GridResult run_grid(const DeviceClip& clip, double input_jitter, const st
     const size_t esz = clip.fmt.bits > 8 ? 2 : 1;
     std::string failure;
 
-    auto worker = [&]() {
+    auto worker = [&](int t) {
+        const int slot = t % G;
+        const DeviceClip& clip = *clips[(size_t)slot];
+        const int device = clip.device;
         try {
             hip_check(hipSetDevice(device), "hipSetDevice");
             vs_aligner* scorer = vs_aligner_create(nullptr, device);
@@ -43,6 +60,7 @@ inline GridResult run_grid(const DeviceClip& clip, double input_jitter, const st
                 const size_t idx = next.fetch_add(1);
                 if (idx >= total) break;
                 const GridCombo& c = combos[idx];
+                const auto c0 = std::chrono::steady_clock::now();
                 vs_stabilizer* stab = vs_stabilizer_create(&c.params, device);
                 if (!stab) {      // a parameter set this build rejects (phase_correlate): report and move on
                     skipped++;
@@ -73,10 +91,15 @@ inline GridResult run_grid(const DeviceClip& clip, double input_jitter, const st
                 const double ratio = out_jitter / input_jitter;
                 const size_t finished = ++done;
                 std::lock_guard<std::mutex> lk(mu);
+                res.ratios[idx] = ratio;
+                res.slot_seconds[(size_t)slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+                res.slot_done[(size_t)slot]++;
                 const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 std::cout << "[" << finished << "/" << total << "] " << c.label << "  outJit=" << out_jitter << "  ratio=" << ratio
                           << "  elapsed=" << sec << "s";
-                if (ratio < res.best_ratio) {
+                if (G > 1) std::cout << "  slot=" << slot << " dev=" << device;
+                // ties go to the lower combination index, so the winner does not depend on which worker finished first
+                if (ratio < res.best_ratio || (ratio == res.best_ratio && (int)idx < res.best)) {
                     res.best_ratio = ratio;
                     res.best = (int)idx;
                     std::cout << "  ** new best **";
@@ -91,24 +114,42 @@ inline GridResult run_grid(const DeviceClip& clip, double input_jitter, const st
         }
     };
     std::vector<std::thread> threads;
-    for (int i = 0; i < jobs; i++) threads.emplace_back(worker);
+    jobs = std::max(jobs, G);                    // at least one worker per device slot
+    for (int i = 0; i < jobs; i++) threads.emplace_back(worker, i);
     for (auto& t : threads) t.join();
     if (!failure.empty()) throw std::runtime_error(failure);
     res.evaluated = done;
     res.skipped = skipped;
+    if (G > 1) {
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << "Device split: " << G << " slots, " << jobs << " workers, wall " << wall << " s" << std::endl;
+        for (int g = 0; g < G; g++)
+            std::cout << "  slot " << g << " (device " << clips[(size_t)g]->device << "): " << res.slot_done[(size_t)g] << " combinations, "
+                      << res.slot_seconds[(size_t)g] << " worker-seconds" << std::endl;
+    }
     return res;
 }
+// every combination's ratio in index order, full precision: what a device split must reproduce (--dump-ratios)
+inline void dump_ratios(const GridResult& r) {
+    for (size_t i = 0; i < r.ratios.size(); i++) std::printf("RATIO %zu %.17g\n", i, r.ratios[i]);
+}
 
-// load the clip, put it in HBM, score the input (grid_search_align.cpp:121-132)
-inline bool prepare(const GridArgs& args, DeviceClip& clip, double& input_jitter) {
+// load the clip, put it in HBM -- once per device slot --, score the input (grid_search_align.cpp:121-132)
+inline bool prepare(const GridArgs& args, std::vector<std::unique_ptr<DeviceClip>>& clips, double& input_jitter) {
     vsio::Clip host;
     std::string err;
     if (!vsio::load_clip(args.video, host, err, args.max_frames)) { std::cerr << "Cannot open " << args.video << " (" << err << ")" << std::endl; return false; }
     if (host.frames < 2) { std::cerr << "Video too short." << std::endl; return false; }
-    if (vs_device_count() <= args.device) { std::cerr << "No HIP device " << args.device << std::endl; return false; }
-    hip_check(hipSetDevice(args.device), "hipSetDevice");
-    clip.upload(host);
-    vs_aligner* a = vs_aligner_create(nullptr, args.device);
+    const std::vector<int> slots = args.slots();
+    for (int d : slots) if (d < 0 || vs_device_count() <= d) { std::cerr << "No HIP device " << d << std::endl; return false; }
+    clips.clear();
+    for (int d : slots) {
+        clips.emplace_back(new DeviceClip());
+        clips.back()->upload(host, d);
+    }
+    const DeviceClip& clip = *clips[0];
+    hip_check(hipSetDevice(clip.device), "hipSetDevice");
+    vs_aligner* a = vs_aligner_create(nullptr, clip.device);
     if (!a) { std::cerr << "vs_aligner_create: " << vs_last_error() << std::endl; return false; }
     input_jitter = measure_jitter(a, clip.buf.ptr, clip.frame_elems(), clip.frames, clip.fmt.w, clip.fmt.h, vs_format_of(clip.fmt));
     vs_aligner_destroy(a);

@@ -4,6 +4,8 @@
 // grid_search_align.cpp:121-124).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <algorithm>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -51,7 +53,10 @@ struct DeviceClip {
     int frames = 0;
     DeviceBuffer buf;
     size_t frame_elems() const { return fmt.bgr_elems(); }
-    void upload(const vsio::Clip& c) {
+    int device = 0;               // the device the buffer lives on
+    void upload(const vsio::Clip& c, int dev = 0) {
+        hip_check(hipSetDevice(dev), "hipSetDevice");
+        device = dev;
         fmt = c.fmt;
         frames = (int)c.frames;
         buf.reset(c.data.size());
@@ -72,11 +77,13 @@ inline double measure_jitter(vs_aligner* a, const void* d_frames, size_t frame_s
     return vsjit::jitter(t.data(), n, w, h);
 }
 
-// `video [-j N] [--device D] [--frames M]` as the grid searches take it (grid_search_align.cpp:62-90)
+// `video [-j N] [--device D | --devices a,b,...|all] [--frames M]` as the grid searches take it (grid_search_align.cpp:62-90)
 struct GridArgs {
     std::string video;
-    int jobs = 4;        // worker threads, each with its own stabilizer + scoring handles on the same GPU
+    int jobs = 4;        // worker threads, each with its own stabilizer + scoring handles; worker t works on device slot t mod G
     int device = 0;
+    std::vector<int> devices;   // the device slots (--devices); empty = {device}.  A device may be listed more than once: every
+                                // slot has its own copy of the clip, like a GPU of its own (how the one-GPU box rehearses the split)
     size_t max_frames = 0;
     bool parse(int argc, char** argv) {
         for (int i = 1; i < argc; i++) {
@@ -85,11 +92,32 @@ struct GridArgs {
             int v = 0;
             if (a == "-j" || a == "--jobs") { if (!value(v)) return false; jobs = std::max(1, v); }
             else if (a == "--device") { if (!value(v)) return false; device = v; }
+            else if (a == "--devices") {
+                if (i + 1 >= argc) return false;
+                const std::string list = argv[++i];
+                devices.clear();
+                if (list == "all") {
+                    for (int d = 0; d < vs_device_count(); d++) devices.push_back(d);
+                } else {
+                    size_t pos = 0;
+                    while (pos <= list.size()) {
+                        const size_t comma = std::min(list.find(',', pos), list.size());
+                        const std::string tok = list.substr(pos, comma - pos);
+                        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) return false;
+                        devices.push_back(std::atoi(tok.c_str()));
+                        pos = comma + 1;
+                    }
+                }
+                if (devices.empty()) return false;
+            }
             else if (a == "--frames") { if (!value(v)) return false; max_frames = (size_t)std::max(0, v); }
+            else if (a == "--dump-ratios") dump = true;
             else video = a;
         }
         return !video.empty();
     }
+    bool dump = false;          // print every combination's ratio in index order after the search (tests compare device splits)
+    std::vector<int> slots() const { return devices.empty() ? std::vector<int>{device} : devices; }
 };
 
 }  // namespace vsh

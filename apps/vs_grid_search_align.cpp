@@ -1,5 +1,5 @@
 // vs_grid_search_align -- search the aligner parameters that minimise output jitter (the role of the reference's
-// grid_search_align.cpp:62-219).   vs_grid_search_align clip.y4m [-j N] [--device D] [--frames M]
+// grid_search_align.cpp:62-219).   vs_grid_search_align clip.y4m [-j N] [--device D | --devices a,b,...|all] [--frames M]
 // Grid: phase_correlate x threshold x smallest_fraction x max_displacement, stabilizer with the smoother off, lag 1,
 // smoother_memory 0 (grid_search_align.cpp:135-167).
 #include <sstream>
@@ -7,9 +7,9 @@
 
 int main(int argc, char** argv) {
     vsh::GridArgs args;
-    if (!args.parse(argc, argv)) { std::cerr << "Usage: " << argv[0] << " video.y4m [-j N] [--device D] [--frames M]" << std::endl; return 1; }
+    if (!args.parse(argc, argv)) { std::cerr << "Usage: " << argv[0] << " video.y4m [-j N] [--device D | --devices a,b,...|all] [--frames M]" << std::endl; return 1; }
     try {
-        vsh::DeviceClip clip;
+        std::vector<std::unique_ptr<vsh::DeviceClip>> clip;      // one copy of the clip per device slot
         double input_jitter = 0.0;
         if (!vsh::prepare(args, clip, input_jitter)) return 1;
 
@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
                     }
         std::cerr << vsjit::score_note() << std::endl;
         std::cout << "Running " << combos.size() << " parameter combinations using " << args.jobs << " threads" << std::endl;
-        const vsh::GridResult r = vsh::run_grid(clip, input_jitter, combos, args.jobs, args.device);
+        const vsh::GridResult r = vsh::run_grid(clip, input_jitter, combos, args.jobs);
+        if (args.dump) vsh::dump_ratios(r);
         if (r.best < 0) { std::cerr << "No combination produced output." << std::endl; return 1; }
         const vs_aligner_params& b = combos[(size_t)r.best].params.aligner;
         std::cout << "\nBest params: phase_correlate=" << b.phase_correlate << "  threshold=" << b.threshold

@@ -1,5 +1,5 @@
 // vs_grid_search_smoother -- search the smoother / decay parameters that minimise output jitter (the role of the
-// reference's grid_search_smoother.cpp:91-287).   vs_grid_search_smoother clip.y4m [-j N] [--device D] [--frames M] [--quick]
+// reference's grid_search_smoother.cpp:91-287).   vs_grid_search_smoother clip.y4m [-j N] [--device D | --devices a,b,...|all] [--frames M] [--quick]
 // Grid: lag x smoother_memory x lambda x (min_disp < max_disp) x (min_decay > max_decay), aligner defaults
 // (grid_search_smoother.cpp:160-186); --quick keeps the first value of the displacement / decay axes (48 combinations).
 #include <sstream>
@@ -13,9 +13,9 @@ int main(int argc, char** argv) {
         else rest.push_back(argv[i]);
     }
     vsh::GridArgs args;
-    if (!args.parse((int)rest.size(), rest.data())) { std::cerr << "Usage: " << argv[0] << " video.y4m [-j N] [--device D] [--frames M] [--quick]" << std::endl; return 1; }
+    if (!args.parse((int)rest.size(), rest.data())) { std::cerr << "Usage: " << argv[0] << " video.y4m [-j N] [--device D | --devices a,b,...|all] [--frames M] [--quick]" << std::endl; return 1; }
     try {
-        vsh::DeviceClip clip;
+        std::vector<std::unique_ptr<vsh::DeviceClip>> clip;      // one copy of the clip per device slot
         double input_jitter = 0.0;
         if (!vsh::prepare(args, clip, input_jitter)) return 1;
 
@@ -51,7 +51,8 @@ int main(int argc, char** argv) {
                         }
         std::cerr << vsjit::score_note() << std::endl;
         std::cout << "Evaluating " << combos.size() << " parameter combinations using " << args.jobs << " threads" << std::endl;
-        const vsh::GridResult r = vsh::run_grid(clip, input_jitter, combos, args.jobs, args.device);
+        const vsh::GridResult r = vsh::run_grid(clip, input_jitter, combos, args.jobs);
+        if (args.dump) vsh::dump_ratios(r);
         if (r.best < 0) { std::cerr << "No combination produced output." << std::endl; return 1; }
         const vs_stabilizer_params& b = combos[(size_t)r.best].params;
         std::cout << "\nBest parameters:" << std::endl;

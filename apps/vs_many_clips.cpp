@@ -1,0 +1,179 @@
+// vs_many_clips -- BASELINE configs[3] from C++: a batch of independent clips split over the GPUs of one node, host side in C++
+// on the C ABI (north_star: "the host stays C++"; the reference's only many-clip precedent is the worker pool of
+// grid_search_align.cpp:159-210 -- independent workers, nothing shared but a work counter).
+//
+//   vs_many_clips [--devices a,b,...|all] [--clips 64] [--frames 120] [--size 1920x1080] [--steps 3] [--min-width 256]
+//                 [--exact] [--no-warp]
+//
+// One thread per device slot (a device may be listed twice: the one-GPU box rehearses the split that way).  Clip i belongs to
+// slot i mod G -- the same static round robin as bench.py's ranks --; a slot's clips sit back to back in its HBM.  The timed step
+// is bench.py's: vs_aligner_align_clips over all the slot's clips (VS_BATCH_SHARED: the small-footprint solver build), then ONE
+// vs_bgr_image_warp_batch of every frame by its measured transform on a second stream, so that the warp of step k runs under the
+// alignment of step k + 1.  No exchange between slots: the threads meet at a barrier before and after the timed steps, and the
+// line reports every slot's own seconds beside the whole job's (the slowest slot's) -- the C++ point of comparison for the
+// Python ranks of `bench.py --gpus N` (c4_strong.per_rank_seconds), where a host-side knee would show first.
+// The clips are copies of ONE seeded synthetic clip (apps/synth_clip.hpp): every slot aligns real texture and converges like
+// bench.py's clips do; for a throughput measurement distinct camera paths per clip add nothing.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/vs_amd.h"
+#include "synth_clip.hpp"
+
+namespace {
+
+struct Barrier {                       // (std::barrier is C++20)
+    explicit Barrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const int gen = gen_;
+        if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen != gen_; });
+    }
+    std::mutex mu_; std::condition_variable cv_; int n_, count_ = 0, gen_ = 0;
+};
+
+struct SlotResult { double seconds = 0; long long frames = 0, aligned = 0; std::string error; };
+
+bool parse_devices(const std::string& list, std::vector<int>& out) {
+    out.clear();
+    if (list == "all") { for (int d = 0; d < vs_device_count(); d++) out.push_back(d); return !out.empty(); }
+    size_t pos = 0;
+    while (pos <= list.size()) {
+        const size_t comma = std::min(list.find(',', pos), list.size());
+        const std::string tok = list.substr(pos, comma - pos);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) return false;
+        out.push_back(std::atoi(tok.c_str()));
+        pos = comma + 1;
+    }
+    return !out.empty();
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::vector<int> devices = {0};
+    int clips = 64, frames = 120, w = 1920, h = 1080, steps = 3, min_width = 256;
+    bool exact = false, warp = true;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
+        const char* v = nullptr;
+        if (a == "--devices") { if (!(v = next()) || !parse_devices(v, devices)) { std::fprintf(stderr, "Error: --devices a,b,...|all\n"); return 1; } }
+        else if (a == "--clips") { if (!(v = next())) return 1; clips = std::atoi(v); }
+        else if (a == "--frames") { if (!(v = next())) return 1; frames = std::atoi(v); }
+        else if (a == "--steps") { if (!(v = next())) return 1; steps = std::atoi(v); }
+        else if (a == "--min-width") { if (!(v = next())) return 1; min_width = std::atoi(v); }
+        else if (a == "--size") { if (!(v = next()) || std::sscanf(v, "%dx%d", &w, &h) != 2) { std::fprintf(stderr, "Error: --size WxH\n"); return 1; } }
+        else if (a == "--exact") exact = true;
+        else if (a == "--no-warp") warp = false;
+        else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--exact] [--no-warp]\n", argv[0]); return 1; }
+    }
+    const int G = (int)devices.size();
+    if (clips < 1 || frames < 2 || steps < 1 || w < 64 || h < 64) { std::fprintf(stderr, "Error: bad sizes\n"); return 1; }
+    for (int d : devices) if (d < 0 || d >= vs_device_count()) { std::fprintf(stderr, "Error: no HIP device %d\n", d); return 1; }
+    if (vs_abi_version() != VS_ABI_VERSION) { std::fprintf(stderr, "Error: libvs_amd ABI %d, built for %d\n", vs_abi_version(), VS_ABI_VERSION); return 1; }
+
+    // ---- one synthetic clip on the host ----
+    const size_t fs = (size_t)w * h * 3;
+    std::vector<uint8_t> host(fs * frames);
+    {
+        const std::vector<float> tex = vssynth::base_texture(w + 2 * vssynth::kMargin, h + 2 * vssynth::kMargin);
+        const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++)
+            th.emplace_back([&, t] {
+                std::vector<uint8_t> f(fs);
+                for (int i = t; i < frames; i += nthreads) { vssynth::make_clip_frame(f, tex, w, h, i); std::memcpy(&host[fs * i], f.data(), fs); }
+            });
+        for (auto& t : th) t.join();
+    }
+
+    std::vector<SlotResult> res((size_t)G);
+    Barrier barrier(G);
+    const int mode = exact ? VS_WARP_LANCZOS2 : VS_WARP_LANCZOS2_FAST;
+    auto slot = [&](int g) {
+        SlotResult& r = res[(size_t)g];
+        const int dev = devices[(size_t)g];
+        int mine = 0;
+        for (int c = g; c < clips; c += G) mine++;                  // clip i -> slot i mod G
+        uint8_t *in = nullptr, *out = nullptr;
+        vs_aligner* a = nullptr;
+        hipStream_t ws = nullptr;
+        auto fail = [&](const std::string& what) { if (r.error.empty()) r.error = what; };
+        const int n = mine * frames;
+        std::vector<vs_transform> t((size_t)std::max(n, 1));
+        std::vector<int32_t> st((size_t)std::max(n, 1));
+        if (mine > 0) {
+            if (hipSetDevice(dev) != hipSuccess) fail("hipSetDevice");
+            if (r.error.empty() && hipMalloc((void**)&in, fs * n) != hipSuccess) fail("hipMalloc (clips)");
+            if (r.error.empty() && warp && hipMalloc((void**)&out, fs * n) != hipSuccess) fail("hipMalloc (outputs)");
+            if (r.error.empty() && hipMemcpy(in, host.data(), fs * frames, hipMemcpyHostToDevice) != hipSuccess) fail("hipMemcpy H2D");
+            for (int c = 1; r.error.empty() && c < mine; c++)
+                if (hipMemcpy(in + fs * frames * c, in, fs * frames, hipMemcpyDeviceToDevice) != hipSuccess) fail("hipMemcpy D2D");
+            vs_aligner_params p;
+            vs_aligner_params_default(&p);
+            p.pyramid_min_width = min_width;
+            if (r.error.empty() && !(a = vs_aligner_create(&p, dev))) fail(std::string("vs_aligner_create: ") + vs_last_error());
+            if (r.error.empty() && warp) vs_aligner_set_batch_mode(a, VS_BATCH_SHARED);
+            if (r.error.empty() && hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) fail("hipStreamCreate");
+        }
+        auto step = [&]() -> int {
+            const int good = vs_aligner_align_clips(a, in, fs, mine, frames, w, h, 3 * w, VS_FMT_BGR8, VS_MEM_DEVICE, nullptr, t.data(), st.data());
+            if (good < 0) { fail(std::string("vs_aligner_align_clips: ") + vs_last_error()); return -1; }
+            if (warp && vs_bgr_image_warp_batch(in, fs, n, w, h, 3 * w, 3, 8, t.data(), mode, VS_BORDER_CLAMP, 255, out, fs, 3 * w, VS_MEM_DEVICE, ws) < 0) {
+                fail(std::string("vs_bgr_image_warp_batch: ") + vs_last_error());
+                return -1;
+            }
+            return good;
+        };
+        if (mine > 0 && r.error.empty()) { step(); (void)hipDeviceSynchronize(); }          // warm: allocations, clocks
+        barrier.wait();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; mine > 0 && r.error.empty() && k < steps; k++) {
+            const int good = step();
+            if (good < 0) break;
+            r.frames += n; r.aligned += good;
+        }
+        if (mine > 0) (void)hipDeviceSynchronize();
+        r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        barrier.wait();
+        if (ws) { (void)vs_stream_retire(ws); (void)hipStreamDestroy(ws); }
+        if (a) vs_aligner_destroy(a);
+        if (in) (void)hipFree(in);
+        if (out) (void)hipFree(out);
+    };
+    std::vector<std::thread> threads;
+    const auto j0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; g++) threads.emplace_back(slot, g);
+    for (auto& t : threads) t.join();
+    const double job = std::chrono::duration<double>(std::chrono::steady_clock::now() - j0).count();
+
+    double slowest = 0;
+    long long total_frames = 0, total_aligned = 0;
+    for (const SlotResult& r : res) {
+        if (!r.error.empty()) { std::fprintf(stderr, "Error: %s\n", r.error.c_str()); return 1; }
+        slowest = std::max(slowest, r.seconds);
+        total_frames += r.frames; total_aligned += r.aligned;
+    }
+    std::printf("{\"program\": \"vs_many_clips\", \"host\": \"C++ threads, one per device slot\", \"devices\": [");
+    for (int g = 0; g < G; g++) std::printf("%s%d", g ? ", " : "", devices[(size_t)g]);
+    std::printf("], \"clips\": %d, \"frames_per_clip\": %d, \"width\": %d, \"height\": %d, \"steps\": %d, \"warp\": \"%s\", \"scaling\": \"strong\", ", clips, frames, w, h,
+                steps, warp ? (exact ? "lanczos2" : "lanczos2 contracted") : "none");
+    std::printf("\"value\": %.2f, \"unit\": \"aligned frames/s\", \"frames_per_s\": %.2f, \"seconds\": %.5f, \"per_slot_seconds\": [", total_aligned / slowest,
+                total_frames / slowest, slowest);
+    for (int g = 0; g < G; g++) std::printf("%s%.5f", g ? ", " : "", res[(size_t)g].seconds);
+    std::printf("], \"per_slot_clips\": [");
+    for (int g = 0; g < G; g++) { int m = 0; for (int c = g; c < clips; c += G) m++; std::printf("%s%d", g ? ", " : "", m); }
+    std::printf("], \"aligned_per_step\": %lld, \"setup_and_run_seconds\": %.2f}\n", total_aligned / steps, job);
+    return 0;
+}

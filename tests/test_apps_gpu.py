@@ -181,6 +181,25 @@ def test_grid_search_align(gpu_vs, clip):
     assert abs(float(m.group(2)) - j_out / j_in) <= 1e-4
 
 
+def test_grid_search_device_split_reproduces_the_single_device_search(gpu_vs, clip):
+    """--devices a,b,...: the C++ many-clip split (worker t -> device slot t mod G, the clip uploaded once per slot, handles per
+    worker: the independence model of grid_search_align.cpp:159-210).  The one-GPU box rehearses it with `--devices 0,0` -- two
+    slots with their own clip copies and workers; every combination's ratio must equal the single-device search's, bit for bit
+    (same frames, same handles' arithmetic, no state shared between workers), whichever worker got which combination."""
+    d, frames, raw = clip
+    one = run("vs_grid_search_align", raw, "-j", 2, "--frames", 24, "--dump-ratios")
+    two = run("vs_grid_search_align", raw, "-j", 4, "--frames", 24, "--devices", "0,0", "--dump-ratios")
+    r1 = re.findall(r"^RATIO (\d+) (\S+)$", one, re.M)
+    r2 = re.findall(r"^RATIO (\d+) (\S+)$", two, re.M)
+    assert len(r1) == 54 and r1 == r2
+    assert re.search(r"Best params: .*", one).group(0) == re.search(r"Best params: .*", two).group(0)
+    assert "Device split: 2 slots, 4 workers" in two and "Device split" not in one
+    per_slot = [int(x) for x in re.findall(r"^  slot \d+ \(device 0\): (\d+) combinations", two, re.M)]
+    assert len(per_slot) == 2 and sum(per_slot) == 54 and min(per_slot) >= 1
+    out = subprocess.run([os.path.join(BIN, "vs_grid_search_align"), str(raw), "--devices", "0,7"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "No HIP device 7" in out.stderr
+
+
 def test_grid_search_smoother_quick(gpu_vs, clip):
     d, frames, raw = clip
     out = run("vs_grid_search_smoother", raw, "-j", 2, "--quick")
@@ -242,3 +261,18 @@ def test_latency_harness_aligns_every_frame_of_its_clip(gpu_vs, clip):
         out = json.loads(run("vs_latency", *args).strip().splitlines()[-1])
         assert out["w"] == args[0] and out["frames"] == args[2] and out["aligned"] == args[2] - 1
         assert 3 <= out["gn_iterations_per_frame"] <= 60 and out["ms_per_call"] > 0
+
+
+def test_many_clips_cpp_harness_splits_clips_over_device_slots(gpu_vs, clip):
+    """apps/vs_many_clips: BASELINE configs[3] with the host side in C++ -- one thread per device slot, clip i -> slot i mod G, no
+    exchange, per-slot seconds.  Two slots on the one GPU here; the frames aligned must not depend on the split."""
+    import json
+    one = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2).strip().splitlines()[-1])
+    two = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--devices", "0,0").strip().splitlines()[-1])
+    assert one["devices"] == [0] and one["per_slot_clips"] == [5] and len(one["per_slot_seconds"]) == 1
+    assert two["devices"] == [0, 0] and two["per_slot_clips"] == [3, 2] and len(two["per_slot_seconds"]) == 2
+    assert one["aligned_per_step"] == two["aligned_per_step"] == 5 * 11          # every frame but each clip's first
+    for j in (one, two):
+        assert j["value"] > 0 and j["scaling"] == "strong" and j["seconds"] == max(j["per_slot_seconds"]) and j["warp"] == "lanczos2 contracted"
+    out = subprocess.run([os.path.join(BIN, "vs_many_clips"), "--devices", "0,9"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no HIP device 9" in out.stderr

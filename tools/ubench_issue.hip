@@ -40,6 +40,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // one ds_read_b128 (conflict-free: lane * 16 bytes) -- LDS issue beside the vector stream
 #define L(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i & 3]) : "v"(laddr), "n"(((i) & 7) * 1024));
 #define LW asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+// v_fma_mix_f32: fp32 fma whose second source is a HALF taken from the low / high 16 bits of a register (converted exactly), so
+// that an LDS tile kept in fp16 (u8 / 10-bit samples are exact in fp16) needs half the ds_read traffic and no conversion
+#define FM(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(a[i]) : "v"(m), "v"(hq[(i) & 7]));
+#define FMH(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a[i]) : "v"(m), "v"(hq[(i) & 7]));
+#define L64(i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(h2[i & 3]) : "v"(laddr8), "n"(((i) & 7) * 512));
+#define L128H(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[i & 3]) : "v"(laddr), "n"(((i) & 7) * 1024));
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 struct Stamp { unsigned long long t0, t1, r0, r1; };
@@ -47,7 +53,7 @@ struct Stamp { unsigned long long t0, t1, r0, r1; };
 template <int KIND>
 __global__ __launch_bounds__(256) void k(Stamp* stamps, unsigned long long* out, float seed) {
     __shared__ f4 lds[2048];                                           // 32 KB
-    float a[16], b[16]; f2 p[16]; unsigned ui[16]; f4 q[4];
+    float a[16], b[16]; f2 p[16]; unsigned ui[16]; f4 q[4]; f2 h2[4]; unsigned hq[8];
 #pragma unroll
     for (int i = 0; i < 16; i++) { a[i] = seed + i + threadIdx.x; b[i] = seed * i; p[i] = f2{a[i], b[i]}; ui[i] = threadIdx.x * 17 + i; }
     for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = f4{seed, seed, seed, seed};
@@ -55,6 +61,11 @@ __global__ __launch_bounds__(256) void k(Stamp* stamps, unsigned long long* out,
     for (int i = 0; i < 4; i++) q[i] = f4{0, 0, 0, 0};
     __syncthreads();
     const unsigned laddr = (unsigned)(uintptr_t)lds + (threadIdx.x & 63) * 16;
+    const unsigned laddr8 = (unsigned)(uintptr_t)lds + (threadIdx.x & 63) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) h2[i] = f2{0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) hq[i] = 0x3c003c00u + threadIdx.x;
     float m = seed * 0.5f + 1.0f, c = seed + 0.25f;
     f2 pm = {m, m + 1.f}, pc = {c, c + 1.f};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -88,6 +99,12 @@ __global__ __launch_bounds__(256) void k(Stamp* stamps, unsigned long long* out,
         if (KIND == 25) { L(0) L(1) L(2) L(3) REP16(F) LW }
         if (KIND == 26) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) LW }                          // LDS reads alone: 8 per iteration
         if (KIND == 27) { L(0) P(0) P(1) L(1) P(2) P(3) L(2) P(4) P(5) L(3) P(6) P(7) LW }     // the exact kernel: one read per 2 packed (4 flops-pairs)
+        if (KIND == 28) { REP16(FM) }
+        if (KIND == 29) { FM(0) FMH(1) FM(2) FMH(3) FM(4) FMH(5) FM(6) FMH(7) FM(8) FMH(9) FM(10) FMH(11) FM(12) FMH(13) FM(14) FMH(15) }
+        // an fp16 tile: one ds_read_b64 per tap ({B,G,R,1} as four halves), or one ds_read_b128 per TWO taps
+        if (KIND == 30) { L64(0) FM(0) FMH(1) FM(2) FMH(3) L64(1) FM(4) FMH(5) FM(6) FMH(7) L64(2) FM(8) FMH(9) FM(10) FMH(11) L64(3) FM(12) FMH(13) FM(14) FMH(15) LW }
+        if (KIND == 31) { L128H(0) FM(0) FMH(1) FM(2) FMH(3) FM(4) FMH(5) FM(6) FMH(7) L128H(1) FM(8) FMH(9) FM(10) FMH(11) FM(12) FMH(13) FM(14) FMH(15) LW }
+        if (KIND == 32) { L(0) F(0) F(1) F(2) A(3) L(1) F(4) F(5) F(6) A(7) L(2) F(8) F(9) F(10) A(11) L(3) F(12) F(13) F(14) A(15) LW }   // the contracted kernel's tap: read, 3 fma, 1 add
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1, r0, r1};
@@ -95,7 +112,9 @@ __global__ __launch_bounds__(256) void k(Stamp* stamps, unsigned long long* out,
 #pragma unroll
     for (int i = 0; i < 16; i++) s += a[i] + b[i] + p[i].x + p[i].y + (float)ui[i];
 #pragma unroll
-    for (int i = 0; i < 4; i++) s += q[i].x + q[i].y + q[i].z + q[i].w;
+    for (int i = 0; i < 4; i++) s += q[i].x + q[i].y + q[i].z + q[i].w + h2[i].x + h2[i].y;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += (float)hq[i];
     if (s == 12345.678f) out[0] = 1;
 }
 
@@ -142,5 +161,8 @@ int main() {
     run<22>("mul -> add dependent pairs, 8 chains", 16, st, d); run<23>("pk_mul -> pk_add dependent pairs, 8 chains", 16, st, d);
     run<24>("[ds_read_b128 + 4 fma] x4 + wait (20 instr)", 20, st, d); run<25>("4 ds_read_b128, 16 fma, wait (20 instr)", 20, st, d);
     run<26>("8 ds_read_b128 + wait (8 instr)", 8, st, d); run<27>("[ds_read_b128 + 2 pk_fma] x4 + wait (12 instr)", 12, st, d);
+    run<28>("v_fma_mix_f32 (f16 lo source) x16", 16, st, d); run<29>("v_fma_mix_f32 lo / hi alternating x16", 16, st, d);
+    run<30>("[ds_read_b64 + 4 fma_mix] x4 + wait (20 instr)", 20, st, d); run<31>("[ds_read_b128 + 8 fma_mix] x2 + wait (18 instr)", 18, st, d);
+    run<32>("[ds_read_b128 + 3 fma + add] x4 + wait (20 instr)", 20, st, d);
     return 0;
 }

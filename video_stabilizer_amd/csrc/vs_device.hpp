@@ -9,6 +9,50 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- debug build with bounds-checked LDS / scratch indexing (-DVS_DEBUG_BOUNDS, tools/build_variant.sh bounds) ----------------
+// GPU AddressSanitizer is not available on this pool, so the index arithmetic of the LDS-tiled kernels has no other net.  In the
+// debug build the arrays the kernels carve out of LDS (and the per-pair scratch in global memory) are wrapped in vsd::Span:
+// every operator[] checks its index against the extent the carving code derived, records the FIRST violation of the
+// translation unit in a device word (site id, index, limit, workgroup, thread) and performs the access on element 0 instead --
+// a violation is reported, never executed: nothing faults, the kernel finishes, and vs_debug_bounds_check() (include/vs_amd.h)
+// hands the record to the host.  (No trap: on this pool a trapping wave can take the whole node down.)  In the regular build
+// VS_SPAN declares the plain restrict pointer the code had before, so the shipped kernels are unchanged instruction for instruction.
+// Site ids: 1xx vs_align_kernels.inc (selection, gather, exchange, staging), 2xx vs_warp.hip, 3xx vs_phase.hip.
+#ifdef VS_DEBUG_BOUNDS
+namespace vsd {
+static __device__ unsigned int g_bounds_rec[8];      // [0] violations, [1] site, [2] index (low 32 bits), [3] limit, [4] blockIdx.x, [5] threadIdx.x
+__device__ __forceinline__ bool bounds_ok(long long i, long long n, int site) {
+    if (i >= 0 && i < n) return true;
+    if (atomicAdd(&g_bounds_rec[0], 1u) == 0u) {
+        g_bounds_rec[1] = (unsigned)site; g_bounds_rec[2] = (unsigned)i; g_bounds_rec[3] = (unsigned)n;
+        g_bounds_rec[4] = blockIdx.x; g_bounds_rec[5] = threadIdx.x;
+    }
+    return false;
+}
+template <typename P>
+struct Span {
+    P p; long long n; int site;
+    __device__ __forceinline__ decltype(auto) operator[](long long i) const { return p[bounds_ok(i, n, site) ? i : 0]; }
+    __device__ __forceinline__ P raw() const { return p; }
+};
+}  // namespace vsd
+#define VS_SPAN(ptr_type, name, expr, extent, site) const vsd::Span<ptr_type> name{(ptr_type)(expr), (long long)(extent), (site)}
+#define VS_SPAN_RAW(name) ((name).raw())
+#define VS_BOUNDS_CHECK(i, extent, site) ((void)vsd::bounds_ok((long long)(i), (long long)(extent), (site)))
+// the host-side reader of this translation unit's record (defined once per .hip file: the record is per translation unit)
+#define VS_BOUNDS_TU(fn)                                                                                                \
+    extern "C" int fn(unsigned out[8], int reset) {                                                                     \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vsd::g_bounds_rec), sizeof(unsigned) * 8) != hipSuccess) return -1;      \
+        if (reset) { const unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(vsd::g_bounds_rec), z, sizeof(z)); } \
+        return 0;                                                                                                       \
+    }
+#else
+#define VS_SPAN(ptr_type, name, expr, extent, site) ptr_type __restrict__ name = (ptr_type)(expr)
+#define VS_SPAN_RAW(name) (name)
+#define VS_BOUNDS_CHECK(i, extent, site) ((void)0)
+#define VS_BOUNDS_TU(fn)
+#endif
+
 namespace vsd {
 
 constexpr int kWave = 64;
