@@ -232,6 +232,16 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
  * call it.  tests/test_alloc_failure_gpu.py walks k over every allocation of the engine-level calls. */
 int vs_test_fail_alloc(int k);
 
+/* Debug build only (tools/build_variant.sh bounds: -DVS_DEBUG_BOUNDS; the reference's "bounds asserts in debug kernels").
+ * In that build the LDS / scratch arrays of the selection, gather, exchange, warp-tile and FFT-line code are indexed through a
+ * checked accessor: an out-of-range index is recorded (first one per source file: site id, index, limit, workgroup, thread) and
+ * the access is redirected to element 0 -- reported, never executed, nothing traps.  vs_debug_bounds_check() synchronises the
+ * device, returns the number of violations since the previous call (0 = clean) with the first one described in vs_last_error(),
+ * and clears the record.  vs_debug_bounds_selftest() commits one violation on purpose (site 900, index 11 of 8) and returns 202.
+ * In the regular library both return VS_ERR_UNSUPPORTED, and the kernels carry no checks (identical instruction streams). */
+int vs_debug_bounds_check(void);
+int vs_debug_bounds_selftest(void);
+
 /* Profiling aid, not part of the reference's surface: device-to-device copy of floor(bytes/12)*12 bytes
  * with 12-byte accesses per lane, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for the warp
  * kernel's access width (tools/calibrate_counters.py). */

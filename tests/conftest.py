@@ -42,3 +42,15 @@ def gpu_vs(vs):
     if vs.device_count() < 1:
         pytest.fail("gpu-marked test but libvs_amd sees no HIP device")
     return vs
+
+
+# ---- the debug build with bounds-checked LDS / scratch indexing (tests/test_bounds_build_gpu.py runs a pytest of its own with
+# VS_AMD_LIB pointing at variants/libvs_amd_bounds.so and VS_BOUNDS_BUILD=1): after EVERY test of that run the library's bounds
+# record must be clean, so a violation is pinned to the test that committed it
+@pytest.fixture(autouse=True)
+def _bounds_record_stays_clean(request):
+    yield
+    if os.environ.get("VS_BOUNDS_BUILD") == "1" and request.node.get_closest_marker("gpu") is not None:
+        from video_stabilizer_amd import capi
+        n, first = capi.debug_bounds_check()
+        assert n == 0, "out-of-bounds index in a kernel of the bounds build during this test: %s" % first

@@ -267,8 +267,8 @@ def test_many_clips_cpp_harness_splits_clips_over_device_slots(gpu_vs, clip):
     """apps/vs_many_clips: BASELINE configs[3] with the host side in C++ -- one thread per device slot, clip i -> slot i mod G, no
     exchange, per-slot seconds.  Two slots on the one GPU here; the frames aligned must not depend on the split."""
     import json
-    one = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2).strip().splitlines()[-1])
-    two = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--devices", "0,0").strip().splitlines()[-1])
+    one = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64).strip().splitlines()[-1])
+    two = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64, "--devices", "0,0").strip().splitlines()[-1])
     assert one["devices"] == [0] and one["per_slot_clips"] == [5] and len(one["per_slot_seconds"]) == 1
     assert two["devices"] == [0, 0] and two["per_slot_clips"] == [3, 2] and len(two["per_slot_seconds"]) == 2
     assert one["aligned_per_step"] == two["aligned_per_step"] == 5 * 11          # every frame but each clip's first

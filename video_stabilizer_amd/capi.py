@@ -84,6 +84,8 @@ SIGNATURES = {
     "vs_abi_version": (_i32, []),
     "vs_sizeof_align_info": (_sz, []),
     "vs_test_fail_alloc": (_i32, [_i32]),
+    "vs_debug_bounds_check": (_i32, []),
+    "vs_debug_bounds_selftest": (_i32, []),
     "vs_device_count": (_i32, []),
     "vs_stream_retire": (_i32, [_vp]),
     "vs_format_bits": (_i32, [_i32]),
@@ -192,6 +194,14 @@ def _c(a, dtype):
 
 def device_count():
     return lib().vs_device_count()
+
+
+def debug_bounds_check():
+    """bounds build only: violations since the last call (0 = clean); raises VsError in the regular library"""
+    r = lib().vs_debug_bounds_check()
+    if r < 0:
+        raise VsError("vs_amd error %d: %s" % (r, lib().vs_last_error().decode()))
+    return r, (lib().vs_last_error().decode() if r else "")
 
 
 def test_fail_alloc(k):

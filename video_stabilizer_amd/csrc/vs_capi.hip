@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -235,6 +236,64 @@ extern "C" {
 int vs_stream_retire(void* stream) {
     VS_HIP(vsi::retire_stream((hipStream_t)stream));      // a fault of the work that was in flight on the stream surfaces here
     return VS_OK;
+}
+
+// ---- the debug build's bounds record (vs_device.hpp, -DVS_DEBUG_BOUNDS) ---------------------------------------------------
+#ifdef VS_DEBUG_BOUNDS
+}  // extern "C"
+#include "vs_device.hpp"
+extern "C" int vs_bounds_fetch_engine(unsigned out[8], int reset);
+extern "C" int vs_bounds_fetch_warp(unsigned out[8], int reset);
+extern "C" int vs_bounds_fetch_phase(unsigned out[8], int reset);
+namespace {
+// the checker checked: element 11 of an 8-element LDS array through a Span -- reported under site 900, executed on element 0
+__global__ void vs_k_bounds_selftest(int* out) {
+    __shared__ int arr[8];
+    if (threadIdx.x < 8) arr[threadIdx.x] = 100 + (int)threadIdx.x;
+    __syncthreads();
+    VS_SPAN(int*, a, arr, 8, 900);
+    if (threadIdx.x == 3) out[0] = a[11] + a[2];          // 100 (element 0 stands in) + 102
+}
+}  // namespace
+VS_BOUNDS_TU(vs_bounds_fetch_capi)
+extern "C" {
+#endif
+
+int vs_debug_bounds_check(void) {
+#ifdef VS_DEBUG_BOUNDS
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    VS_HIP(hipDeviceSynchronize());
+    int (*const fetch[])(unsigned*, int) = {vs_bounds_fetch_engine, vs_bounds_fetch_warp, vs_bounds_fetch_phase, vs_bounds_fetch_capi};
+    const char* const names[] = {"vs_engine.hip", "vs_warp.hip", "vs_phase.hip", "vs_capi.hip"};
+    unsigned total = 0;
+    char msg[512] = "";
+    for (int k = 0; k < 4; k++) {
+        unsigned r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (fetch[k](r, 1) != 0) return set_error(VS_ERR_HIP, "bounds record of %s is not readable", names[k]);
+        if (r[0] && !total)
+            snprintf(msg, sizeof msg, "%s: site %u, index %d, limit %u, workgroup %u, thread %u", names[k], r[1], (int)r[2], r[3], r[4], r[5]);
+        total += r[0];
+    }
+    if (total) set_error(VS_ERR_STATE, "%u out-of-bounds index(es) since the last check; first: %s", total, msg);
+    return (int)std::min<unsigned>(total, 0x7fffffffu);
+#else
+    return set_error(VS_ERR_UNSUPPORTED, "vs_debug_bounds_check: this is not a -DVS_DEBUG_BOUNDS build of libvs_amd (tools/build_variant.sh bounds)");
+#endif
+}
+
+int vs_debug_bounds_selftest(void) {
+#ifdef VS_DEBUG_BOUNDS
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    vsi::DevBuf out;
+    VS_HIP(out.alloc(sizeof(int)));
+    hipLaunchKernelGGL(vs_k_bounds_selftest, dim3(1), dim3(64), 0, nullptr, out.as<int>());
+    VS_HIP(hipGetLastError());
+    int v = 0;
+    VS_HIP(hipMemcpy(&v, out.p, sizeof(int), hipMemcpyDeviceToHost));
+    return v;                                  // 202 when the violating access was redirected to element 0
+#else
+    return set_error(VS_ERR_UNSUPPORTED, "vs_debug_bounds_selftest: this is not a -DVS_DEBUG_BOUNDS build of libvs_amd");
+#endif
 }
 
 int vs_test_fail_alloc(int k) {

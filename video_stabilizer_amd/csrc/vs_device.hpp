@@ -38,7 +38,11 @@ struct Span {
 }  // namespace vsd
 #define VS_SPAN(ptr_type, name, expr, extent, site) const vsd::Span<ptr_type> name{(ptr_type)(expr), (long long)(extent), (site)}
 #define VS_SPAN_RAW(name) ((name).raw())
+#define VS_ARR(ptr_type) const vsd::Span<ptr_type>&          /* an array parameter */
 #define VS_BOUNDS_CHECK(i, extent, site) ((void)vsd::bounds_ok((long long)(i), (long long)(extent), (site)))
+#define VS_DEBUG_CLAMP(i, extent) (min(max((i), 0), (extent) - 1))      /* a reported index is not used as it stands */
+/* a byte offset that must lie in [0, extent): checked, reported under `site`, clamped */
+#define VS_DEBUG_CLAMP_BYTES(off, extent, site) (vsd::bounds_ok((off), (extent), (site)) ? (off) : 0)
 // the host-side reader of this translation unit's record (defined once per .hip file: the record is per translation unit)
 #define VS_BOUNDS_TU(fn)                                                                                                \
     extern "C" int fn(unsigned out[8], int reset) {                                                                     \
@@ -49,7 +53,10 @@ struct Span {
 #else
 #define VS_SPAN(ptr_type, name, expr, extent, site) ptr_type __restrict__ name = (ptr_type)(expr)
 #define VS_SPAN_RAW(name) (name)
+#define VS_ARR(ptr_type) ptr_type __restrict__
 #define VS_BOUNDS_CHECK(i, extent, site) ((void)0)
+#define VS_DEBUG_CLAMP(i, extent) (i)
+#define VS_DEBUG_CLAMP_BYTES(off, extent, site) (off)
 #define VS_BOUNDS_TU(fn)
 #endif
 

@@ -294,6 +294,8 @@ constexpr int kPipelineMaxPairs = 128;   // half the CUs   // largest level hand
 
 }  // namespace
 
+VS_BOUNDS_TU(vs_bounds_fetch_engine)
+
 // =================================================================================================
 // VideoAligner
 // =================================================================================================

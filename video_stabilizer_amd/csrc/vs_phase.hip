@@ -18,6 +18,7 @@
 
 #include "vs_phase.hpp"
 #include "vs_internal.hpp"
+#include "vs_device.hpp"
 
 namespace {
 
@@ -42,7 +43,10 @@ __device__ __forceinline__ void fft_pass(const float2* __restrict__ src, float2*
     for (int idx = threadIdx.x; idx < nb * per; idx += kThreads) {
         const int t = per > 1 ? (int)__umulhi((uint32_t)idx, inv_per) : idx, bf = idx - t * per;
         const int p = s > 1 ? (int)__umulhi((uint32_t)bf, inv_s) : bf, q = bf - p * s;
-        const float2* in = src + t * n + q + s * p;
+        VS_BOUNDS_CHECK(t * n + q + s * p + s * m * (R - 1), nb * n, 301);        // the butterfly's last input
+        VS_BOUNDS_CHECK(t * n + q + s * (R * p) + s * (R - 1), nb * n, 302);      // ... and last output, inside the nb lines
+        VS_BOUNDS_CHECK(p * (R - 1) * tstep, n, 303);                              // twiddle table
+        const float2* in = src + t * n + q + s * p;          // (record only: an LDS access past the block does not fault)
         float2* out = dst + t * n + q + s * (R * p);
         float2 a[R], b[R];
 #pragma unroll
@@ -281,6 +285,8 @@ __global__ __launch_bounds__(kThreads) void vs_k_phase_peak(const float* __restr
 }
 
 }  // namespace
+
+VS_BOUNDS_TU(vs_bounds_fetch_phase)
 
 namespace vsp {
 

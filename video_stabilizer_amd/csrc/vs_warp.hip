@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
             if (!live[s]) continue;
-            f4* t = tile + it[s].row * WS_RS + 4 * it[s].g;
+            VS_BOUNDS_CHECK(it[s].row * WS_RS + 4 * it[s].g + 3, WS_H * WS_RS, 201);     // four staged pixels of one fill item
+            f4* t = tile + VS_DEBUG_CLAMP(it[s].row * WS_RS + 4 * it[s].g, WS_H * WS_RS - 3);
             if (direct[s]) {
                 if (sizeof(T) == 1) {
                     const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
@@ -539,7 +540,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         const float Wy = Bx + A1 * fy + TY;                  // generators.cpp:142
         const float flx = floorf(Wx), fly = floorf(Wy);
         fr_all[k] = f2{Wx - flx, Wy - fly};
-        const int boff = (int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0));
+        // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
+        const int boff = VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
+                                              16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
         t_all[k] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
     }
 #if VS_WARP_COORDS_FIRST
@@ -660,6 +663,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 }
 
 }  // namespace
+
+VS_BOUNDS_TU(vs_bounds_fetch_warp)
 
 namespace vsk {
 
