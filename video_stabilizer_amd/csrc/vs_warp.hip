@@ -25,11 +25,14 @@
 // Tiles whose footprint does not fit the LDS window (large rotation / zoom) take the generic
 // global-memory path inside the same kernel, so every transform is supported.
 //
-// Cost model (DESIGN.md "bgr_image_warp roofline", tools/ubench_valu.hip): the kernel is VALU-bound, not
-// HBM-bound.  Measured issue cost on gfx950 with >= 2 waves per SIMD (kernel time x 2.4 GHz / instructions):
-// v_fma/mul/add_f32 2.7 cycles, v_pk_{fma,mul,add}_f32 4.9, conversions / v_perm / v_med3 4.3-4.5, v_rcp 8.2.
-// The exact mode needs 248 separately rounded fp32 operations per pixel (112 Horner, 16 weight products, 96 tap
-// multiply / adds, 16 den adds, 8 selects) = 128 packed instructions = 632 cycles per 64 pixels before any overhead.
+// Cost model (tools/ubench_issue.hip, profiles/r04_ubench_issue.txt): the kernel is VALU-issue-bound, not
+// HBM-bound.  Issue cost per instruction per SIMD on gfx950 at settled clocks (in-kernel clock 2.37-2.40 GHz, 4 waves per SIMD,
+// wall time x in-kernel clock / instructions): v_fma_f32 2.8 cycles (4.3 with 2 waves), v_mul / v_add_f32 2.5, v_pk_{fma,mul,add}_f32
+// 4.4-4.8 (= 2.2-2.4 per lane-operation: packed wins for the exact mode's separately rounded mul -> add pairs, 3.1 scalar), a mix
+// of scalar and packed fp32 4.3-4.6 per instruction (worse than either pure stream), conversions / v_perm / v_med3 / v_floor / DPP
+// 4.2-4.5, v_rcp 8.2, v_fma_mix_f32 4.4 (an fp16 tile buys nothing); ds_read_b128 4.1 cycles per CU (16.5 per SIMD when all
+// four SIMDs read).  The exact mode needs 248 separately rounded fp32 operations per pixel (112 Horner, 16 weight products, 96 tap
+// multiply / adds, 16 den adds, 8 selects) = 128 packed instructions = ~590 cycles per 64 pixels before any overhead.
 #include "vs_kernels.hpp"
 #include <algorithm>
 #include <cmath>
@@ -64,6 +67,12 @@ namespace {
 #endif
 #ifndef VS_WARP_ROW_BLOCK
 #define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
+#endif
+#ifndef VS_WARP_FAST_PIPE
+#define VS_WARP_FAST_PIPE 1              // contracted mode: 1 = the software-pipelined sampler (fast_rows_pipelined), 0 = row pairs (fast_pair); bit-identical
+#endif
+#ifndef VS_WARP_PIPE_AHEAD
+#define VS_WARP_PIPE_AHEAD 6             // ... tap reads in flight ahead of the tap being consumed (< 8: the ring has eight slots)
 #endif
 constexpr int WT_W = 64, WT_H = VS_WARP_TILE_H;      // output tile
 constexpr int RPW = WT_H / 4;            // output rows per wave
@@ -181,9 +190,10 @@ __device__ __forceinline__ void exact_pair(const lds_f4 t[2], const f2 fr[2], fl
 
 // VS_WARP_LANCZOS2_FAST of two output pixels: the contracted sampler of vs_device.hpp (oracle twin VSO_WARP_LANCZOS2_CONTRACTED)
 // written out for the LDS tile -- Horner steps as single fmas, w2d = wx * wy a rounded product, num = fma(w2d, val, num) per
-// channel and den = den + w2d in the reference's tap order (rx inner, ry outer).  Everything is scalar fp32: on gfx950 a packed
-// fp32 instruction costs the issue time of two scalar ones AND slows the scalar instructions around it (tools/ubench_mix.hip:
-// fma alone 3.2 cycles, pk_fma 5.6, a 3:1 mix 4.9 per instruction).  num[j] = {numB, numG, numR, den}; the caller divides.
+// channel and den = den + w2d in the reference's tap order (rx inner, ry outer).  Everything is scalar fp32: a packed fp32
+// instruction next to scalar ones costs more than either pure stream (profiles/r04_ubench_issue.txt: fma 2.8 cycles, pk_fma 4.8,
+// a 3:1 mix 4.6 per instruction).  num[j] = {numB, numG, numR, den}; the caller divides.  (Kept for VS_WARP_FAST_PIPE=0 and the
+// what-if builds; the shipped contracted kernel runs fast_rows_pipelined below.)
 __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], float num[2][4]) {
     // weight chain c of pixel j: 0..3 = x taps 1..4, 4..7 = y taps 1..4
     float x[2][8], x2[2][8], v[2][8];
@@ -228,6 +238,99 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
             }
         }
         if (VS_WARP_FAST_SCHED >= 2) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// VS_WARP_FAST_PIPE: the same contracted arithmetic for the RB = 4 pixels of a lane (rows k = 0..3), software-pipelined so that a wave's
+// LDS reads are spread evenly over ALL of its vector work instead of arriving in bursts.  In fast_pair a pixel pair is 150 vector
+// instructions of weight chains with no LDS traffic followed by 32 ds_read_b128 inside 160 instructions of tap arithmetic; the four
+// waves of a workgroup leave the fill barrier together, so their tap phases coincide and one workgroup alone asks for ~80 % of the
+// CU's LDS read rate during them (profiles/r04_ubench_issue.txt: a ds_read_b128 per 4 fmas is LDS-bound, 81 cycles per 4 taps
+// against 44 for the fmas).  Here stage k runs three things interleaved, slice by slice (16 slices, one tap each): the taps of pixel k,
+// the weight chains of pixel k + 1 and the division / store conversion of pixel k - 1 -- one ds_read_b128 per ~11 vector
+// instructions throughout, issued VS_WARP_PIPE_AHEAD taps ahead of their use through a ring of eight float4 registers.  Per pixel the
+// operations and their order are fast_pair's (weights: Horner fmas per chain; taps rx inner, ry outer; num = fma(w2d, val, num),
+// den = den + w2d; div3_core; store_u), so the result is bit-identical: the pipelining only decides WHEN an instruction issues.
+// Scheduling fences between the slices keep the compiler from undoing the interleave.
+template <int NPX>
+__device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
+                                                    uint32_t (&o)[NPX][3], bool& all_ok) {
+    constexpr int NV = 8, AHEAD = VS_WARP_PIPE_AHEAD;
+    static_assert(AHEAD >= 1 && AHEAD < NV && 16 % NV == 0, "ring of eight tap registers");
+    const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
+    f4 vals[NV];
+    float wgt[2][8];                 // finished weights: wgt[k & 1] belongs to pixel k (x taps 1..4, then y taps 1..4)
+    float wx_[8], wx2[8];            // the chains under construction: arguments, their squares (values in wgt[(k + 1) & 1])
+    float r_ = 0.f, q_[3] = {0.f, 0.f, 0.f};     // division state of pixel k - 1
+    // one slice of the weight chains of pixel kk (72 instructions in 16 slices)
+    auto w_slice = [&](int j, int kk) {
+        float (&v)[8] = wgt[kk & 1];
+        const float f = (j == 0) ? fr[kk].x : fr[kk].y;
+        if (j < 2) {
+            const int b = 4 * j;
+            wx_[b + 0] = -1.0f - f; wx_[b + 1] = 0.0f - f; wx_[b + 2] = 1.0f - f; wx_[b + 3] = 2.0f - f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { wx2[b + c] = wx_[b + c] * wx_[b + c]; v[b + c] = 0.000858519f; }
+        } else if (j < 14) {
+            const int step = (j - 2) >> 1, b = 4 * ((j - 2) & 1);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[b + c] = __builtin_fmaf(v[b + c], wx2[b + c], C[step]);
+        } else {
+            const int b = 4 * (j - 14);                      // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
+            v[b + 0] = fabsf(wx_[b + 0]) >= 2.0f ? 0.0f : v[b + 0];
+            v[b + 3] = fabsf(wx_[b + 3]) >= 2.0f ? 0.0f : v[b + 3];
+        }
+    };
+    // one slice of the division + store conversion of pixel kk (div3_core and store_u, 29 instructions in 7 slices)
+    auto d_slice = [&](int j, int kk) {
+        const float den = num[kk][3];
+        if (j == 0) {
+            all_ok = all_ok && (den > 0.5f && den < 2.0f);
+            r_ = __builtin_amdgcn_rcpf(den);
+            const float e = __builtin_fmaf(-den, r_, 1.0f);
+            r_ = __builtin_fmaf(e, r_, r_);
+        } else if (j == 2 || j == 4 || j == 6) {
+            const int c = (j - 2) >> 1;
+            const float n = num[kk][c];
+            float a = n * r_, tt = __builtin_fmaf(-den, a, n);
+            a = __builtin_fmaf(tt, r_, a); tt = __builtin_fmaf(-den, a, n);
+            q_[c] = __builtin_fmaf(tt, r_, a);
+        } else if (j == 8 || j == 10 || j == 12) {
+            const int c = (j - 8) >> 1;
+            o[kk][c] = store_u(q_[c], maxv);
+        }
+    };
+    // the tap read that is AHEAD slices in front of tap j of pixel kk (it may belong to pixel kk + 1)
+    auto issue = [&](int j, int kk) {
+        const int jj = j + AHEAD, kt = kk + (jj >> 4), tj = jj & 15;
+        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * WS_RS + (tj & 3)];
+    };
+    // ---- prologue: the first reads of pixel 0 in flight under its weight chains ----
+#pragma unroll
+    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * WS_RS + (j & 3)];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w_slice(j, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k <= NPX; k++) {
+        if (k < NPX) { num[k][0] = 0.0f; num[k][1] = 0.0f; num[k][2] = 0.0f; num[k][3] = 0.0f; }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (k < NPX) {
+                issue(j, k);
+                const f4 val = vals[j % NV];
+                const float w2d = wgt[k & 1][j & 3] * wgt[k & 1][4 + (j >> 2)];
+                num[k][0] = __builtin_fmaf(w2d, val.x, num[k][0]);
+                num[k][1] = __builtin_fmaf(w2d, val.y, num[k][1]);
+                num[k][2] = __builtin_fmaf(w2d, val.z, num[k][2]);
+                // den + w2d through the tile's trailing 1.0 (w2d * 1.0 is exact: the same sum): with val.w unused the register allocator
+                // recycles that quarter of an in-flight ds_read_b128's destination, and every such reuse drains the LDS queue
+                num[k][3] = __builtin_fmaf(w2d, val.w, num[k][3]);
+                if (k + 1 < NPX) w_slice(j, k + 1);
+            }
+            if (k >= 1) d_slice(j, k - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -548,6 +651,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
 #if VS_WARP_COORDS_FIRST
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    if (MODE == 2 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
+        fast_rows_pipelined<RB>(t_all, fr_all, maxv, num, o, all_ok);
+    } else
 #pragma unroll
     for (int kp = 0; kp < RB; kp += 2) {
         const f2 fr[2] = {fr_all[kp], fr_all[kp + 1]};
