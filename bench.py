@@ -217,7 +217,7 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     src = torch.randint(0, 256, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint8)
     dst = torch.empty_like(src)
     ts = [capi.Transform.of(0.002, -0.0015, 3.3 + 0.37 * i, -2.7 - 0.21 * i) for i in range(frames)]
-    pmc, pmc_name = load_profile("r03_warp_pmc.json", "r02_warp_pmc.json")
+    pmc, pmc_name = load_profile("r04_warp_pmc.json", "r03_warp_pmc.json", "r02_warp_pmc.json")
     out = {}
     for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted")):
         def run():
@@ -581,7 +581,7 @@ def main():
         # there is no profile for this frame format
         traffic, tname = None, None
         try:
-            tj, tname = load_profile("r03_traffic.json", "r02_traffic.json")
+            tj, tname = load_profile("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")
             key, per = {(1920, 8): ("c2_1080p_240_frames", 240), (3840, 8): ("c3_4k_32_frames", 32)}[(aw.W, aw.bits)]
             traffic = int(tj[key]["traffic_bytes"] / per * nframes_total)
         except Exception:

@@ -15,6 +15,7 @@ SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2
 DST = os.path.join(ROOT, "profiles")
 RN = sys.argv[2] if len(sys.argv) > 2 else "r02"        # round prefix of the files written
 SECOND = "fast" if RN == "r02" else "contracted"        # round 3: VS_WARP_LANCZOS2_FAST is the contracted form of the sampler
+VALUE_FORM = SECOND if RN >= "r04" else "exact"         # round 4: bench.py's `value` runs the contracted form
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
@@ -31,8 +32,11 @@ def counters(d, kernel="warp_c3"):
     return {k: v / n for k, v in agg.items()}
 
 
-for wl in ("c2", "c3"):
-    f = sorted(glob.glob(os.path.join(SRC, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
+for wl in ("c2", "c3", "c5", "default"):
+    found = sorted(glob.glob(os.path.join(SRC, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if not found:
+        continue
+    f = found[-1]
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "vs_k_" in r[0] or "vsp" in r[0]]     # the library's kernels (torch's generator kernels dropped)
     with open(os.path.join(DST, RN + "_bench_%s_kernel_stats.csv" % wl), "w", newline="") as o:
@@ -70,15 +74,16 @@ for name, m in (("exact", "lanczos2"), (SECOND, "fast")):
 json.dump(out, open(os.path.join(DST, RN + "_warp_pmc.json"), "w"), indent=1)
 
 fz, wz = counters("pmcF_c2")["FETCH_SIZE"], counters("pmcW_c2")["WRITE_SIZE"]
-tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2,clamp> per launch of 240 x 1080p frames (" + RN + " kernel), separate "
+tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2" + (" contracted" if RN >= "r04" else "") + ",clamp> per launch of 240 x 1080p frames (" + RN + " kernel), separate "
                   "--pmc FETCH_SIZE / WRITE_SIZE passes, counter unit KiB, FETCH_SIZE doubled (see " + RN + "_warp_pmc.json).",
       "c2_1080p_240_frames": {"fetch_size_kib_raw": int(fz), "write_size_kib": int(wz), "traffic_bytes": int((2 * fz + wz) * 1024),
                               "algorithmic_bytes": 1920 * 1080 * 3 * 2 * 240},
-      "c3_4k_32_frames": {"fetch_size_kib_raw": out["exact"]["fetch_size_kib_raw_32_frames"], "write_size_kib": out["exact"]["write_size_kib_32_frames"],
-                          "traffic_bytes": out["exact"]["traffic_bytes_per_frame"] * 32, "algorithmic_bytes": 3840 * 2160 * 3 * 2 * 32}}
+      "c3_4k_32_frames": {"fetch_size_kib_raw": out[VALUE_FORM]["fetch_size_kib_raw_32_frames"], "write_size_kib": out[VALUE_FORM]["write_size_kib_32_frames"],
+                          "traffic_bytes": out[VALUE_FORM]["traffic_bytes_per_frame"] * 32, "algorithmic_bytes": 3840 * 2160 * 3 * 2 * 32,
+                          "kernel_form": VALUE_FORM}}
 json.dump(tr, open(os.path.join(DST, RN + "_traffic.json"), "w"), indent=1)
 for f in ("host_fed_1080p.json", "host_fed_4k.json", "latency_1080p.json", "latency_4k.json", "latency_cpp.txt", "step_trace_shared.md",
-          "step_trace_exclusive.md", "pmc_align_summary.txt", "stats_c2x.json"):
+          "step_trace_exclusive.md", "pmc_align_summary.txt", "stats_c2x.json", "many_clips_cpp.jsonl"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, RN + "_" + f))
 for f, t in (("ubench_valu.txt", "r02_ubench_valu.txt"), ("ubench_mix.txt", "r02_ubench_mix.txt")):
