@@ -223,7 +223,7 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         def run():
             capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
                                              max_value=255, stream=stream.cuda_stream)
-        # The card's shader clock takes ~40 ms of continuous work to settle (tools/exp13.py: 64 -> 56 -> 49 us per frame over the
+        # The card's shader clock takes ~40 ms of continuous work to settle (tools/clock_settling.py: 64 -> 56 -> 49 us per frame over the
         # first 5 / 12 / 40 ms after an idle spell, flat from there on): launches back to back for >= 80 ms first, then `reps` more,
         # still back to back, each between two events on the launch stream.
         run()

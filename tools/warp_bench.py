@@ -37,7 +37,7 @@ def main():
 
     def run():
         capi.bgr_image_warp_batch_device(src.data_ptr(), n, W, H, 3, args.bits, ts, dst.data_ptr(), mode, border, max_value=mv, stream=st.cuda_stream)
-    # the shader clock needs ~40 ms of continuous work to settle (tools/exp13.py): back-to-back launches for >= 80 ms first
+    # the shader clock needs ~40 ms of continuous work to settle (tools/clock_settling.py): back-to-back launches for >= 80 ms first
     import time
     run()
     torch.cuda.synchronize()
