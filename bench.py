@@ -211,6 +211,52 @@ def load_profile(*names):
     return {}, None
 
 
+def measure_traffic_live(W, H, n_frames, bits, timeout_s=150):
+    """HBM-side bytes of ONE warp launch of the headline's shape, measured in THIS run: two rocprofv3 counter passes (FETCH_SIZE and
+    WRITE_SIZE on their own: they do not fit one pass on gfx950) of tools/warp_bench.py as child processes -- `--pmc` alone, no trace
+    domain, the program itself behind `--`, TMPDIR=/tmp, as MI355X_MICROARCH.md prescribes.  FETCH_SIZE is doubled (gfx950 tallies
+    128-byte read requests at 64 bytes; re-checked on this kernel's 12-byte-per-lane loads in round 1: 0.500x), WRITE_SIZE is exact;
+    counter unit KiB.  -> (bytes per launch, description) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process is itself running under a profiler (no nested counter passes)"
+    tmp = tempfile.mkdtemp(prefix="vs_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 20:
+                return None, "the counter passes ran out of their %d s budget" % timeout_s
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "warp_bench.py"),
+                   "--mode", "fast", "--w", str(W), "--h", str(H), "--frames", str(n_frames), "--reps", "2", "--bits", "8" if bits == 8 else "16"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=left, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            vals, ids = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "warp_c3" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals += float(row["Counter_Value"])
+                        ids.add(row["Dispatch_Id"])
+            if not ids:
+                return None, "rocprofv3 --pmc %s gave no rows for the warp kernel (exit code %d)" % (ctr, r.returncode)
+            got[ctr] = vals / len(ids)
+    except Exception as e:                                   # noqa: BLE001 -- a profiler problem must not cost the line its headline
+        return None, "counter pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024), (
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the same launch shape (tools/warp_bench.py, "
+        "%d x %dx%d frames per launch, contracted form), FETCH_SIZE doubled per the gfx950 correction, %.0f s" % (n_frames, W, H, time.perf_counter() - t0))
+
+
 def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     """bgr_image_warp where the north star quotes it: `frames` 4K u8 frames per launch, nothing else running."""
     W, H = 3840, 2160
@@ -513,6 +559,9 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the 4K 10-bit full-stabilizer (configs[4]) leg of the default one-GPU run")
     ap.add_argument("--c5-clips", type=int, default=8)
     ap.add_argument("--no-drop-in", action="store_true", help="skip the per-frame host-call (drop-in pattern) legs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 counter passes that measure roofline.traffic in this run (the figure scaled from the "
+                         "committed passes is reported instead)")
     ap.add_argument("--c4-strong", action="store_true", help="run the 64-clip strong-scaling leg (configs[3]) on one GPU even if free memory looks short")
     ap.add_argument("--no-c4-strong", action="store_true", help="skip the strong-scaling leg")
     ap.add_argument("--c4-clips", type=int, default=64, help="total clips of the strong-scaling leg (rehearsals use fewer)")
@@ -722,6 +771,16 @@ def main():
                                             "bit-identical to the oracle's select rule 1"}
         if aw and aw.ev:
             out["roofline"] = roofline_of(aw, n * n_clips)
+            if default_run and world == 1 and not args.no_live_traffic and args.warp_mode != "exact" and not args.no_warp:
+                # the HBM-side bytes of the dominant kernel, measured live (child processes; the figure from the committed passes stays
+                # beside it, so a regression shows as a disagreement between the two)
+                live, how = measure_traffic_live(aw.W, aw.H, n * n_clips, aw.bits)
+                out["roofline"]["traffic_from_committed_passes"] = out["roofline"]["traffic"]
+                if live is not None:
+                    out["roofline"]["traffic"] = live
+                    out["roofline"]["traffic_source"] = how
+                else:
+                    out["roofline"]["traffic_source"] += "; a live measurement was attempted and failed: " + how
 
     # ---- parity gate + CPU baseline (rank 0 of a one-GPU run; the oracle is the checker, never the thing measured) ----------
     if rank == 0 and not args.no_cpu_baseline and world == 1:

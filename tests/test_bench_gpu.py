@@ -30,6 +30,10 @@ def test_bench_line_contract(gpu_vs):
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["binding"] == "valu" and "traffic_source" in r
+    # the HBM-side bytes are measured in the run itself (two rocprofv3 counter passes as child processes) and agree with the
+    # algorithmic bytes: no wasted re-reads (8 frames here)
+    assert "measured in this run" in r["traffic_source"], r["traffic_source"]
+    assert 0.97 * r["bytes_per_launch"] <= r["traffic"] <= 1.10 * r["bytes_per_launch"], (r["traffic"], r["bytes_per_launch"])
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]
     assert j["align_only"]["value"] > j["value"]

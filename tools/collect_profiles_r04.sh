@@ -11,7 +11,7 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -- python
 echo "stats c2 headline rc=$?"
 python3 tools/step_trace.py "$(find $O/stats_c2 -name '*kernel_trace.csv' | head -1)" 40 110 > $O/step_trace_shared.md
 # (b) the driver's own command, every leg (c3, c5, c4_strong, roofline_4k, parity, drop_in, host_fed, cpu_baseline)
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/stats_default.json 2> $O/stats_default.err
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-live-traffic > $O/stats_default.json 2> $O/stats_default.err
 echo "stats default rc=$?"
 # (c) the 4K half and the 4K 10-bit stabilizer loop on their own
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-host-fed --no-roofline-4k --no-drop-in > $O/stats_c3.json 2> $O/stats_c3.err
