@@ -591,8 +591,17 @@ def main():
         # one process per GPU; "nccl" is RCCL on ROCm.  No data-path collective: clips are independent.
         # (every rank joins a gloo group first and the ranks AGREE over it whether RCCL is up: all of them report over RCCL, or all
         # of them over gloo with the first failing rank's reason -- video_stabilizer_amd/dist.py)
-        dist, backend_used, backend_note = vsdist.init_with_fallback(args.dist_backend, rank, world,
-                                                                      device_id=dev if args.dist_backend == "nccl" else None)
+        # (gloo and RCCL print banners to fd 1 from C++ while they come up: stdout carries ONE JSON line, so fd 1 points at stderr meanwhile)
+        sys.stdout.flush()
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist, backend_used, backend_note = vsdist.init_with_fallback(args.dist_backend, rank, world,
+                                                                          device_id=dev if args.dist_backend == "nccl" else None)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd1, 1)
+            os.close(saved_fd1)
         assert dist.get_world_size() == world, "process group has %d ranks, launcher says %d" % (dist.get_world_size(), world)
         assert world == args.gpus or args.force_dist, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
     red_dev = dev if (dist is not None and backend_used == "nccl") else None     # where the three report scalars are reduced

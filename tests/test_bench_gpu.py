@@ -91,6 +91,7 @@ def test_bench_spawns_its_own_ranks(gpu_vs):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1                                          # one line for the whole job
+    assert out.stdout.strip() == lines[0]                           # ... and nothing else on stdout (library banners go to stderr)
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "gloo"
     assert j["aligned_per_step"] == 2 * 5                           # both ranks' clips are counted
