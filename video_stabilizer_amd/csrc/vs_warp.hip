@@ -65,6 +65,9 @@ namespace {
 #ifndef VS_WARP_TILES_PER_WG
 #define VS_WARP_TILES_PER_WG 1           // consecutive tiles of its XCD's run a workgroup walks; > 1: the next tile's source loads are in flight during the current tile's sampler blocks
 #endif
+#ifndef VS_WARP_TILES_PER_WG_BILINEAR
+#define VS_WARP_TILES_PER_WG_BILINEAR VS_WARP_TILES_PER_WG     // the same for the bilinear mode (29 arithmetic instructions per pixel: bound by the fill's load latency, not by issue)
+#endif
 #ifndef VS_WARP_ROW_BLOCK
 #define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
 #endif
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear id order and
     // gridDim.x is a multiple of 8, so workgroup b of a frame works on its tile (b % 8) * chunk + b / 8: every XCD walks
     // one contiguous run of tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
-    constexpr int NT = VS_WARP_TILES_PER_WG;
+    constexpr int NT = MODE == 1 ? VS_WARP_TILES_PER_WG_BILINEAR : VS_WARP_TILES_PER_WG;
     const int tl0 = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) * NT;         // this workgroup's first tile
     const int tl_end = min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk);        // end of its XCD's run
     if (tl0 >= tl_end) return;
@@ -790,7 +793,8 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
         T* dp = dst + (size_t)f0 * dst_fs;
         const float4* pp = params_dev + f0;
         const float4* ep = extents_dev ? extents_dev + f0 : nullptr;
-        dim3 grid((unsigned)((chunk + VS_WARP_TILES_PER_WG - 1) / VS_WARP_TILES_PER_WG * 8), (unsigned)nf), block(256);
+        const int nt_wg = mode == 1 ? VS_WARP_TILES_PER_WG_BILINEAR : VS_WARP_TILES_PER_WG;     // tiles a workgroup walks (the kernel's NT)
+        dim3 grid((unsigned)((chunk + nt_wg - 1) / nt_wg * 8), (unsigned)nf), block(256);
 #define VS_LAUNCH(M, Bd) \
         hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
                            tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
