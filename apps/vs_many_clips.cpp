@@ -12,9 +12,17 @@
 // alignment of step k + 1.  No exchange between slots: the threads meet at a barrier before and after the timed steps, and the
 // line reports every slot's own seconds beside the whole job's (the slowest slot's) -- the C++ point of comparison for the
 // Python ranks of `bench.py --gpus N` (c4_strong.per_rank_seconds), where a host-side knee would show first.
+// Aggregate: the whole job's numbers are the sum of the slots' frame counters and the maximum of their seconds.  With distinct devices
+// they are reduced where the north star puts them -- "RCCL over xGMI only for aggregate throughput reporting": one communicator per
+// slot (ncclCommInitAll, one process, one thread per GPU), one ncclAllReduce(sum) of {frames, aligned} and one ncclAllReduce(max) of
+// {seconds} after the closing barrier, 24 bytes per slot, nothing on the data path -- and cross-checked against the host-side sum.
+// A device listed twice (the one-GPU rehearsal) or a failing RCCL set-up falls back to the host-side aggregate, and the line says so
+// ("if RCCL init fails on the box, fall back to host-side aggregation and say so").  --no-rccl skips the attempt.
 // The clips are copies of ONE seeded synthetic clip (apps/synth_clip.hpp): every slot aligns real texture and converges like
 // bench.py's clips do; for a throughput measurement distinct camera paths per clip add nothing.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -63,7 +71,7 @@ bool parse_devices(const std::string& list, std::vector<int>& out) {
 int main(int argc, char** argv) {
     std::vector<int> devices = {0};
     int clips = 64, frames = 120, w = 1920, h = 1080, steps = 3, min_width = 256;
-    bool exact = false, warp = true;
+    bool exact = false, warp = true, use_rccl = true;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -76,7 +84,8 @@ int main(int argc, char** argv) {
         else if (a == "--size") { if (!(v = next()) || std::sscanf(v, "%dx%d", &w, &h) != 2) { std::fprintf(stderr, "Error: --size WxH\n"); return 1; } }
         else if (a == "--exact") exact = true;
         else if (a == "--no-warp") warp = false;
-        else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--exact] [--no-warp]\n", argv[0]); return 1; }
+        else if (a == "--no-rccl") use_rccl = false;
+        else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--exact] [--no-warp] [--no-rccl]\n", argv[0]); return 1; }
     }
     const int G = (int)devices.size();
     if (clips < 1 || frames < 2 || steps < 1 || w < 64 || h < 64) { std::fprintf(stderr, "Error: bad sizes\n"); return 1; }
@@ -97,6 +106,32 @@ int main(int argc, char** argv) {
             });
         for (auto& t : th) t.join();
     }
+
+    // ---- RCCL communicators for the report (distinct devices only) ----
+    std::vector<ncclComm_t> comms((size_t)G, nullptr);
+    std::string aggregate = "host";
+    std::string rccl_note;
+    if (!use_rccl) rccl_note = "--no-rccl";
+    else {
+        bool distinct = true;
+        for (int i = 0; i < G; i++) for (int j = i + 1; j < G; j++) if (devices[(size_t)i] == devices[(size_t)j]) distinct = false;
+        if (!distinct) rccl_note = "a device is listed more than once: one RCCL rank per GPU only";
+        else {
+            // (RCCL prints its version banner to fd 1 while it comes up: stdout carries the one JSON line, so fd 1 points at stderr meanwhile)
+            std::fflush(stdout);
+            const int saved = dup(1);
+            (void)dup2(2, 1);
+            const ncclResult_t r = ncclCommInitAll(comms.data(), G, devices.data());
+            std::fflush(stdout);
+            (void)dup2(saved, 1);
+            (void)close(saved);
+            if (r == ncclSuccess) aggregate = "rccl";
+            else { rccl_note = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); for (auto& c : comms) c = nullptr; }
+        }
+    }
+    struct Agg { unsigned long long frames, aligned; double seconds; };
+    std::vector<Agg> agg((size_t)G, Agg{0, 0, 0.0});
+    std::vector<std::string> agg_err((size_t)G);
 
     std::vector<SlotResult> res((size_t)G);
     Barrier barrier(G);
@@ -147,6 +182,28 @@ int main(int argc, char** argv) {
         if (mine > 0) (void)hipDeviceSynchronize();
         r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         barrier.wait();
+        if (aggregate == "rccl") {
+            // every slot contributes its counters and its seconds; every slot gets the whole job's (slot 0's copy is reported)
+            unsigned long long* d_cnt = nullptr; double* d_sec = nullptr;
+            const unsigned long long h_cnt[2] = {(unsigned long long)r.frames, (unsigned long long)r.aligned};
+            hipStream_t cs = nullptr;
+            bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess &&
+                      hipMalloc((void**)&d_cnt, 16) == hipSuccess && hipMalloc((void**)&d_sec, 8) == hipSuccess &&
+                      hipMemcpyAsync(d_cnt, h_cnt, 16, hipMemcpyHostToDevice, cs) == hipSuccess &&
+                      hipMemcpyAsync(d_sec, &r.seconds, 8, hipMemcpyHostToDevice, cs) == hipSuccess;
+            ncclResult_t nr = ncclSuccess;
+            if (ok) nr = ncclAllReduce(d_cnt, d_cnt, 2, ncclUint64, ncclSum, comms[(size_t)g], cs);
+            if (ok && nr == ncclSuccess) nr = ncclAllReduce(d_sec, d_sec, 1, ncclDouble, ncclMax, comms[(size_t)g], cs);
+            unsigned long long o_cnt[2] = {0, 0};
+            double o_sec = 0.0;
+            ok = ok && nr == ncclSuccess && hipMemcpyAsync(o_cnt, d_cnt, 16, hipMemcpyDeviceToHost, cs) == hipSuccess &&
+                 hipMemcpyAsync(&o_sec, d_sec, 8, hipMemcpyDeviceToHost, cs) == hipSuccess && hipStreamSynchronize(cs) == hipSuccess;
+            if (ok) agg[(size_t)g] = Agg{o_cnt[0], o_cnt[1], o_sec};
+            else agg_err[(size_t)g] = nr != ncclSuccess ? ncclGetErrorString(nr) : "HIP error around the all-reduce";
+            if (d_cnt) (void)hipFree(d_cnt);
+            if (d_sec) (void)hipFree(d_sec);
+            if (cs) (void)hipStreamDestroy(cs);
+        }
         if (ws) { (void)vs_stream_retire(ws); (void)hipStreamDestroy(ws); }
         if (a) vs_aligner_destroy(a);
         if (in) (void)hipFree(in);
@@ -165,6 +222,19 @@ int main(int argc, char** argv) {
         slowest = std::max(slowest, r.seconds);
         total_frames += r.frames; total_aligned += r.aligned;
     }
+    for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+    if (aggregate == "rccl") {
+        // the collective's answer must be the host-side sum on every slot; anything else is reported and the host-side figures stand
+        for (int g = 0; g < G; g++) {
+            const Agg& a = agg[(size_t)g];
+            if (!agg_err[(size_t)g].empty()) { aggregate = "host"; rccl_note = "all-reduce failed on slot " + std::to_string(g) + ": " + agg_err[(size_t)g]; break; }
+            if ((long long)a.frames != total_frames || (long long)a.aligned != total_aligned || a.seconds != slowest) {
+                std::fprintf(stderr, "Error: the RCCL aggregate on slot %d (%llu frames, %llu aligned, %.6f s) differs from the host-side one (%lld, %lld, %.6f)\n", g,
+                             a.frames, a.aligned, a.seconds, total_frames, total_aligned, slowest);
+                return 1;
+            }
+        }
+    }
     std::printf("{\"program\": \"vs_many_clips\", \"host\": \"C++ threads, one per device slot\", \"devices\": [");
     for (int g = 0; g < G; g++) std::printf("%s%d", g ? ", " : "", devices[(size_t)g]);
     std::printf("], \"clips\": %d, \"frames_per_clip\": %d, \"width\": %d, \"height\": %d, \"steps\": %d, \"warp\": \"%s\", \"scaling\": \"strong\", ", clips, frames, w, h,
@@ -174,6 +244,8 @@ int main(int argc, char** argv) {
     for (int g = 0; g < G; g++) std::printf("%s%.5f", g ? ", " : "", res[(size_t)g].seconds);
     std::printf("], \"per_slot_clips\": [");
     for (int g = 0; g < G; g++) { int m = 0; for (int c = g; c < clips; c += G) m++; std::printf("%s%d", g ? ", " : "", m); }
-    std::printf("], \"aligned_per_step\": %lld, \"setup_and_run_seconds\": %.2f}\n", total_aligned / steps, job);
+    std::printf("], \"aligned_per_step\": %lld, \"aggregate\": \"%s\", \"aggregate_note\": \"%s\", \"setup_and_run_seconds\": %.2f}\n", total_aligned / steps,
+                aggregate == "rccl" ? "rccl: ncclAllReduce sum {frames, aligned} + max {seconds} over one communicator per GPU, equal to the host-side sums" : "host-side sums",
+                rccl_note.c_str(), job);
     return 0;
 }

@@ -267,11 +267,17 @@ def test_many_clips_cpp_harness_splits_clips_over_device_slots(gpu_vs, clip):
     """apps/vs_many_clips: BASELINE configs[3] with the host side in C++ -- one thread per device slot, clip i -> slot i mod G, no
     exchange, per-slot seconds.  Two slots on the one GPU here; the frames aligned must not depend on the split."""
     import json
-    one = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64).strip().splitlines()[-1])
+    raw = run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64)
+    assert raw.strip().startswith("{") and len(raw.strip().splitlines()) == 1    # one JSON line, no library banners on stdout
+    one = json.loads(raw.strip().splitlines()[-1])
     two = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64, "--devices", "0,0").strip().splitlines()[-1])
     assert one["devices"] == [0] and one["per_slot_clips"] == [5] and len(one["per_slot_seconds"]) == 1
     assert two["devices"] == [0, 0] and two["per_slot_clips"] == [3, 2] and len(two["per_slot_seconds"]) == 2
     assert one["aligned_per_step"] == two["aligned_per_step"] == 5 * 11          # every frame but each clip's first
+    # the report scalars travel over RCCL (one communicator per GPU) and equal the host-side sums; a device listed twice cannot have
+    # two RCCL ranks: the harness says so and aggregates on the host
+    assert one["aggregate"].startswith("rccl") and one["aggregate_note"] == ""
+    assert two["aggregate"] == "host-side sums" and "more than once" in two["aggregate_note"]
     for j in (one, two):
         assert j["value"] > 0 and j["scaling"] == "strong" and j["seconds"] == max(j["per_slot_seconds"]) and j["warp"] == "lanczos2 contracted"
     out = subprocess.run([os.path.join(BIN, "vs_many_clips"), "--devices", "0,9"], capture_output=True, text=True, timeout=120)
