@@ -20,9 +20,7 @@ def oracle():
     return O
 
 
-@pytest.fixture(scope="session")
-def vs():
-    """the product's C ABI via ctypes; a missing library is an error, never a skip"""
+def _torch_first():
     # torch first, where it is installed: torch ships its own copy of the HIP runtime, and the copy that is loaded first is
     # the one the whole process uses (same SONAME) -- the other way round torch finds "no HIP GPUs" in tests that also use
     # torch for device memory / streams.  bench.py imports in this order too (INTEGRATION.md, "one HIP runtime per process").
@@ -32,6 +30,12 @@ def vs():
             torch.cuda.init()
     except ImportError:
         pass
+
+
+@pytest.fixture(scope="session")
+def vs():
+    """the product's C ABI via ctypes; a missing library is an error, never a skip"""
+    _torch_first()
     from video_stabilizer_amd import capi
     capi.lib()
     return capi
@@ -51,6 +55,7 @@ def gpu_vs(vs):
 def _bounds_record_stays_clean(request):
     yield
     if os.environ.get("VS_BOUNDS_BUILD") == "1" and request.node.get_closest_marker("gpu") is not None:
+        _torch_first()                      # (a test that did all its GPU work in child processes has not loaded anything yet)
         from video_stabilizer_amd import capi
         n, first = capi.debug_bounds_check()
         assert n == 0, "out-of-bounds index in a kernel of the bounds build during this test: %s" % first
