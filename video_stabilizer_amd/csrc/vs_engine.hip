@@ -1114,7 +1114,15 @@ vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
         }();
         if (env_mode >= 0) a->select_mode = env_mode;
     }
-    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+    // VS_ALIGNER_STREAM_PRIORITY=low|high (read once; experiments): the handle's stream at the device's least / greatest priority
+    static const int prio_env = []() { const char* e = getenv("VS_ALIGNER_STREAM_PRIORITY"); return !e ? 0 : (e[0] == 'l' ? -1 : (e[0] == 'h' ? 1 : 0)); }();
+    hipError_t se;
+    if (prio_env != 0) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        se = hipStreamCreateWithPriority(&a->stream, hipStreamNonBlocking, prio_env < 0 ? least : greatest);
+    } else se = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
         set_error(VS_ERR_HIP, "hipStreamCreate failed");
         delete a;
         return nullptr;
