@@ -265,7 +265,8 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     ts = [capi.Transform.of(0.002, -0.0015, 3.3 + 0.37 * i, -2.7 - 0.21 * i) for i in range(frames)]
     pmc, pmc_name = load_profile("r04_warp_pmc.json", "r03_warp_pmc.json", "r02_warp_pmc.json")
     out = {}
-    for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted")):
+    for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted"),
+                            ("bilinear", capi.WARP_BILINEAR, "bilinear")):
         def run():
             capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
                                              max_value=255, stream=stream.cuda_stream)
@@ -295,6 +296,14 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         ipp = p.get("valu_instr_per_px")
         # VALU-peak fraction: wave-instructions the launch issues / what 1024 SIMDs issue in that time at one per 2 cycles
         valu_peak_frac = round(ipp * W * H * frames / 64.0 / (med * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if ipp else None
+        if name == "bilinear":
+            # the stabilizer's DEFAULT sampler (cv::warpAffine INTER_LINEAR in the reference, imgproc.cpp:472): ~60 vector instructions per
+            # pixel, bound by its tile fill, not by issue (profiles/r04_ab_warp_bilinear.md)
+            out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "tile fill",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
+                         "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR)"}
+            continue
         out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,%s,clamp>" % ("lanczos2" if name == "exact" else "lanczos2 contracted (VS_WARP_LANCZOS2_FAST)"),
                      "bound": "hbm", "binding": "valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": int(p["traffic_bytes_per_frame"] * frames) if "traffic_bytes_per_frame" in p else None,

@@ -87,6 +87,15 @@ constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;   // fill items pe
 // A staged row holds WS_W pixels but is WS_RS slots long: 81 slots = 1296 bytes = 16 (mod 128), so the fill's ds_write_b128
 // (8-lane groups = 4 rows x 2 column groups, 64-byte column-group stride) touch every bank once.
 constexpr int WS_RS = WS_W + 1;
+// Bilinear mode on 8-bit frames: the tile holds the source BYTES, one dword {B,G,R,0} per pixel (8.4 KB instead of 31 KB: 8 workgroups
+// per CU instead of 5), and the sampler converts its four taps itself (v_cvt_f32_ubyteN: the byte select is free).  With ~60 vector
+// instructions per pixel the bilinear kernel is bound by the bytes a CU keeps in flight, not by issue: the float tile's fill (load ->
+// 16 conversions -> 4 x ds_write_b128 per item -> barrier) was 15 of its 21.8 us per 4K frame (profiles/r04_ab_warp_bilinear.md).
+// Row pitch 88 dwords = 24 (mod 64): the fill's 8-lane ds_write_b128 groups (4 rows x 2 column groups) touch every bank once.
+#ifndef VS_WARP_BILINEAR_U8_TILE
+#define VS_WARP_BILINEAR_U8_TILE 1
+#endif
+constexpr int WS_RS8 = WS_W + 8;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -352,6 +361,19 @@ __device__ __forceinline__ void sample_bilinear(lds_f4 t, f2 fr, float q[3]) {
     }
 }
 
+// The same on the byte tile: t = dword of staged pixel (iy, ix) = B | G << 8 | R << 16.  Two ds_read2_b32 fetch the 2 x 2 window; the
+// twelve conversions are exact, so every float below is the float-tile path's value: bit-identical.
+__device__ __forceinline__ void sample_bilinear_u8(const __attribute__((address_space(3))) uint32_t* t, f2 fr, float q[3]) {
+    const uint32_t a0 = t[0], a1 = t[1], b0 = t[WS_RS8], b1 = t[WS_RS8 + 1];
+    const float tx = fr.x, ty = fr.y, otx = 1.0f - tx, oty = 1.0f - ty;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float top = ub(a0, c) * otx + ub(a1, c) * tx;
+        const float bot = ub(b0, c) * otx + ub(b1, c) * tx;
+        q[c] = top * oty + bot * ty;
+    }
+}
+
 template <typename T, int MODE, int BORDER>
 __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int w, int h, int stride, float Wx,
                                                   float Wy, float maxv, uint32_t out[3]) {
@@ -428,11 +450,13 @@ __device__ __forceinline__ FillItem fill_item(int lane, int slot) {
 }
 
 template <typename T, int MODE, int BORDER>
-__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EXACT_MINWAVES) void vs_k_bgr_warp_c3(
+__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 1 && sizeof(T) == 1 && VS_WARP_BILINEAR_U8_TILE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
-    __shared__ f4 tile[WS_H * WS_RS];                      // {B,G,R,1} per staged source pixel
+    constexpr bool U8TILE = MODE == 1 && sizeof(T) == 1 && VS_WARP_BILINEAR_U8_TILE;
+    __shared__ f4 tile[U8TILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
+    __shared__ __attribute__((aligned(16))) uint32_t tile8[U8TILE ? WS_H * WS_RS8 : 4];    // bilinear on 8-bit frames: B | G << 8 | R << 16
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
     if (w < 0) lds_pad[threadIdx.x] = 0;
@@ -549,6 +573,39 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         }
         uint32_t one = 1u;
         asm volatile("" : "+v"(one));                        // opaque: keeps the conversion below from folding to a constant
+        if (U8TILE) {
+#pragma unroll
+            for (int s = 0; s < FILL_SLOTS; s++) {
+                if (!live[s]) continue;
+                VS_BOUNDS_CHECK(it[s].row * WS_RS8 + 4 * it[s].g + 3, WS_H * WS_RS8, 204);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 px;
+                if (direct[s]) {
+                    const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
+                    px.x = q.x & 0x00ffffffu;
+                    px.y = __builtin_amdgcn_perm(q.y, q.x, 0x0c050403u);       // {x3, y0, y1, 0}
+                    px.z = __builtin_amdgcn_perm(q.z, q.y, 0x0c040302u);       // {y2, y3, z0, 0}
+                    px.w = q.z >> 8;
+                } else {
+                    // frame border, an unaligned frame, or (constant border) a row outside the frame: pixel by pixel
+                    const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+                    const bool row_in = sy >= 0 && sy < h;
+                    uint32_t d[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int pxi = sx + k;
+                        if (BORDER == 1 && (!row_in || pxi < 0 || pxi >= w)) d[k] = 0u;
+                        else {
+                            const T* qq = rowp[s] + clampi(pxi, 0, w - 1) * 3;
+                            d[k] = (uint32_t)qq[0] | ((uint32_t)qq[1] << 8) | ((uint32_t)qq[2] << 16);
+                        }
+                    }
+                    px = u32x4{d[0], d[1], d[2], d[3]};
+                }
+                *(u32x4*)(tile8 + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3)) = px;
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
             if (!live[s]) continue;
@@ -622,7 +679,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
     const float A1x = A1 * fx, Bx = B * fx;
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
-    const float c0 = -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
+    const float c0 = U8TILE ? -4.0f * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
     const bool lane_in = x < roi.w;
     const int yw_first = yw;
 #pragma unroll 1
@@ -647,9 +704,11 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
         const float flx = floorf(Wx), fly = floorf(Wy);
         fr_all[k] = f2{Wx - flx, Wy - fly};
         // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
-        const int boff = VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
-                                              16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
-        t_all[k] = (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
+        const int boff = U8TILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * WS_RS8, __builtin_fmaf(flx, 4.0f, c0)), 4 * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
+                                : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
+                                                       16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
+        t_all[k] = U8TILE ? (lds_f4)((const __attribute__((address_space(3))) char*)tile8 + boff)
+                          : (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
     }
 #if VS_WARP_COORDS_FIRST
     __builtin_amdgcn_sched_barrier(0);
@@ -679,8 +738,13 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : VS_WARP_EX
                 else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else {
-            sample_bilinear(t[0], fr[0], q[0]);
-            sample_bilinear(t[1], fr[1], q[1]);
+            if (U8TILE) {
+                sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[0], fr[0], q[0]);
+                sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[1], fr[1], q[1]);
+            } else {
+                sample_bilinear(t[0], fr[0], q[0]);
+                sample_bilinear(t[1], fr[1], q[1]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
