@@ -8,7 +8,7 @@
 // FMA contraction.  VS_WARP_LANCZOS2_FAST is the contracted form of the same sampler (vs_device.hpp), bit-identical to
 // the oracle's VSO_WARP_LANCZOS2_CONTRACTED.
 //
-// Structure (one 256-thread workgroup = one 64x16 output tile of one frame):
+// Structure (one 256-thread workgroup = one 64x16 output tile of one frame; 64x32 and 8 rows per wave for bilinear on 8-bit frames):
 //   1. The similarity is affine, so the tile's source footprint is the bounding box of its four
 //      corners (fp32 rounding is monotonic, so the corners bound every pixel exactly).  For the
 //      near-identity transforms of stabilisation that is ~67x19 pixels.
@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <vector>
 #include "vs_device.hpp"
 
 using namespace vsd;
@@ -97,6 +98,15 @@ constexpr int WS_RS = WS_W + 1;
 #define VS_WARP_BILINEAR_U8_TILE 1
 #endif
 constexpr int WS_RS8 = WS_W + 8;
+// ... and its output tile is taller: the per-workgroup prologue (tile geometry, fill set-up, ~200 instructions) is paid once per tile, and
+// with a 14 KB tile 32 rows still leave 8 workgroups per CU.  4K: 17.3 -> 15.6 us per frame (64 rows: 15.1, but a 1080p frame is then only
+// 510 tiles); the float-tile kernels lose occupancy instead (contracted Lanczos2 38.2 -> 40.3 us).  profiles/r04_ab_warp_bilinear.md.
+#ifndef VS_WARP_TILE_H_BILINEAR_U8
+#define VS_WARP_TILE_H_BILINEAR_U8 32
+#endif
+constexpr int tile_h_of(bool u8tile) { return u8tile ? VS_WARP_TILE_H_BILINEAR_U8 : VS_WARP_TILE_H; }
+constexpr int tile_h_of(int bits, int mode) { return tile_h_of(bits == 8 && mode == 1 && VS_WARP_BILINEAR_U8_TILE); }
+static_assert(VS_WARP_TILE_H_BILINEAR_U8 % 8 == 0 && (VS_WARP_TILE_H_BILINEAR_U8 + 8) / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
 // Experiment, off (bit-identical, slower): tiles whose whole footprint lies inside the frame skip the tile, every output pixel
 // fetching its 2 x 2 window with two unaligned 8-byte loads (B0 G0 R0 B1 G1 R1 + two spare bytes per row) through the vector L1.
 // No fill, no barrier -- but a wave's 8-byte gather at a 3-byte lane stride costs ~40 cycles in the texture path against 8 for the two
@@ -104,6 +114,21 @@ constexpr int WS_RS8 = WS_W + 8;
 // profiles/r04_ab_warp_bilinear.md, tools/ab_warp_bilinear_direct.sh.
 #ifndef VS_WARP_BILINEAR_DIRECT
 #define VS_WARP_BILINEAR_DIRECT 0
+#endif
+
+// analysis build (tools/warp_stamps.py): every wave of the first STAMP_WGS workgroups of a launch leaves eight s_memtime stamps
+// (entry, geometry done, loads issued, loads landed, tile written, barrier passed, rows stored, stores drained) and its HW_ID / XCC_ID
+#ifndef VS_WARP_STAMPS
+#define VS_WARP_STAMPS 0
+#endif
+#if VS_WARP_STAMPS
+constexpr int STAMP_WGS = 8192, STAMP_N = 10;
+__device__ unsigned long long g_warp_stamps[STAMP_WGS * 4 * STAMP_N];
+#define VS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VS_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define VS_STAMP(i) ((void)0)
+#define VS_STAMP_DRAIN() ((void)0)
 #endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -480,6 +505,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
     constexpr bool U8TILE = MODE == 1 && sizeof(T) == 1 && VS_WARP_BILINEAR_U8_TILE;
     constexpr bool U8DIRECT = U8TILE && VS_WARP_BILINEAR_DIRECT;
+    // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
+    constexpr int WT_H = tile_h_of(U8TILE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
+    constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
+    static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
     __shared__ f4 tile[U8TILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
     __shared__ __attribute__((aligned(16))) uint32_t tile8[U8TILE ? WS_H * WS_RS8 : 4];    // bilinear on 8-bit frames: B | G << 8 | R << 16
 #ifdef VS_WARP_LDS_PAD
@@ -490,6 +519,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
     // gridDim.x is a multiple of 8, so workgroup b of a frame works on its tile (b % 8) * chunk + b / 8: every XCD walks
     // one contiguous run of tiles in raster order and the halo rows / columns shared by neighbouring tiles hit in its L2.
     constexpr int NT = MODE == 1 ? VS_WARP_TILES_PER_WG_BILINEAR : VS_WARP_TILES_PER_WG;
+#if VS_WARP_STAMPS
+    unsigned long long stamp[STAMP_N] = {};
+    VS_STAMP(0);
+#endif
     const int tl0 = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3) * NT;         // this workgroup's first tile
     const int tl_end = min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk);        // end of its XCD's run
     if (tl0 >= tl_end) return;
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
 
     // source footprint of the tile.  Wx = fl(fl(A1*x) - fl(B*y)) + TX is monotone in x and in y (rounding is monotone), so its
     // extremes over the tile sit at corners chosen by the signs of A1 and B: 4 evaluations -- or, when the host has sent the
-    // frame's extents (vsk::bgr_warp_c3: the range of A1*i - B*j and B*i + A1*j over a full 64 x 16 tile, widened by a bound on
+    // frame's extents (vsk::bgr_warp_c3: the range of A1*i - B*j and B*i + A1*j over a full tile (64 x WT_H), widened by a bound on
     // the fp32 rounding of the position arithmetic), ONE evaluation at the tile origin plus four adds: every position a pixel
     // of the tile computes lies inside [W00 + lo, W00 + hi], which is all the footprint has to guarantee (it may come out a
     // pixel larger than the exact one; the window has 8 columns and 3 rows to spare for near-identity transforms).
@@ -582,6 +615,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
         const T* rowp[FILL_SLOTS];
         if (g.interior) {
             if (!loaded) issue(g);
+            VS_STAMP(2);
+            VS_STAMP_DRAIN();
+            VS_STAMP(3);
 #pragma unroll
             for (int s = 0; s < FILL_SLOTS; s++) {
                 it[s] = fill_item(lane, wv + 4 * s);
@@ -868,6 +904,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
     };
 
     Geom g = geom(tl0);
+    VS_STAMP(1);
     bool loaded = false;
     if (NT > 1 && g.interior) { issue(g); loaded = true; }
 #pragma unroll 1
@@ -880,7 +917,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
             continue;
         }
         if (g.fits && !(VS_WARP_WHATIF & 2)) fill(g, loaded);
+        VS_STAMP(4);
         __syncthreads();
+        VS_STAMP(5);
         Geom gn = g;
         bool loaded_n = false;
         if (more) {
@@ -888,6 +927,18 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
             if (gn.interior) { issue(gn); loaded_n = true; }          // in flight during this tile's sampler blocks
         }
         sample_tile(g, std::false_type{});
+        VS_STAMP(6);
+        VS_STAMP_DRAIN();
+        VS_STAMP(7);
+#if VS_WARP_STAMPS
+        {
+            const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+            stamp[8] = __builtin_amdgcn_s_getreg(4 | (31 << 11));              // HW_REG_HW_ID
+            stamp[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));             // HW_REG_XCC_ID
+            if (lane == 0 && wg < (unsigned)STAMP_WGS && g.interior)
+                for (int i = 0; i < STAMP_N; i++) g_warp_stamps[((size_t)wg * 4 + wv) * STAMP_N + i] = stamp[i];
+        }
+#endif
         if (!more) break;
         __syncthreads();                                               // every wave has read its taps: the tile buffer is free
         g = gn; loaded = loaded_n;
@@ -898,12 +949,26 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
 
 VS_BOUNDS_TU(vs_bounds_fetch_warp)
 
+#if VS_WARP_STAMPS
+// (analysis build only) copies the stamps of the last launches out and clears them; n = capacity in 64-bit words
+extern "C" __attribute__((visibility("default"))) int vs_debug_warp_stamps(unsigned long long* out, size_t n) {
+    const size_t total = (size_t)STAMP_WGS * 4 * STAMP_N;
+    if (n < total) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_warp_stamps), total * sizeof(unsigned long long)) != hipSuccess) return -3;
+    static std::vector<unsigned long long> zero(total, 0ULL);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_warp_stamps), zero.data(), total * sizeof(unsigned long long)) != hipSuccess) return -4;
+    return STAMP_WGS;
+}
+#endif
+
 namespace vsk {
 
 template <typename T>
 static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, const float4* extents_dev, int mode,
                             int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
-    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + WT_H - 1) / WT_H;
+    const int th = tile_h_of((int)sizeof(T) * 8, mode);
+    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + th - 1) / th;
     const long long tpf = (long long)tiles_x * tiles_y;
     // the kernel's tl / tiles_x is a multiply-high, exact while tl * tiles_x < 2^32: wider windows take the generic kernel
     if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
@@ -943,17 +1008,18 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
 }
 
 // The per-frame extents the tuned kernel's tile prologue adds to the position of a tile's origin (see the kernel): for the kernel
-// parameters P = {A, B, TX, TY} of a frame, {min, max of A1*i - B*j, min, max of B*i + A1*j} over i in [0, 63], j in [0, 15],
+// parameters P = {A, B, TX, TY} of a frame, {min, max of A1*i - B*j, min, max of B*i + A1*j} over i in [0, 63], j in [0, tile height - 1],
 // widened by eps = 2^-20 * M, M = a bound on every intermediate of the fp32 position arithmetic over the output window (the
 // arithmetic makes four roundings of relative size 2^-24 on values below M, for the pixel and for the tile origin: 8 * 2^-24 * M;
 // eps doubles that and covers the adds below), and rounded outward to float.
-void bgr_warp_c3_extents(const float* P4, int n_frames, Roi roi, float* E4) {
+void bgr_warp_c3_extents(const float* P4, int n_frames, Roi roi, int bits, int mode, float* E4) {
+    const int th = tile_h_of(bits, mode);                  // the tile of the kernel that (bits, mode) selects
     for (int f = 0; f < n_frames; f++) {
         const double A1 = (double)(1.0f + P4[4 * f]), B = (double)P4[4 * f + 1], TX = (double)P4[4 * f + 2], TY = (double)P4[4 * f + 3];
-        const double X = (double)(roi.x + roi.w) + 64.0, Y = (double)(roi.y + roi.h) + 16.0;
+        const double X = (double)(roi.x + roi.w) + 64.0, Y = (double)(roi.y + roi.h) + (double)th;
         const double M = std::max(std::fabs(A1) * X + std::fabs(B) * Y + std::fabs(TX), std::fabs(B) * X + std::fabs(A1) * Y + std::fabs(TY)) + 1.0;
         const double eps = M * (1.0 / 1048576.0);
-        const double ax = A1 * (WT_W - 1), bx = -B * (WT_H - 1), ay = B * (WT_W - 1), by = A1 * (WT_H - 1);
+        const double ax = A1 * (WT_W - 1), bx = -B * (th - 1), ay = B * (WT_W - 1), by = A1 * (th - 1);
         const double lo_x = std::min(0.0, ax) + std::min(0.0, bx) - eps, hi_x = std::max(0.0, ax) + std::max(0.0, bx) + eps;
         const double lo_y = std::min(0.0, ay) + std::min(0.0, by) - eps, hi_y = std::max(0.0, ay) + std::max(0.0, by) + eps;
         const double v[4] = {lo_x, hi_x, lo_y, hi_y};
