@@ -297,9 +297,9 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         # VALU-peak fraction: wave-instructions the launch issues / what 1024 SIMDs issue in that time at one per 2 cycles
         valu_peak_frac = round(ipp * W * H * frames / 64.0 / (med * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if ipp else None
         if name == "bilinear":
-            # the stabilizer's DEFAULT sampler (cv::warpAffine INTER_LINEAR in the reference, imgproc.cpp:472): ~60 vector instructions per
-            # pixel, bound by its tile fill, not by issue (profiles/r04_ab_warp_bilinear.md)
-            out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "tile fill",
+            # the stabilizer's DEFAULT sampler (cv::warpAffine INTER_LINEAR in the reference, imgproc.cpp:472): 88 vector instructions per
+            # pixel (counted: profiles/r04_pmc_bilinear.json), VALU-issue-bound like the Lanczos kernels (profiles/r04_ab_warp_bilinear.md)
+            out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "valu", "valu_instr_per_px": 87.8,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR)"}
