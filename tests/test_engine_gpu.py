@@ -37,7 +37,10 @@ def _check_seq(res):
         if ok_c or dbg.fail_reason in (2, 3):
             for l in range(dbg.levels):
                 if dbg.iterations[l]:
-                    assert abs(inf.condition[l] - dbg.condition[l]) <= 1e-9 * dbg.condition[l]
+                    # cond = w0 / (w3 + 1e-10) (alignment.cpp:567): the smallest singular value of a nearly singular Hessian moves by
+                    # ~eps * w0 when H's double sums differ in their last bit, i.e. cond by a relative eps * cond (test_engine_sweep_gpu.py
+                    # draws such levels: cond 3.6e13 on a 12-pixel-wide top level)
+                    assert abs(inf.condition[l] - dbg.condition[l]) <= (1e-9 + 1e-15 * dbg.condition[l]) * dbg.condition[l]
                 # the reference's PerformanceMetrics custom metrics (alignment.cpp:489-490) and the estimate each level ended on
                 assert (inf.selected_x[l], inf.selected_y[l]) == (dbg.selected_x[l], dbg.selected_y[l]), (i, l)
                 assert _cmp_transform(inf.level_transform[l], dbg.level_transform[l]) < TOL, (i, l, inf.level_transform[l].tup(), dbg.level_transform[l].tup())
