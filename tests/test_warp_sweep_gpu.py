@@ -1,0 +1,46 @@
+"""Seeded random sweep of bgr_image_warp against the CPU restatement, bit for bit: frame sizes from one pixel up,
+8 / 10 / 12 / 16-bit containers, the three samplers, both borders, transforms from near-identity to degenerate (zero scale, mirror,
+far outside the frame), two-frame batches and output windows (a window = the same rows and columns cut out of the whole warp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _transform(rng):
+    kind = int(rng.integers(0, 6))
+    if kind == 0:      # stabilisation-sized
+        return (rng.uniform(-0.01, 0.01), rng.uniform(-0.01, 0.01), rng.uniform(-8, 8), rng.uniform(-8, 8))
+    if kind == 1:      # visible rotation / zoom: still inside the LDS window for most tiles
+        return (rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1), rng.uniform(-30, 30), rng.uniform(-30, 30))
+    if kind == 2:      # large: the per-pixel global path
+        return (rng.uniform(-0.9, 2.0), rng.uniform(-1.5, 1.5), rng.uniform(-100, 100), rng.uniform(-100, 100))
+    if kind == 3:      # everything samples one point (scale 0) or a mirror image (scale -1)
+        return (float(rng.choice([-1.0, -2.0])), 0.0, rng.uniform(0, 50), rng.uniform(0, 50))
+    if kind == 4:      # far outside the frame: border handling only
+        return (0.0, 0.0, float(rng.choice([-1e4, 1e4, 3e5])), float(rng.choice([-1e4, 1e4])))
+    return (0.0, 0.0, float(rng.integers(-5, 6)), float(rng.integers(-5, 6)))     # integer shift: weights exactly {0, 1}
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_warp_is_bit_exact(gpu_vs, oracle, seed):
+    rng = np.random.default_rng(31000 + seed)
+    small = rng.random() < 0.3
+    w = int(rng.integers(1, 70)) if small else int(rng.integers(70, 420))
+    h = int(rng.integers(1, 40)) if small else int(rng.integers(40, 260))
+    bits = int(rng.choice([8, 8, 10, 12, 16]))
+    max_value = (1 << bits) - 1
+    mode, border = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    dt = np.uint8 if bits == 8 else np.uint16
+    n = int(rng.integers(1, 3))
+    src = rng.integers(0, max_value + 1, (n, h, w, 3)).astype(dt)
+    trs = [_transform(rng) for _ in range(n)]
+    exp = np.stack([oracle.bgr_image_warp(src[i], oracle.Transform.of(*trs[i]), mode, border, max_value=max_value) for i in range(n)])
+    ts = [gpu_vs.Transform.of(*t) for t in trs]
+    got = gpu_vs.bgr_image_warp_batch(src, ts, mode, border, max_value=max_value)
+    assert np.array_equal(got, exp), (w, h, bits, mode, border, trs)
+    # a window of the same warp
+    rw, rh = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
+    rx, ry = int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1))
+    win = gpu_vs.bgr_image_warp_roi_batch(src, ts, (rx, ry, rw, rh), mode, border, max_value=max_value)
+    assert np.array_equal(win, exp[:, ry:ry + rh, rx:rx + rw]), (w, h, bits, mode, border, trs, (rx, ry, rw, rh))
