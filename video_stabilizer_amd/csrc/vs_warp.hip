@@ -62,7 +62,7 @@ namespace {
 #endif
 
 #ifndef VS_WARP_WHATIF
-#define VS_WARP_WHATIF 0                 // analysis builds only (wrong results): 1 one LDS read per pixel instead of 16, 2 no fill, 4 no division, 8 no store, 16 no weight chains
+#define VS_WARP_WHATIF 0                 // analysis builds only (wrong results): 1 one LDS read per pixel instead of 16, 2 no fill, 4 no division, 8 no store, 16 no weight chains, 32 loads hit the same lines, 256 every tile takes the rim fill (right results)
 #endif
 #ifndef VS_WARP_TILES_PER_WG
 #define VS_WARP_TILES_PER_WG 1           // consecutive tiles of its XCD's run a workgroup walks; > 1: the next tile's source loads are in flight during the current tile's sampler blocks
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
     }
     // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
     // tests per item, one offset from a uniform base
-    const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform
+    const bool interior = !(VS_WARP_WHATIF & 256) && fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform (analysis bit 256: every tile fills like a rim tile)
     return Geom{x0, y0, sx_lo, sy_lo, rows, groups, fits, interior, false};
     };
 
