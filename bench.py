@@ -260,16 +260,24 @@ def measure_traffic_live(W, H, n_frames, bits, timeout_s=150):
 def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     """bgr_image_warp where the north star quotes it: `frames` 4K u8 frames per launch, nothing else running."""
     W, H = 3840, 2160
-    src = torch.randint(0, 256, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint8)
-    dst = torch.empty_like(src)
+    src8 = torch.randint(0, 256, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint8)
+    dst8 = torch.empty_like(src8)
     ts = [capi.Transform.of(0.002, -0.0015, 3.3 + 0.37 * i, -2.7 - 0.21 * i) for i in range(frames)]
     pmc, pmc_name = load_profile("r04_warp_pmc.json", "r03_warp_pmc.json", "r02_warp_pmc.json")
     out = {}
     for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted"),
-                            ("bilinear", capi.WARP_BILINEAR, "bilinear")):
+                            ("bilinear", capi.WARP_BILINEAR, "bilinear"), ("bilinear_10bit", capi.WARP_BILINEAR, "bilinear_10bit")):
+        bits = 16 if name == "bilinear_10bit" else 8
+        if bits == 16:                                       # 10-bit frames in 16-bit containers (configs[4]'s format): twice the bytes per pixel
+            src8 = dst8 = None
+            src = torch.randint(0, 1024, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.int16)
+            dst = torch.empty_like(src)
+        else:
+            src, dst = src8, dst8
+
         def run():
-            capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, 8, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
-                                             max_value=255, stream=stream.cuda_stream)
+            capi.bgr_image_warp_batch_device(src.data_ptr(), frames, W, H, 3, bits, ts, dst.data_ptr(), mode, capi.BORDER_CLAMP,
+                                             max_value=255 if bits == 8 else 1023, stream=stream.cuda_stream)
         # The card's shader clock takes ~40 ms of continuous work to settle (tools/clock_settling.py: 64 -> 56 -> 49 us per frame over the
         # first 5 / 12 / 40 ms after an idle spell, flat from there on): launches back to back for >= 80 ms first, then `reps` more,
         # still back to back, each between two events on the launch stream.
@@ -290,12 +298,18 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in evs[4:])
         med = ms[len(ms) // 2]
-        nbytes = W * H * 3 * 2 * frames
+        nbytes = W * H * 3 * 2 * frames * (bits // 8)
         ach = nbytes / (med * 1e-3) / 1e9
         p = pmc.get(key, {})
         ipp = p.get("valu_instr_per_px")
         # VALU-peak fraction: wave-instructions the launch issues / what 1024 SIMDs issue in that time at one per 2 cycles
         valu_peak_frac = round(ipp * W * H * frames / 64.0 / (med * 1e-3) / VALU_WAVE_INSTR_PER_S, 4) if ipp else None
+        if name == "bilinear_10bit":
+            out[name] = {"kernel": "vs_k_bgr_warp_c3<u16,bilinear,clamp> (word tile)", "bound": "hbm", "binding": "hbm + valu",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
+                         "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR, 10-bit)"}
+            continue
         if name == "bilinear":
             # the stabilizer's DEFAULT sampler (cv::warpAffine INTER_LINEAR in the reference, imgproc.cpp:472): 88 vector instructions per
             # pixel (counted: profiles/r04_pmc_bilinear.json), VALU-issue-bound like the Lanczos kernels (profiles/r04_ab_warp_bilinear.md)

@@ -104,8 +104,20 @@ constexpr int WS_RS8 = WS_W + 8;
 #ifndef VS_WARP_TILE_H_BILINEAR_U8
 #define VS_WARP_TILE_H_BILINEAR_U8 32
 #endif
-constexpr int tile_h_of(bool u8tile) { return u8tile ? VS_WARP_TILE_H_BILINEAR_U8 : VS_WARP_TILE_H; }
-constexpr int tile_h_of(int bits, int mode) { return tile_h_of(bits == 8 && mode == 1 && VS_WARP_BILINEAR_U8_TILE); }
+// Bilinear on 16-bit containers (10 / 12 / 16-bit frames) the same way: the tile holds the source words, 8 bytes {B | G << 16, R} per
+// pixel (17 KB for a 64 x 16 output tile instead of 31 KB of float4), two pixels per ds_write_b128 in the fill, one ds_read2_b64 per window
+// row in the sampler, conversions by SDWA word select.  Same 88-pixel pitch: 176 dwords = 48 (mod 64), conflict-free like the byte tile.
+#ifndef VS_WARP_BILINEAR_U16_TILE
+#define VS_WARP_BILINEAR_U16_TILE 1
+#endif
+#ifndef VS_WARP_TILE_H_BILINEAR_U16
+#define VS_WARP_TILE_H_BILINEAR_U16 16
+#endif
+constexpr bool raw_tile_of(int bits, int mode) { return mode == 1 && (bits == 8 ? VS_WARP_BILINEAR_U8_TILE : VS_WARP_BILINEAR_U16_TILE) != 0; }
+constexpr int tile_h_of(int bits, int mode) {
+    return !raw_tile_of(bits, mode) ? VS_WARP_TILE_H : (bits == 8 ? VS_WARP_TILE_H_BILINEAR_U8 : VS_WARP_TILE_H_BILINEAR_U16);
+}
+static_assert(VS_WARP_TILE_H_BILINEAR_U16 % 8 == 0, "rows per wave in pairs");
 static_assert(VS_WARP_TILE_H_BILINEAR_U8 % 8 == 0 && (VS_WARP_TILE_H_BILINEAR_U8 + 8) / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
 // Experiment, off (bit-identical, slower): tiles whose whole footprint lies inside the frame skip the tile, every output pixel
 // fetching its 2 x 2 window with two unaligned 8-byte loads (B0 G0 R0 B1 G1 R1 + two spare bytes per row) through the vector L1.
@@ -408,6 +420,22 @@ __device__ __forceinline__ void sample_bilinear_u8(const __attribute__((address_
     }
 }
 
+// ... and on the word tile: t = the 8 bytes {B | G << 16, R | x << 16} of staged pixel (iy, ix)
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float uw(uint32_t q, int k) { return (float)((q >> (16 * k)) & 0xffffu); }
+__device__ __forceinline__ void sample_bilinear_u16(const __attribute__((address_space(3))) u32x2_t* t, f2 fr, float q[3]) {
+    const u32x2_t a0 = t[0], a1 = t[1], b0 = t[WS_RS8], b1 = t[WS_RS8 + 1];
+    const float tx = fr.x, ty = fr.y, otx = 1.0f - tx, oty = 1.0f - ty;
+    const float a0c[3] = {uw(a0.x, 0), uw(a0.x, 1), uw(a0.y, 0)}, a1c[3] = {uw(a1.x, 0), uw(a1.x, 1), uw(a1.y, 0)};
+    const float b0c[3] = {uw(b0.x, 0), uw(b0.x, 1), uw(b0.y, 0)}, b1c[3] = {uw(b1.x, 0), uw(b1.x, 1), uw(b1.y, 0)};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float top = a0c[c] * otx + a1c[c] * tx;
+        const float bot = b0c[c] * otx + b1c[c] * tx;
+        q[c] = top * oty + bot * ty;
+    }
+}
+
 // The same from the source bytes themselves: a = bytes {B0 G0 R0 B1 | G1 R1 . .} of row iy from pixel ix, b = the same of row iy + 1
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(1))) U32x2Unaligned { u32x2 v; };
@@ -499,18 +527,19 @@ __device__ __forceinline__ FillItem fill_item(int lane, int slot) {
 }
 
 template <typename T, int MODE, int BORDER>
-__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 1 && sizeof(T) == 1 && VS_WARP_BILINEAR_U8_TILE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
+__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
-    constexpr bool U8TILE = MODE == 1 && sizeof(T) == 1 && VS_WARP_BILINEAR_U8_TILE;
-    constexpr bool U8DIRECT = U8TILE && VS_WARP_BILINEAR_DIRECT;
+    constexpr bool U8TILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
+    constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
+    constexpr bool U8DIRECT = U8TILE && sizeof(T) == 1 && VS_WARP_BILINEAR_DIRECT;
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
-    constexpr int WT_H = tile_h_of(U8TILE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
+    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
     constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
     static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
     __shared__ f4 tile[U8TILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
-    __shared__ __attribute__((aligned(16))) uint32_t tile8[U8TILE ? WS_H * WS_RS8 : 4];    // bilinear on 8-bit frames: B | G << 8 | R << 16
+    __shared__ __attribute__((aligned(16))) uint32_t tile8[U8TILE ? WS_H * WS_RS8 * PXD : 4];    // bilinear: B | G << 8 | R << 16 (8-bit frames), {B | G << 16, R} (16-bit containers)
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
     if (w < 0) lds_pad[threadIdx.x] = 0;
@@ -648,6 +677,35 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
                 if (!live[s]) continue;
                 VS_BOUNDS_CHECK(it[s].row * WS_RS8 + 4 * it[s].g + 3, WS_H * WS_RS8, 204);
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                if (sizeof(T) == 2) {
+                    u32x4 lo, hi;                            // pixels 0, 1 and 2, 3 of the group
+                    if (direct[s]) {
+                        const u32x3 a = q0[s], b = q1[s];    // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3 (the sampler reads the low word of .y only)
+                        lo = u32x4{a.x, a.y, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
+                        hi = u32x4{b.x, b.y, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
+                    } else {
+                        const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+                        const bool row_in = sy >= 0 && sy < h;
+                        uint32_t d[4][2];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int pxi = sx + k;
+                            if (BORDER == 1 && (!row_in || pxi < 0 || pxi >= w)) d[k][0] = d[k][1] = 0u;
+                            else {
+                                const T* qq = rowp[s] + clampi(pxi, 0, w - 1) * 3;
+                                d[k][0] = (uint32_t)qq[0] | ((uint32_t)qq[1] << 16);
+                                d[k][1] = (uint32_t)qq[2];
+                            }
+                        }
+                        lo = u32x4{d[0][0], d[0][1], d[1][0], d[1][1]};
+                        hi = u32x4{d[2][0], d[2][1], d[3][0], d[3][1]};
+                    }
+                    VS_BOUNDS_CHECK((it[s].row * WS_RS8 + 4 * it[s].g + 3) * 2 + 1, WS_H * WS_RS8 * 2, 209);
+                    u32x4* dstp = (u32x4*)(tile8 + 2 * VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3));
+                    dstp[0] = lo;
+                    dstp[1] = hi;
+                    continue;
+                }
                 u32x4 px;
                 if (direct[s]) {
                     const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
@@ -750,7 +808,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
     const float A1x = A1 * fx, Bx = B * fx;
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
-    const float c0 = U8TILE ? -4.0f * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
+    const float c0 = U8TILE ? -4.0f * PXD * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
     const bool lane_in = x < roi.w;
     const int yw_first = yw;
 #pragma unroll 1
@@ -790,7 +848,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
             continue;
         }
         // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
-        const int boff = U8TILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * WS_RS8, __builtin_fmaf(flx, 4.0f, c0)), 4 * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
+        const int boff = U8TILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * PXD * WS_RS8, __builtin_fmaf(flx, 4.0f * PXD, c0)), 4 * PXD * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
                                 : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
                                                        16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
         t_all[k] = U8TILE ? (lds_f4)((const __attribute__((address_space(3))) char*)tile8 + boff)
@@ -827,6 +885,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : ((MODE == 
             if constexpr (DIRECT) {
                 sample_bilinear_bytes(ga[kp], gb[kp], fr[0], q[0]);
                 sample_bilinear_bytes(ga[kp + 1], gb[kp + 1], fr[1], q[1]);
+            } else if (U8TILE && sizeof(T) == 2) {
+                sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[0], fr[0], q[0]);
+                sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[1], fr[1], q[1]);
             } else if (U8TILE) {
                 sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[0], fr[0], q[0]);
                 sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[1], fr[1], q[1]);
