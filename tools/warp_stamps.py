@@ -80,7 +80,7 @@ def main():
     key = (xcc << 8) | ((hw >> 8) & 0xff)
     wg0 = t[:, :, 0].min(axis=1)
     wg1 = t[:, :, 7].max(axis=1)
-    conc, gaps, per_cu = [], [], []
+    conc, gaps, per_cu, mid = [], [], [], []
     for k in np.unique(key):
         m = key == k
         b0, e0 = wg0[m], wg1[m]
@@ -88,6 +88,8 @@ def main():
         if span <= 0 or m.sum() < 4:
             continue
         conc.append((e0 - b0).sum() / span)
+        lo, hi = b0.min() + 0.25 * span, b0.min() + 0.75 * span     # steady state: the middle half of this CU's recorded span
+        mid.append((np.clip(e0, lo, hi) - np.clip(b0, lo, hi)).sum() / (hi - lo))
         per_cu.append(int(m.sum()))
         # busy-slot view: a new workgroup can start when one ends; the delay from the k-th end to the (k + resident)-th start
         o = np.sort(b0)
@@ -95,6 +97,7 @@ def main():
     out["cus_seen"] = len(conc)
     out["workgroups_per_cu_recorded_mean"] = round(float(np.mean(per_cu)), 1)
     out["resident_workgroups_per_cu_mean"] = round(float(np.mean(conc)), 2)
+    out["resident_workgroups_per_cu_steady_state"] = round(float(np.mean(mid)), 2)
     out["median_cycles_between_workgroup_starts_on_a_cu"] = round(float(np.median(gaps)), 1)
     out["workgroup_lifetime_cycles_mean"] = round(float((wg1 - wg0).mean()), 1)
     print(json.dumps(out))
