@@ -143,6 +143,16 @@ __device__ unsigned long long g_warp_stamps[STAMP_WGS * 4 * STAMP_N];
 #define VS_STAMP_DRAIN() ((void)0)
 #endif
 
+// the aligned output stores: plain, or (experiment) non-temporal -- the output is written once and not read by this kernel
+#ifndef VS_WARP_NT_STORE
+#define VS_WARP_NT_STORE 0
+#endif
+#if VS_WARP_NT_STORE
+#define VS_STORE32(p, v) __builtin_nontemporal_store((uint32_t)(v), (uint32_t*)(p))
+#else
+#define VS_STORE32(p, v) (*(uint32_t*)(p) = (v))
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
             if (y < roi.h) {                                 // wave-uniform
                 uint8_t* orow = (uint8_t*)dst + (size_t)y * dst_stride;
                 if (rows_aligned && quad_in) {
-                    if (m < 3 && (!(VS_WARP_WHATIF & 8) || d == 0x12345678u)) *(uint32_t*)(orow + loff) = d;
+                    if (m < 3 && (!(VS_WARP_WHATIF & 8) || d == 0x12345678u)) VS_STORE32((uint32_t*)(orow + loff), d);
                 } else if (lane_in) {
                     orow[(size_t)x * 3] = (uint8_t)o[k][0];
                     orow[(size_t)x * 3 + 1] = (uint8_t)o[k][1];
@@ -951,8 +961,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                 T* orow = dst + (size_t)y * dst_stride;
                 if (rows_aligned && pair_in) {
                     uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
-                    if (x & 1) q[2] = d0;
-                    else { q[0] = d0; q[1] = d1; }
+                    if (x & 1) VS_STORE32(q + 2, d0);
+                    else { VS_STORE32(q, d0); VS_STORE32(q + 1, d1); }
                 } else if (lane_in) {
                     orow[(size_t)x * 3] = (T)o[k][0];
                     orow[(size_t)x * 3 + 1] = (T)o[k][1];
