@@ -36,7 +36,6 @@
 #include "vs_kernels.hpp"
 #include <algorithm>
 #include <cmath>
-#include <type_traits>
 #include <vector>
 #include "vs_device.hpp"
 
@@ -119,14 +118,6 @@ constexpr int tile_h_of(int bits, int mode) {
 }
 static_assert(VS_WARP_TILE_H_BILINEAR_U16 % 8 == 0, "rows per wave in pairs");
 static_assert(VS_WARP_TILE_H_BILINEAR_U8 % 8 == 0 && (VS_WARP_TILE_H_BILINEAR_U8 + 8) / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
-// Experiment, off (bit-identical, slower): tiles whose whole footprint lies inside the frame skip the tile, every output pixel
-// fetching its 2 x 2 window with two unaligned 8-byte loads (B0 G0 R0 B1 G1 R1 + two spare bytes per row) through the vector L1.
-// No fill, no barrier -- but a wave's 8-byte gather at a 3-byte lane stride costs ~40 cycles in the texture path against 8 for the two
-// ds_read2_b32: 23.8 us per 4K frame against the byte tile's 17.3 (18.3 with the stores removed; aligning the loads buys 1.7 us).
-// profiles/r04_ab_warp_bilinear.md, tools/ab_warp_bilinear_direct.sh.
-#ifndef VS_WARP_BILINEAR_DIRECT
-#define VS_WARP_BILINEAR_DIRECT 0
-#endif
 
 // analysis build (tools/warp_stamps.py): every wave of the first STAMP_WGS workgroups of a launch leaves eight s_memtime stamps
 // (entry, geometry done, loads issued, loads landed, tile written, barrier passed, rows stored, stores drained) and its HW_ID / XCC_ID
@@ -446,21 +437,6 @@ __device__ __forceinline__ void sample_bilinear_u16(const __attribute__((address
     }
 }
 
-// The same from the source bytes themselves: a = bytes {B0 G0 R0 B1 | G1 R1 . .} of row iy from pixel ix, b = the same of row iy + 1
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(1))) U32x2Unaligned { u32x2 v; };
-__device__ __forceinline__ void sample_bilinear_bytes(u32x2 a, u32x2 b, f2 fr, float q[3]) {
-    const float tx = fr.x, ty = fr.y, otx = 1.0f - tx, oty = 1.0f - ty;
-    const float a0[3] = {ub(a.x, 0), ub(a.x, 1), ub(a.x, 2)}, a1[3] = {ub(a.x, 3), ub(a.y, 0), ub(a.y, 1)};
-    const float b0[3] = {ub(b.x, 0), ub(b.x, 1), ub(b.x, 2)}, b1[3] = {ub(b.x, 3), ub(b.y, 0), ub(b.y, 1)};
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float top = a0[c] * otx + a1[c] * tx;
-        const float bot = b0[c] * otx + b1[c] * tx;
-        q[c] = top * oty + bot * ty;
-    }
-}
-
 template <typename T, int MODE, int BORDER>
 __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int w, int h, int stride, float Wx,
                                                   float Wy, float maxv, uint32_t out[3]) {
@@ -543,7 +519,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
     constexpr bool U8TILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
     constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
-    constexpr bool U8DIRECT = U8TILE && sizeof(T) == 1 && VS_WARP_BILINEAR_DIRECT;
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
     constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
     constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
@@ -574,10 +549,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)((size_t)src_stride * sizeof(T))) & 3) == 0;   // uniform
     float4 E = make_float4(0.f, 0.f, 0.f, 0.f);
     if (extents != nullptr) E = extents[frame];
-    const bool frame_addressable = src_stride < (1 << 23) && (unsigned long long)(unsigned)h * (unsigned)src_stride < 0x7fffffffULL;   // 32-bit byte offsets inside a frame (uniform)
 
     // everything about a tile that the fill and the sampler blocks need; all of it wave-uniform
-    struct Geom { int x0, y0, sx_lo, sy_lo, rows, groups; bool fits, interior, direct; };
+    struct Geom { int x0, y0, sx_lo, sy_lo, rows, groups; bool fits, interior; };
     auto geom = [&](int tl) -> Geom {
     const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);         // tl / tiles_x (scalar unit)
     const int txi = tl - tyi * tiles_x;
@@ -607,13 +581,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     }
     bool fits = fmaxf(fmaxf(fabsf(mnx), fabsf(mxx)), fmaxf(fabsf(mny), fabsf(mxy))) < 1.0e6f;
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
-    bool direct = false;
-    if (U8DIRECT && fits) {
-        // every pixel's 2 x 2 window, and the two spare bytes its 8-byte row loads take along (pixel ix + 2), inside the frame
-        const int fx_lo = (int)floorf(mnx), fx_hi = (int)floorf(mxx), fy_lo = (int)floorf(mny), fy_hi = (int)floorf(mxy);
-        direct = frame_addressable && fx_lo >= 0 && fx_hi + 2 < w && fy_lo >= 0 && fy_hi + 1 < h;
-        if (direct) return Geom{x0, y0, fx_lo, fy_lo, 0, 0, true, false, true};
-    }
     if (fits) {
         sx_lo = ((int)floorf(mnx) - 1) & ~3;               // first staged column: a multiple of 4 pixels (12 bytes)
         const int sx_hi = (int)floorf(mxx) + 2;
@@ -626,7 +593,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
     // tests per item, one offset from a uniform base
     const bool interior = !(VS_WARP_WHATIF & 256) && fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;   // uniform (analysis bit 256: every tile fills like a rim tile)
-    return Geom{x0, y0, sx_lo, sy_lo, rows, groups, fits, interior, false};
+    return Geom{x0, y0, sx_lo, sy_lo, rows, groups, fits, interior};
     };
 
     // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
@@ -784,9 +751,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     };
 
     // the sampler blocks and stores of one tile (LDS filled, barrier passed)
-    // (direct_tag: std::true_type = the tile-less bilinear path of a Geom::direct tile)
-    auto sample_tile = [&](const Geom& g, auto direct_tag) {
-    constexpr bool DIRECT = decltype(direct_tag)::value;
+    auto sample_tile = [&](const Geom& g) {
     const int x0 = g.x0, y0 = g.y0, sx_lo = g.sx_lo, sy_lo = g.sy_lo;
     const bool fits = g.fits;
     const int x = x0 + lane;
@@ -834,10 +799,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     // between packed ones than among themselves, tools/ubench_mix.hip)
     f2 fr_all[RB];
     lds_f4 t_all[RB];
-    u32x2 ga[RB], gb[RB];                                      // DIRECT: the two 8-byte rows of each pixel's window
-    // DIRECT: byte offsets count from the footprint's first pixel (g.sx_lo, g.sy_lo), a uniform base; all of them >= 0
-    const int gc = DIRECT ? sy_lo * src_stride + 3 * sx_lo : 0;
-    const uint8_t* gbase = (const uint8_t*)src + gc;
 #pragma unroll
     for (int k = 0; k < RB; k++) {
         const int yq = min(yw + k, roi.h - 1);               // rows below the window repeat its last row (masked below)
@@ -846,17 +807,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
         const float Wy = Bx + A1 * fy + TY;                  // generators.cpp:142
         const float flx = floorf(Wx), fly = floorf(Wy);
         fr_all[k] = f2{Wx - flx, Wy - fly};
-        if constexpr (DIRECT) {
-            const int ix = (int)flx, iy = (int)fly;
-            VS_BOUNDS_CHECK(ix - sx_lo, w - 2 - sx_lo, 206);       // ix >= the footprint's first column, ix + 2 < w
-            VS_BOUNDS_CHECK(iy - sy_lo, h - 1 - sy_lo, 207);
-            uint32_t off = (uint32_t)(__mul24(iy, src_stride) + 3 * ix - gc);
-            if (VS_WARP_WHATIF & 64) off &= ~3u;                    // (analysis: aligned 8-byte loads)
-            if (VS_WARP_WHATIF & 128) off &= ~7u;
-            ga[k] = ((const U32x2Unaligned*)(gbase + VS_DEBUG_CLAMP_BYTES(off, (uint32_t)(h - 1 - sy_lo) * (uint32_t)src_stride, 208)))->v;
-            gb[k] = ((const U32x2Unaligned*)(gbase + src_stride + VS_DEBUG_CLAMP_BYTES(off, (uint32_t)(h - 1 - sy_lo) * (uint32_t)src_stride, 208)))->v;
-            continue;
-        }
         // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
         const int boff = U8TILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * PXD * WS_RS8, __builtin_fmaf(flx, 4.0f * PXD, c0)), 4 * PXD * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
                                 : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
@@ -892,10 +842,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                 else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else {
-            if constexpr (DIRECT) {
-                sample_bilinear_bytes(ga[kp], gb[kp], fr[0], q[0]);
-                sample_bilinear_bytes(ga[kp + 1], gb[kp + 1], fr[1], q[1]);
-            } else if (U8TILE && sizeof(T) == 2) {
+            if (U8TILE && sizeof(T) == 2) {
                 sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[0], fr[0], q[0]);
                 sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[1], fr[1], q[1]);
             } else if (U8TILE) {
@@ -981,12 +928,6 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
 #pragma unroll 1
     for (int i = 0; i < NT; i++) {
         const bool more = i + 1 < NT && tl0 + i + 1 < tl_end;        // (uniform)
-        if (U8DIRECT && g.direct) {                                    // no tile: nothing to fill, nothing to wait for
-            sample_tile(g, std::true_type{});
-            if (!more) break;
-            g = geom(tl0 + i + 1); loaded = false;
-            continue;
-        }
         if (g.fits && !(VS_WARP_WHATIF & 2)) fill(g, loaded);
         VS_STAMP(4);
         __syncthreads();
@@ -997,7 +938,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
             gn = geom(tl0 + i + 1);
             if (gn.interior) { issue(gn); loaded_n = true; }          // in flight during this tile's sampler blocks
         }
-        sample_tile(g, std::false_type{});
+        sample_tile(g);
         VS_STAMP(6);
         VS_STAMP_DRAIN();
         VS_STAMP(7);
