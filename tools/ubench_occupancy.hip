@@ -4,6 +4,7 @@
 //   fma16      16 independent v_fma_f32 per iteration
 //   tap        the contracted Lanczos tap: ds_read_b128 (4 KB tile), v_mul_f32 (w2d), 4 v_fma_f32  -- x4 per iteration, one wait
 //   mix        8 v_fma_f32 + 4 v_mul_f32 + 2 v_cvt_f32_ubyte0 + 2 v_sub_f32 per iteration (roughly the sampler's mix)
+//   pkfma16 / pk|fma by wave / pk,fma alternating: is the packed + scalar mixing penalty per wave (instruction adjacency) or per SIMD?
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/build/ubench_occupancy tools/ubench_occupancy.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -19,13 +20,35 @@ __global__ __launch_bounds__(256, 8) void k(Stamp* stamps, float* out, float see
     __shared__ f4 tile[256];
     tile[threadIdx.x] = f4{seed, seed * 2.f, seed * 3.f, 1.f};
     __syncthreads();
+    typedef float f2 __attribute__((ext_vector_type(2)));
     float a[16];
+    f2 pa[8];
 #pragma unroll
     for (int i = 0; i < 16; i++) a[i] = seed + (float)i;
+#pragma unroll
+    for (int i = 0; i < 8; i++) pa[i] = f2{seed - (float)i, seed * (float)i};
     float x = seed * 0.5f, y = seed * 0.25f;
     unsigned u = __float_as_uint(seed) | 0x01020304u;
     const __attribute__((address_space(3))) f4* t = (const __attribute__((address_space(3))) f4*)tile + (threadIdx.x & 63);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (KIND == 4) {
+        // waves of alternate workgroups run 16 v_pk_fma_f32 / 16 v_fma_f32 per iteration: each SIMD hosts both kinds side by side, no wave mixes them
+        // (workgroups are dealt round-robin over the 8 XCDs: bit 3 of the id alternates between the workgroups that share a CU)
+        const f2 px = f2{x, y}, py = f2{y, x};
+        if (((blockIdx.x >> 3) & 1) == 0) {
+#pragma unroll 1
+            for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pa[i & 7]) : "v"(px), "v"(py));
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+            }
+        }
+    } else
 #pragma unroll 1
     for (int it = 0; it < ITERS; it++) {
         if (KIND == 0) {
@@ -45,6 +68,19 @@ __global__ __launch_bounds__(256, 8) void k(Stamp* stamps, float* out, float see
                 asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[2]) : "v"(w), "v"(v[j].z));
                 asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[3]) : "v"(w), "v"(v[j].w));
             }
+        } else if (KIND == 3 || KIND == 5) {
+            // 3: every wave runs 16 v_pk_fma_f32; 5: every wave alternates v_pk_fma_f32 and v_fma_f32 instruction by instruction
+            const f2 px = f2{x, y}, py = f2{y, x};
+            if (KIND == 5) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pa[i & 3]) : "v"(px), "v"(py));
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[8 + i]) : "v"(x), "v"(y));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pa[i & 7]) : "v"(px), "v"(py));
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
@@ -61,6 +97,8 @@ __global__ __launch_bounds__(256, 8) void k(Stamp* stamps, float* out, float see
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; i++) s += a[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += pa[i].x + pa[i].y;
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -85,7 +123,7 @@ template <int K> static int run(const char* name, int valu_per_iter, Stamp* dst,
         std::sort(clk.begin(), clk.end());
         const double ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
         const double n = (double)ITERS * valu_per_iter;
-        std::printf("%-8s waves/SIMD %d: %7.3f ms wall | in-kernel clock %.3f GHz | %.2f cycles per VALU instruction per SIMD\n", name, wps, ms, ghz,
+        std::printf("%-20s waves/SIMD %d: %7.3f ms wall | in-kernel clock %.3f GHz | %.2f cycles per VALU instruction per SIMD\n", name, wps, ms, ghz,
                     ms * 1e-3 * ghz * 1e9 / (n * wps));
     }
     return 0;
@@ -94,5 +132,6 @@ int main() {
     float* d; CK(hipMalloc(&d, 64));
     Stamp* st; CK(hipMalloc(&st, sizeof(Stamp) * 256 * 8 * 4));
     run<0>("fma16", 16, st, d); run<1>("tap", 20, st, d); run<2>("mix", 16, st, d);
+    run<3>("pkfma16", 16, st, d); run<4>("pk|fma by wave", 16, st, d); run<5>("pk,fma alternating", 16, st, d);
     return 0;
 }
