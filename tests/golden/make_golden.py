@@ -81,10 +81,33 @@ def stabilizer_fixture():
                         out_checksum=np.array(outs, np.int64), last=o)
 
 
+def warp_modes_fixture():
+    """round 4: the forms of bgr_image_warp that the first fixture predates -- the contracted Lanczos2 twin (VSO_WARP_LANCZOS2_CONTRACTED), 10-bit
+    frames in all three modes (the word-tile bilinear path and the u16 Lanczos kernels on the GPU side), a window -- and the two selection rules"""
+    d = {}
+    bgr8, _ = synth.make_clip(96, 64, 1, seed=105, channels=3, path=[(0, 0, 0, 0)], margin=8)
+    bgr10, _ = synth.make_clip(83, 47, 1, seed=106, channels=3, bits=10, path=[(0, 0, 0, 0)], margin=8)
+    d["bgr8"], d["bgr10"] = bgr8[0], bgr10[0]
+    tw = (0.012, -0.007, -1.7, 2.45)
+    d["tw"] = np.array(tw)
+    for border in (0, 1):
+        d["u8_m2_b%d" % border] = O.bgr_image_warp(bgr8[0], O.Transform.of(*tw), O.WARP_LANCZOS2_CONTRACTED, border)
+        for mode in (0, 1, 2):
+            d["u10_m%d_b%d" % (mode, border)] = O.bgr_image_warp(bgr10[0], O.Transform.of(*tw), mode, border, max_value=1023)
+    rng = np.random.default_rng(107)
+    wd = np.minimum(rng.poisson(3.0, (27, 31)), 65535).astype(np.uint16)
+    d["wd"] = wd
+    d["sel_stl"] = O.select_smallest(wd, 0.8)
+    d["sel_stable"] = O.select_smallest_stable(wd, 0.8)
+    np.savez_compressed(os.path.join(HERE, "warp_modes_96x64.npz"), **d)
+
+
 if __name__ == "__main__":
-    kernels_fixture()
-    aligner_fixture()
-    stabilizer_fixture()
+    if "--only-new" not in sys.argv:                # (the first three files are frozen: regenerate them only on purpose)
+        kernels_fixture()
+        aligner_fixture()
+        stabilizer_fixture()
+    warp_modes_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -99,3 +99,34 @@ def test_gpu_matches_aligner_and_stabilizer_fixtures(gpu_vs):
         assert (o is None) == (int(s["out_checksum"][i]) == -1)
     d = np.abs(o.astype(np.int16) - s["last"].astype(np.int16))
     assert d.max() <= 1 and (d != 0).mean() < 1e-2
+
+
+def _warp_modes_outputs(m, d):
+    T = m.Transform.of
+    contracted = getattr(m, "WARP_LANCZOS2_CONTRACTED", None) or m.WARP_LANCZOS2_FAST      # the oracle's / the product's name of mode 2
+    out = {}
+    for border in (0, 1):
+        out["u8_m2_b%d" % border] = m.bgr_image_warp(d["bgr8"], T(*d["tw"]), contracted, border)
+        for mode in (0, 1, 2):
+            out["u10_m%d_b%d" % (mode, border)] = m.bgr_image_warp(d["bgr10"], T(*d["tw"]), mode, border, max_value=1023)
+    return out
+
+
+def test_oracle_reproduces_warp_modes_fixture(oracle):
+    """round-4 fixture: the contracted Lanczos2 twin, 10-bit frames in all three modes, the two selection rules"""
+    d = np.load(os.path.join(G, "warp_modes_96x64.npz"))
+    for k, v in _warp_modes_outputs(oracle, d).items():
+        assert np.array_equal(v, d[k]), k
+    assert np.array_equal(oracle.select_smallest(d["wd"], 0.8), d["sel_stl"])
+    assert np.array_equal(oracle.select_smallest_stable(d["wd"], 0.8), d["sel_stable"])
+    assert int(d["u10_m1_b0"].max()) > 255                  # (really 10-bit content)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_warp_modes_fixture(gpu_vs):
+    d = np.load(os.path.join(G, "warp_modes_96x64.npz"))
+    for k, v in _warp_modes_outputs(gpu_vs, d).items():
+        assert np.array_equal(v, d[k]), k
+    got, status = gpu_vs.select_smallest(d["wd"], 0.8)
+    assert not status.any() and np.array_equal(got[0], d["sel_stl"])
+    assert np.array_equal(gpu_vs.select_smallest_stable(d["wd"], 0.8)[0], d["sel_stable"])
