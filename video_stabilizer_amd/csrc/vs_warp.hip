@@ -517,14 +517,14 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
-    constexpr bool U8TILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
+    constexpr bool RAWTILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
     constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
     constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
     constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
     static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
-    __shared__ f4 tile[U8TILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
-    __shared__ __attribute__((aligned(16))) uint32_t tile8[U8TILE ? WS_H * WS_RS8 * PXD : 4];    // bilinear: B | G << 8 | R << 16 (8-bit frames), {B | G << 16, R} (16-bit containers)
+    __shared__ f4 tile[RAWTILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
+    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[RAWTILE ? WS_H * WS_RS8 * PXD : 4];    // bilinear: B | G << 8 | R << 16 (8-bit frames), {B | G << 16, R} (16-bit containers)
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
     if (w < 0) lds_pad[threadIdx.x] = 0;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
         }
         uint32_t one = 1u;
         asm volatile("" : "+v"(one));                        // opaque: keeps the conversion below from folding to a constant
-        if (U8TILE) {
+        if (RAWTILE) {
 #pragma unroll
             for (int s = 0; s < FILL_SLOTS; s++) {
                 if (!live[s]) continue;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                         hi = u32x4{d[2][0], d[2][1], d[3][0], d[3][1]};
                     }
                     VS_BOUNDS_CHECK((it[s].row * WS_RS8 + 4 * it[s].g + 3) * 2 + 1, WS_H * WS_RS8 * 2, 209);
-                    u32x4* dstp = (u32x4*)(tile8 + 2 * VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3));
+                    u32x4* dstp = (u32x4*)(tile_raw + 2 * VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3));
                     dstp[0] = lo;
                     dstp[1] = hi;
                     continue;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                     }
                     px = u32x4{d[0], d[1], d[2], d[3]};
                 }
-                *(u32x4*)(tile8 + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3)) = px;
+                *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, WS_H * WS_RS8 - 3)) = px;
             }
             return;
         }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
     const float A1x = A1 * fx, Bx = B * fx;
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
-    const float c0 = U8TILE ? -4.0f * PXD * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
+    const float c0 = RAWTILE ? -4.0f * PXD * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
     const bool lane_in = x < roi.w;
     const int yw_first = yw;
 #pragma unroll 1
@@ -808,10 +808,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
         const float flx = floorf(Wx), fly = floorf(Wy);
         fr_all[k] = f2{Wx - flx, Wy - fly};
         // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
-        const int boff = U8TILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * PXD * WS_RS8, __builtin_fmaf(flx, 4.0f * PXD, c0)), 4 * PXD * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
+        const int boff = RAWTILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * PXD * WS_RS8, __builtin_fmaf(flx, 4.0f * PXD, c0)), 4 * PXD * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
                                 : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
                                                        16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
-        t_all[k] = U8TILE ? (lds_f4)((const __attribute__((address_space(3))) char*)tile8 + boff)
+        t_all[k] = RAWTILE ? (lds_f4)((const __attribute__((address_space(3))) char*)tile_raw + boff)
                           : (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
     }
 #if VS_WARP_COORDS_FIRST
@@ -842,10 +842,10 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                 else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
             }
         } else {
-            if (U8TILE && sizeof(T) == 2) {
+            if (RAWTILE && sizeof(T) == 2) {
                 sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[0], fr[0], q[0]);
                 sample_bilinear_u16((const __attribute__((address_space(3))) u32x2_t*)t[1], fr[1], q[1]);
-            } else if (U8TILE) {
+            } else if (RAWTILE) {
                 sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[0], fr[0], q[0]);
                 sample_bilinear_u8((const __attribute__((address_space(3))) uint32_t*)t[1], fr[1], q[1]);
             } else {
