@@ -1508,14 +1508,18 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     const bool dense_dev = s && mem == VS_MEM_DEVICE && w > 0 && stride == 3 * w && frame_stride == (size_t)h * stride;
     int group_clips = 0;
     if (overlap_env && dense_dev && clip_len >= 2 && n_clips_all >= 2 && n == n_clips_all * clip_len) {
-        // groups of at least kSharedMinPairs pairs (the small build's threshold), at most 8 groups
+        // groups of at least kSharedMinPairs pairs (the small build's threshold), at most 4 groups (VS_STAB_GROUPS): every group boundary is a host
+        // synchronisation and a latency-bound solver launch -- c5 (8 clips x 60 x 4K 10-bit) 17.3-18.1 k frames/s with 8 groups, 18.9-19.5 k with 4
         group_clips = std::max(1, (kSharedMinPairs + clip_len - 2) / (clip_len - 1));
-        group_clips = std::max(group_clips, (n_clips_all + 7) / 8);
+        static const int max_groups = []() { const char* e = getenv("VS_STAB_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+        group_clips = std::max(group_clips, (n_clips_all + max_groups - 1) / max_groups);
         if (group_clips >= n_clips_all) group_clips = 0;
     }
-    // one long clip: time chunks of >= 48 frames (the small solver build's threshold with room to spare), at most 8 of them
+    // one long clip: time chunks of >= 48 frames (the small solver build's threshold with room to spare), at most 4 of them (VS_STAB_TIME_CHUNKS:
+    // 1080p x480 64 k frames/s with 8 chunks, 70 k with 6, 72 k with 4 or 3, 69-71 k with 2; profiles/r04_stab_long_clip.txt)
     int time_chunk = 0;
-    if (overlap_env && dense_dev && clip_len == 0 && n >= 96) time_chunk = std::max(48, (n + 7) / 8);
+    static const int max_time_chunks = []() { const char* e = getenv("VS_STAB_TIME_CHUNKS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+    if (overlap_env && dense_dev && clip_len == 0 && n >= 96) time_chunk = std::max(48, (n + max_time_chunks - 1) / max_time_chunks);
     if (chunk > 0 && n > chunk)
         r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
                                     out_w, out_h);
