@@ -67,7 +67,7 @@ namespace {
 #define VS_WARP_TILES_PER_WG 1           // consecutive tiles of its XCD's run a workgroup walks; > 1: the next tile's source loads are in flight during the current tile's sampler blocks
 #endif
 #ifndef VS_WARP_TILES_PER_WG_BILINEAR
-#define VS_WARP_TILES_PER_WG_BILINEAR VS_WARP_TILES_PER_WG     // the same for the bilinear mode (29 arithmetic instructions per pixel: bound by the fill's load latency, not by issue)
+#define VS_WARP_TILES_PER_WG_BILINEAR VS_WARP_TILES_PER_WG     // the same for the bilinear mode (measured twice, float tile and raw tile: equal or slower, profiles/r04_ab_warp_bilinear.md)
 #endif
 #ifndef VS_WARP_ROW_BLOCK
 #define VS_WARP_ROW_BLOCK 4              // rows a wave computes in one straight-line block (even); a wave's rows are walked in such blocks
@@ -89,9 +89,10 @@ constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;   // fill items pe
 // (8-lane groups = 4 rows x 2 column groups, 64-byte column-group stride) touch every bank once.
 constexpr int WS_RS = WS_W + 1;
 // Bilinear mode on 8-bit frames: the tile holds the source BYTES, one dword {B,G,R,0} per pixel (8.4 KB instead of 31 KB: 8 workgroups
-// per CU instead of 5), and the sampler converts its four taps itself (v_cvt_f32_ubyteN: the byte select is free).  With ~60 vector
-// instructions per pixel the bilinear kernel is bound by the bytes a CU keeps in flight, not by issue: the float tile's fill (load ->
-// 16 conversions -> 4 x ds_write_b128 per item -> barrier) was 15 of its 21.8 us per 4K frame (profiles/r04_ab_warp_bilinear.md).
+// per CU instead of 5), and the sampler converts its four taps itself (v_cvt_f32_ubyteN: the byte select is free).  The float tile's fill
+// (load -> 16 conversions -> 4 x ds_write_b128 per item -> barrier) and its share of the memory traffic were 15 of the kernel's 21.8 us per
+// 4K frame; with the byte tile the kernel is VALU-bound by count like its Lanczos siblings (88 vector instructions per pixel, ~70 of them
+// the sampler: counters and time stamps in profiles/r04_ab_warp_bilinear.md).
 // Row pitch 88 dwords = 24 (mod 64): the fill's 8-lane ds_write_b128 groups (4 rows x 2 column groups) touch every bank once.
 #ifndef VS_WARP_BILINEAR_U8_TILE
 #define VS_WARP_BILINEAR_U8_TILE 1
