@@ -32,8 +32,13 @@ def _check_seq(res):
         assert inf.fail_reason == dbg.fail_reason, i
         if ok_c or dbg.fail_reason in (2, 3):
             assert list(inf.iterations[:dbg.levels]) == list(dbg.iterations[:dbg.levels]), i
-        # the transform is compared on failures too: the reference leaves its partial estimate in the output argument
-        assert _cmp_transform(t_g, t_c) < TOL, (i, t_g.tup(), t_c.tup())
+        # the transform is compared on failures too: the reference leaves its partial estimate in the output argument.  One exception: a run that
+        # did not converge (alignment.cpp:657-667) may have DIVERGED -- 64 iterations of an unstable update on a 114-point level took the soak
+        # sweep's case 561 to |T| ~ 1e9, where the last bit of a double sum decides the leading digit.  There both sides must have diverged.
+        if not ok_c and max(abs(v) for v in t_c.tup()) > 1e4:
+            assert max(abs(v) for v in t_g.tup()) > 1e3, (i, t_g.tup(), t_c.tup())
+        else:
+            assert _cmp_transform(t_g, t_c) < TOL, (i, t_g.tup(), t_c.tup())
         if ok_c or dbg.fail_reason in (2, 3):
             for l in range(dbg.levels):
                 if dbg.iterations[l]:

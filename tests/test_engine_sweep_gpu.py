@@ -2,12 +2,15 @@
 (alignment.hpp:9-21 VideoAlignerParams), selection mode and the camera path's roughness all drawn at random.  Same gate as
 test_engine_gpu.py (its _check_seq): success / failure decisions, failure reasons, iteration counts per level, selected-point
 counts, condition numbers and the per-level and final transforms (1e-4)."""
+import os
+
 import numpy as np
 import pytest
 
 from test_engine_gpu import TOL, _check_seq, _cmp_transform, _run_both
 
 pytestmark = pytest.mark.gpu
+_SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
 
 
 def _draw(rng):
@@ -25,7 +28,7 @@ def _draw(rng):
     return w, h, int(rng.choice([1, 3])), int(rng.choice([8, 8, 10])), params, float(rng.choice([0.5, 2.0, 6.0]))
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(96 * _SCALE))
 def test_random_configuration_matches_the_oracle(gpu_vs, oracle, seed):
     from video_stabilizer_amd import synth
     rng = np.random.default_rng(9000 + seed)
@@ -44,7 +47,7 @@ def test_random_configuration_matches_the_oracle(gpu_vs, oracle, seed):
     assert not res[0][0]                                    # first frame: no previous frame (alignment.cpp:231-234)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_random_stabilizer_configuration_matches_the_oracle(gpu_vs, oracle, seed):
     """processFrame (stabilizer.cpp:9-117) with random VideoStabilizerParams (stabilizer.hpp:13-30) and both warp modes / borders:
     same has-output sequence, same measurement / accumulated transforms, frames within 1 LSB (the gate of test_stabilizer_matches_oracle)."""

@@ -2,10 +2,13 @@
 (a3), the fused keyframe tables = grad_argmax + sparse_jac (a4, a5) with the reference's tile-size rule or a forced tile size,
 sparse_warpdiff (a6) and sparse_ica (a9, 1e-12 relative: fp64 tree sum against the serial sum) -- on random frame sizes (odd, tiny,
 wider than a strip), content from smooth to tie-heavy, and random transforms."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
 
 
 def _content(rng, w, h):
@@ -24,7 +27,7 @@ def _content(rng, w, h):
     return img
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 * _SCALE))
 def test_random_chain_is_bit_exact(gpu_vs, oracle, seed):
     rng = np.random.default_rng(52000 + seed)
     w, h = int(rng.integers(8, 900)), int(rng.integers(8, 420))

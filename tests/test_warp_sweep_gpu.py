@@ -1,10 +1,13 @@
 """Seeded random sweep of bgr_image_warp against the CPU restatement, bit for bit: frame sizes from one pixel up,
 8 / 10 / 12 / 16-bit containers, the three samplers, both borders, transforms from near-identity to degenerate (zero scale, mirror,
 far outside the frame), two-frame batches and output windows (a window = the same rows and columns cut out of the whole warp)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
 
 
 def _transform(rng):
@@ -22,7 +25,7 @@ def _transform(rng):
     return (0.0, 0.0, float(rng.integers(-5, 6)), float(rng.integers(-5, 6)))     # integer shift: weights exactly {0, 1}
 
 
-@pytest.mark.parametrize("seed", range(200))
+@pytest.mark.parametrize("seed", range(200 * _SCALE))
 def test_random_warp_is_bit_exact(gpu_vs, oracle, seed):
     rng = np.random.default_rng(31000 + seed)
     small = rng.random() < 0.3
