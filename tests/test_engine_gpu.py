@@ -21,7 +21,8 @@ def _diverged(t):
 
 def _run_both(vs, oracle, frames, select_mode=0, **params):
     gpu = vs.Aligner(device=0, select_mode=select_mode, **params)
-    cpu = oracle.Aligner(**params)
+    # (the stable rule has its own twin in the oracle: select rule 1; the two other modes both mean std::nth_element's order)
+    cpu = oracle.Aligner(select_rule=oracle.SELECT_STABLE, **params) if select_mode == vs.SELECT_STABLE else oracle.Aligner(**params)
     res = []
     for f in frames:
         ok_g, t_g = gpu.align_next(f)

@@ -41,7 +41,7 @@ def test_random_configuration_matches_the_oracle(gpu_vs, oracle, seed):
     frames, _ = synth.make_clip(w, h, 5, seed=700 + seed, channels=ch, bits=bits, jitter_t=rough)
     if bits == 10 and ch == 1:
         frames = (frames >> 2).astype(np.uint8)            # (gray frames are 8-bit only: VS_FMT_GRAY8)
-    mode = int(rng.choice([gpu_vs.SELECT_STL_HOST, gpu_vs.SELECT_DEVICE]))
+    mode = int(rng.choice([gpu_vs.SELECT_STL_HOST, gpu_vs.SELECT_DEVICE, gpu_vs.SELECT_STABLE]))     # (stable: against the oracle's rule 1)
     gpu, cpu, res = _run_both(gpu_vs, oracle, frames, select_mode=mode, **params)
     _check_seq(res)
     assert not res[0][0]                                    # first frame: no previous frame (alignment.cpp:231-234)
@@ -62,7 +62,10 @@ def test_random_stabilizer_configuration_matches_the_oracle(gpu_vs, oracle, seed
     kw["lambda"] = float(rng.choice([0.5, 2.0, 8.0]))
     n = 14
     frames, _ = synth.make_clip(w, h, n, seed=300 + seed, channels=3, bits=bits, jitter_t=float(rng.choice([1.0, 4.0, 12.0])))
-    g, c = gpu_vs.Stabilizer(device=0, **kw), oracle.Stabilizer(**kw)
+    if rng.random() < 0.33:                                 # the documented STL-independent selection rule on both sides
+        g, c = gpu_vs.Stabilizer(device=0, select_mode=gpu_vs.SELECT_STABLE, **kw), oracle.Stabilizer(select_rule=oracle.SELECT_STABLE, **kw)
+    else:
+        g, c = gpu_vs.Stabilizer(device=0, **kw), oracle.Stabilizer(**kw)
     produced = 0
     for i, f in enumerate(frames):
         og, oc = g.process(f), c.process(f)
