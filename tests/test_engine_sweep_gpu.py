@@ -137,3 +137,57 @@ def test_random_batch_forms_equal_frame_at_a_time(gpu_vs, seed):
             assert bool(hb[i]) == (outs[i] is not None), i
             if outs[i] is not None:
                 assert np.array_equal(ob[i], outs[i]), (i, skw)
+
+
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
+def test_random_clip_batches_equal_fresh_handles(gpu_vs, seed):
+    """vs_aligner_align_clips / vs_stabilizer_process_clips: every clip as if it went through its own fresh handle (include/vs_amd.h), for random clip
+    counts and lengths -- the device-resident form cuts the clips into groups whose warps run under the next group's alignment, and one long clip
+    into time chunks (at most four of each), so group and chunk boundaries fall in different places from case to case."""
+    import torch
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(88000 + seed)
+    w, h = int(rng.integers(140, 330)), int(rng.integers(110, 250))
+    bits = int(rng.choice([8, 8, 10]))
+    n_clips, fpc = int(rng.integers(1, 10)), int(rng.choice([3, 6, 13, 29, 61]))
+    if n_clips == 1:
+        fpc = int(rng.choice([100, 131, 200]))                    # one long clip: the time-chunk path (>= 96 frames)
+    skw = dict(lag=int(rng.integers(1, 6)), smoother_memory=int(rng.integers(0, 4)), crop_pixels=int(rng.integers(0, 16)),
+               warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)),
+               pyramid_min_width=int(rng.integers(16, w // 4)), pyramid_min_height=int(rng.integers(12, h // 4)))
+    base = [synth.make_clip(w, h, min(fpc, 10), seed=6000 + 10 * seed + c, channels=3, bits=bits, jitter_t=float(rng.choice([1.0, 4.0])))[0]
+            for c in range(n_clips)]
+    clips = [np.ascontiguousarray(b[np.arange(fpc) % len(b)]) for b in base]
+    allf = np.concatenate(clips)
+    c = skw["crop_pixels"]
+    want, want_has, want_t = [], [], []
+    for clip in clips:
+        s = gpu_vs.Stabilizer(device=0, **skw)
+        a = gpu_vs.Aligner(device=0, **{k: skw[k] for k in ("pyramid_min_width", "pyramid_min_height")})
+        for f in clip:
+            o = s.process(f)
+            want_has.append(0 if o is None else 1)
+            want.append(np.zeros((h - 2 * c, w - 2 * c, 3), allf.dtype) if o is None else o)
+            want_t.append(a.align_next(f))
+    want = np.stack(want)
+    fmt = gpu_vs.FMT_BGR8 if bits == 8 else gpu_vs.FMT_BGR10
+    dev = torch.from_numpy(allf.view(np.int16) if bits > 8 else allf).to("cuda:0")
+    out = torch.zeros((len(allf), h - 2 * c, w - 2 * c, 3), dtype=dev.dtype, device="cuda:0")
+    s = gpu_vs.Stabilizer(device=0, **skw)
+    if n_clips == 1:
+        r, has = s.process_batch_device(dev.data_ptr(), fpc, w, h, fmt, out.data_ptr())
+    else:
+        r, has = s.process_clips_device(dev.data_ptr(), n_clips, fpc, w, h, fmt, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    got = got.view(np.uint16) if bits > 8 else got
+    assert has == want_has and r == sum(want_has), (n_clips, fpc, skw)
+    for i in range(len(allf)):
+        if want_has[i]:
+            assert np.array_equal(got[i], want[i]), (i, n_clips, fpc, skw)
+    al = gpu_vs.Aligner(device=0, **{k: skw[k] for k in ("pyramid_min_width", "pyramid_min_height")})
+    st, ts = al.align_clips(len(allf), n_clips, mem_ptr=dev.data_ptr(), w=w, h=h, fmt=fmt)
+    for i in range(len(allf)):
+        assert bool(st[i]) == want_t[i][0], i
+        if want_t[i][0] or max(abs(v) for v in want_t[i][1].tup() + ts[i].tup()) <= 2.0 ** 31:
+            assert ts[i].tup() == want_t[i][1].tup(), i
