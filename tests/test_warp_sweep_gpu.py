@@ -47,3 +47,26 @@ def test_random_warp_is_bit_exact(gpu_vs, oracle, seed):
     rx, ry = int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1))
     win = gpu_vs.bgr_image_warp_roi_batch(src, ts, (rx, ry, rw, rh), mode, border, max_value=max_value)
     assert np.array_equal(win, exp[:, ry:ry + rh, rx:rx + rw]), (w, h, bits, mode, border, trs, (rx, ry, rw, rh))
+
+
+@pytest.mark.parametrize("seed", range(80 * _SCALE))
+def test_random_generic_warp_forms_are_bit_exact(gpu_vs, oracle, seed):
+    """what the tuned 3-channel kernel does not take: 1 / 2 / 4 channels, float output (the type of the reference's image_warp, generators.cpp:126-164),
+    image_warp itself (gray u8 -> f32 bilinear) and the BGR -> gray conversion, on random sizes and transforms"""
+    rng = np.random.default_rng(41000 + seed)
+    small = rng.random() < 0.3
+    w = int(rng.integers(1, 40)) if small else int(rng.integers(40, 300))
+    h = int(rng.integers(1, 30)) if small else int(rng.integers(30, 200))
+    tr = _transform(rng)
+    mode, border = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    c = int(rng.choice([1, 2, 3, 4]))
+    bits = int(rng.choice([8, 16]))
+    src = rng.integers(0, 256 if bits == 8 else 65536, (h, w, c)).astype(np.uint8 if bits == 8 else np.uint16)
+    f32 = bool(rng.integers(0, 2)) or c == 3                     # (3 channels with integer output is the tuned kernel's job: the other test)
+    g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode, border, f32=f32)
+    o = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), mode, border, f32=f32)
+    assert np.array_equal(g, o, equal_nan=True), (w, h, c, bits, mode, border, f32, tr)
+    gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    assert np.array_equal(gpu_vs.image_warp(gray, gpu_vs.Transform.of(*tr)), oracle.image_warp(gray, oracle.Transform.of(*tr)), equal_nan=True), (w, h, tr)
+    bgr = rng.integers(0, 256 if bits == 8 else 1024, (h, w, 3)).astype(src.dtype)
+    assert np.array_equal(gpu_vs.bgr_to_gray(bgr), oracle.bgr_to_gray(bgr)), (w, h, bits)
