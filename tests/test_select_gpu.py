@@ -1,15 +1,18 @@
 """The on-device replica of libstdc++'s std::nth_element (alignment.cpp:466-486) must leave the same
 elements in the same order as the host's std::nth_element -- the reference's result depends on both."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # soak runs: this many times the random cases
 
 
 def _cases():
     rng = np.random.default_rng(0)
     out = []
-    for trial in range(160):
+    for trial in range(160 * _SCALE):
         tx, ty = int(rng.integers(1, 70)), int(rng.integers(1, 70))
         hi = int(rng.choice([1, 2, 3, 5, 20, 300, 60000]))
         wd = rng.integers(0, hi, (ty, tx)).astype(np.uint16)
@@ -29,6 +32,8 @@ def test_select_matches_std_nth_element(gpu_vs, oracle):
         ref = oracle.select_smallest(wd, frac)
         assert status[0] == 0
         assert np.array_equal(got[0], ref), (wd.shape, frac)
+        # the documented STL-independent rule on the same tables (oracle select rule 1)
+        assert np.array_equal(gpu_vs.select_smallest_stable(wd, frac)[0], oracle.select_smallest_stable(wd, frac)), (wd.shape, frac)
 
 
 @pytest.mark.parametrize("tx,ty", [(40, 30), (96, 54), (192, 108), (45, 44), (2, 2), (3, 1), (1, 1), (161, 161)])
