@@ -191,3 +191,36 @@ def test_random_clip_batches_equal_fresh_handles(gpu_vs, seed):
         assert bool(st[i]) == want_t[i][0], i
         if want_t[i][0] or max(abs(v) for v in want_t[i][1].tup() + ts[i].tup()) <= 2.0 ** 31:
             assert ts[i].tup() == want_t[i][1].tup(), i
+
+
+@pytest.mark.parametrize("seed", range(40 * _SCALE))
+def test_tiny_top_levels_device_selection_equals_host_selection(gpu_vs, seed):
+    """Pyramids whose top level has fewer than 64 tiles per point set (a 20 x 13 image: 60 tiles), tie-heavy content (posterised frames: most
+    abs_delta values are equal): the on-device replica of std::nth_element must leave what the host's std::nth_element leaves, bit for bit.
+    (Regression: the register-level rounds' two 64-byte rank tables used to borrow the first 128 bytes of a posR array that holds 2 * n bytes;
+    with n < 64 the x-set's tables ran into the y-set's while both waves were at work -- found by this file's sweep on the bounds-checked build.)"""
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(99000 + seed)
+    w, h = int(rng.integers(150, 420)), int(rng.integers(100, 280))
+    lv_max = min(int(np.log2(w / 8)), int(np.log2(h / 6)))       # (a top level of at least 8 x 6: levels below 4 x 4 are refused)
+    lv = int(rng.integers(max(2, lv_max - 1), lv_max + 1))
+    mw, mh = max(4, (w >> lv) + 1), max(3, (h >> lv) + 1)          # the level after the lv-th is refused: lv + 1 levels
+    kw = dict(pyramid_min_width=mw, pyramid_min_height=mh, smallest_fraction=float(rng.choice([0.5, 0.8, 0.95])), max_iters=int(rng.choice([3, 24])),
+              phase_correlate=int(rng.integers(0, 2)))
+    frames, _ = synth.make_clip(w, h, 5, seed=8000 + seed, channels=1, jitter_t=float(rng.choice([1.0, 6.0])))
+    q = int(rng.choice([1, 32, 64]))
+    frames = (frames // q * q).astype(np.uint8)
+    host = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_STL_HOST, **kw)
+    dev = gpu_vs.Aligner(device=0, select_mode=gpu_vs.SELECT_DEVICE, **kw)
+    for i, f in enumerate(frames):
+        (ok_h, t_h), (ok_d, t_d) = host.align_next(f), dev.align_next(f)
+        ih, idv = host.info(0), dev.info(0)
+        assert ok_h == ok_d and ih.fail_reason == idv.fail_reason, (i, kw)
+        if max(abs(v) for v in t_h.tup() + t_d.tup()) > 2.0 ** 31:
+            continue                                            # (diverged beyond the integer range: see test_random_batch_forms_equal_frame_at_a_time)
+        assert list(ih.iterations[:ih.levels]) == list(idv.iterations[:ih.levels]), (i, kw)
+        for l in range(ih.levels):
+            assert (ih.selected_x[l], ih.selected_y[l]) == (idv.selected_x[l], idv.selected_y[l]), (i, l)
+            # the same survivors in the same order give the same Hessian sums: the condition number is the fingerprint of a level's selection
+            assert abs(ih.condition[l] - idv.condition[l]) <= 1e-9 * abs(ih.condition[l]) + (1e-15 * ih.condition[l]) * ih.condition[l], (i, l, kw, ih.condition[l], idv.condition[l])
+        assert _cmp_transform(t_h, t_d) < TOL, (i, kw, t_h.tup(), t_d.tup())
