@@ -70,3 +70,54 @@ def test_random_generic_warp_forms_are_bit_exact(gpu_vs, oracle, seed):
     assert np.array_equal(gpu_vs.image_warp(gray, gpu_vs.Transform.of(*tr)), oracle.image_warp(gray, oracle.Transform.of(*tr)), equal_nan=True), (w, h, tr)
     bgr = rng.integers(0, 256 if bits == 8 else 1024, (h, w, 3)).astype(src.dtype)
     assert np.array_equal(gpu_vs.bgr_to_gray(bgr), oracle.bgr_to_gray(bgr)), (w, h, bits)
+
+
+@pytest.mark.parametrize("seed", range(100 * _SCALE))
+def test_random_pitches_and_unaligned_device_pointers(gpu_vs, oracle, seed):
+    """the same warps through buffers as callers really hold them: rows longer than the image (pitches that leave every other row unaligned),
+    device pointers that do not start on a dword, frame strides with slack -- host and device memory.  The aligned 12-byte loads and
+    3-dword stores of the tuned kernel must give way to the byte paths exactly where they have to."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(45000 + seed)
+    w, h = int(rng.integers(1, 330)), int(rng.integers(1, 120))
+    bits = int(rng.choice([8, 8, 10]))
+    mode, border = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    n = int(rng.integers(1, 4))
+    max_value = 255 if bits == 8 else 1023
+    dt = np.uint8 if bits == 8 else np.uint16
+    esz = 1 if bits == 8 else 2
+    frames = rng.integers(0, max_value + 1, (n, h, w, 3)).astype(dt)
+    trs = [_transform(rng) for _ in range(n)]
+    exp = np.stack([oracle.bgr_image_warp(frames[i], oracle.Transform.of(*trs[i]), mode, border, max_value=max_value) for i in range(n)])
+    sp, dp = 3 * w + int(rng.integers(0, 8)), 3 * w + int(rng.integers(0, 8))          # row pitches in elements
+    sfs, dfs = h * sp + int(rng.integers(0, 5)), h * dp + int(rng.integers(0, 5))      # frame strides in elements
+    so, do = int(rng.integers(0, 4)), int(rng.integers(0, 4))                          # the first frame starts this many elements into its buffer
+    src = rng.integers(0, max_value + 1, so + n * sfs + 8).astype(dt)                  # (garbage everywhere the image is not)
+    for i in range(n):
+        rows = np.lib.stride_tricks.as_strided(src[so + i * sfs:], (h, 3 * w), (sp * esz, esz))
+        rows[...] = frames[i].reshape(h, 3 * w)
+    dst_fill = int(rng.integers(0, max_value + 1))
+    dst = np.full(do + n * dfs + 8, dst_fill, dt)
+    arr = (gpu_vs.Transform * n)(*[gpu_vs.Transform.of(*t) for t in trs])
+    L = gpu_vs.lib()
+    if rng.random() < 0.5:
+        r = L.vs_bgr_image_warp_batch(C.c_void_p(src.ctypes.data + so * esz), sfs, n, w, h, sp, 3, 8 * esz, arr, mode, border, max_value,
+                                      C.c_void_p(dst.ctypes.data + do * esz), dfs, dp, gpu_vs.MEM_HOST, None)
+        assert r >= 0, gpu_vs.lib().vs_last_error()
+        got = dst
+    else:
+        ds = torch.from_numpy(src.view(np.int16) if esz == 2 else src).to("cuda:0")
+        dd = torch.from_numpy(dst.view(np.int16) if esz == 2 else dst).to("cuda:0")
+        r = L.vs_bgr_image_warp_batch(C.c_void_p(ds.data_ptr() + so * esz), sfs, n, w, h, sp, 3, 8 * esz, arr, mode, border, max_value,
+                                      C.c_void_p(dd.data_ptr() + do * esz), dfs, dp, gpu_vs.MEM_DEVICE, None)
+        assert r >= 0, gpu_vs.lib().vs_last_error()
+        torch.cuda.synchronize()
+        got = dd.cpu().numpy()
+        got = got.view(np.uint16) if esz == 2 else got
+    keep = np.ones(got.shape, bool)
+    for i in range(n):
+        rows = np.lib.stride_tricks.as_strided(got[do + i * dfs:], (h, 3 * w), (dp * esz, esz))
+        assert np.array_equal(rows, exp[i].reshape(h, 3 * w)), (i, w, h, bits, mode, border, sp, dp, so, do, trs[i])
+        np.lib.stride_tricks.as_strided(keep[do + i * dfs:], (h, 3 * w), (dp, 1))[...] = False
+    assert np.all(got[keep] == dst_fill), "bytes outside the output rows were written"
