@@ -224,3 +224,44 @@ def test_tiny_top_levels_device_selection_equals_host_selection(gpu_vs, seed):
             # the same survivors in the same order give the same Hessian sums: the condition number is the fingerprint of a level's selection
             assert abs(ih.condition[l] - idv.condition[l]) <= 1e-9 * abs(ih.condition[l]) + (1e-15 * ih.condition[l]) * ih.condition[l], (i, l, kw, ih.condition[l], idv.condition[l])
         assert _cmp_transform(t_h, t_d) < TOL, (i, kw, t_h.tup(), t_d.tup())
+
+
+@pytest.mark.parametrize("seed", range(60 * _SCALE))
+def test_random_pitched_and_unaligned_frames_align_like_dense_ones(gpu_vs, seed):
+    """AlignNextFrame / the stabilizer on frames as callers hold them -- rows longer than the image (every other row unaligned), frame strides with
+    slack, device pointers that do not start on a dword, host or device memory: the ingest kernel's aligned 12-byte group loads must give way to
+    its byte path exactly where they have to.  Same statuses and transforms as the dense copy, bit for bit; same output frames."""
+    import ctypes as C
+    import torch
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(66000 + seed)
+    w, h = int(rng.integers(130, 400)), int(rng.integers(100, 260))
+    ch, bits = int(rng.choice([1, 3])), int(rng.choice([8, 8, 10]))
+    if ch == 1:
+        bits = 8
+    n = int(rng.integers(2, 7))
+    dt, esz = (np.uint8, 1) if bits == 8 else (np.uint16, 2)
+    frames, _ = synth.make_clip(w, h, n, seed=9000 + seed, channels=ch, bits=bits)
+    kw = dict(pyramid_min_width=int(rng.integers(16, w // 4)), pyramid_min_height=int(rng.integers(12, h // 4)))
+    fmt = gpu_vs.FMT_GRAY8 if ch == 1 else (gpu_vs.FMT_BGR8 if bits == 8 else gpu_vs.FMT_BGR10)
+    ref = gpu_vs.Aligner(device=0, **kw)
+    st_ref, ts_ref = ref.align_batch(frames, fmt=fmt)
+    sp = ch * w + int(rng.integers(0, 8))
+    sfs = h * sp + int(rng.integers(0, 5))
+    so = int(rng.integers(0, 4))
+    buf = rng.integers(0, 256, so + n * sfs + 8).astype(dt)
+    for i in range(n):
+        np.lib.stride_tricks.as_strided(buf[so + i * sfs:], (h, ch * w), (sp * esz, esz))[...] = frames[i].reshape(h, ch * w)
+    out = (gpu_vs.Transform * n)()
+    st = (C.c_int32 * n)()
+    al = gpu_vs.Aligner(device=0, **kw)
+    on_device = rng.random() < 0.5
+    if on_device:
+        dev = torch.from_numpy(buf.view(np.int16) if esz == 2 else buf).to("cuda:0")
+        base, mem = dev.data_ptr() + so * esz, gpu_vs.MEM_DEVICE
+    else:
+        base, mem = buf.ctypes.data + so * esz, gpu_vs.MEM_HOST
+    r = gpu_vs.lib().vs_aligner_align_batch(al.h, C.c_void_p(base), sfs, n, w, h, sp, fmt, mem, C.byref(al.params), out, st)
+    assert r >= 0, gpu_vs.lib().vs_last_error()
+    for i in range(n):
+        assert bool(st[i]) == bool(st_ref[i]) and out[i].tup() == ts_ref[i].tup(), (i, w, h, ch, bits, sp, sfs, so, on_device)
