@@ -230,6 +230,8 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
  * out-of-memory, and the call it belongs to returns VS_ERR_HIP; k = 0 disarms.  Returns the number of allocations made since the
  * previous call of this function.  The environment variable VS_TEST_FAIL_ALLOC=k arms it at load time for programs that cannot
  * call it.  tests/test_alloc_failure_gpu.py walks k over every allocation of the engine-level calls. */
+/* VS_TEST_POISON_ALLOC=<byte> in the environment (read once): every fresh device allocation starts filled with that byte, so that a result
+ * which depends on memory the library never wrote changes with the byte (tests/test_uninitialised_memory_gpu.py). */
 int vs_test_fail_alloc(int k);
 
 /* Debug build only (tools/build_variant.sh bounds: -DVS_DEBUG_BOUNDS; the reference's "bounds asserts in debug kernels").

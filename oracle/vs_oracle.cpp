@@ -51,6 +51,19 @@ inline float lanczos2(float x) {
     return std::fabs(x) >= 2.0f ? 0.0f : val;
 }
 
+/* floor(position) -> integer pixel index.  The reference writes cast<int>(floor(W)) (generators.cpp:147-152, 466-470, 679-683), which is undefined
+ * for positions outside the int range (a Gauss-Newton run that diverges gets there: |T| ~ 1e14) and so is the window arithmetic after it.  Defined
+ * here the way the product defines it: the conversion saturates and maps NaN to 0 (v_cvt_i32_f32), and an index used for ADDRESSING is then pulled
+ * into [-8, n + 8) -- 4 or more outside the image every tap of the window is the same border pixel (or outside, for the constant border) anyway.
+ * Identical to the plain cast for every position inside the int range. */
+inline int sat_int(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return -2147483647 - 1;
+    return (int)f;
+}
+inline int sample_index(float fl, int n) { return clampi(sat_int(fl), -8, n + 7); }
+
 /* Pixel fetch policies.  stride/channels in elements. */
 template <typename T>
 struct ImageRef {
@@ -79,7 +92,7 @@ inline float lanczos_sample(const ImageRef<T>& img, float Wx, float Wy, int c) {
         wx[u] = lanczos2((float)(u - 2) - fracWx);
         wy[u] = lanczos2((float)(u - 2) - fracWy);
     }
-    int ix = (int)floorWx, iy = (int)floorWy;
+    int ix = sample_index(floorWx, img.w), iy = sample_index(floorWy, img.h);
     float sum_num = 0.0f, sum_den = 0.0f;
     for (int ry = 0; ry < 5; ry++) {
         for (int rx = 0; rx < 5; rx++) {
@@ -125,7 +138,7 @@ inline float lanczos_sample_contracted(const ImageRef<T>& img, float Wx, float W
         wx[u] = lanczos2_contracted((float)(u - 2) - fracWx);
         wy[u] = lanczos2_contracted((float)(u - 2) - fracWy);
     }
-    int ix = (int)floorWx, iy = (int)floorWy;
+    int ix = sample_index(floorWx, img.w), iy = sample_index(floorWy, img.h);
     float sum_num = 0.0f, sum_den = 0.0f;
     for (int ry = 0; ry < 5; ry++) {
         for (int rx = 0; rx < 5; rx++) {
@@ -145,8 +158,9 @@ inline float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
 template <typename T, bool CONSTANT_BORDER>
 inline float bilinear_sample(const ImageRef<T>& img, float Wx, float Wy, int c) {
-    int fx = (int)std::floor(Wx), fy = (int)std::floor(Wy);
-    float wx = Wx - (float)fx, wy = Wy - (float)fy;
+    int fx = sat_int(std::floor(Wx)), fy = sat_int(std::floor(Wy));
+    float wx = Wx - (float)fx, wy = Wy - (float)fy;           /* (the fraction comes from the converted index: generators.cpp:150-153) */
+    fx = clampi(fx, -8, img.w + 7); fy = clampi(fy, -8, img.h + 7);
     float x0y0, x1y0, x0y1, x1y1;
     if (CONSTANT_BORDER) {
         x0y0 = img.constant0(fx, fy, c); x1y0 = img.constant0(fx + 1, fy, c);

@@ -16,7 +16,7 @@ def _cmp_transform(tg, tc):
 
 
 def _diverged(t):
-    return max(abs(v) for v in t.tup()) > 1e4
+    return not all(abs(v) <= 1e4 for v in t.tup())          # (NaN counts: a singular level's update)
 
 
 def _run_both(vs, oracle, frames, select_mode=0, **params):
@@ -61,6 +61,25 @@ def _check_seq(res):
                 # the reference's PerformanceMetrics custom metrics (alignment.cpp:489-490) and the estimate each level ended on
                 assert (inf.selected_x[l], inf.selected_y[l]) == (dbg.selected_x[l], dbg.selected_y[l]), (i, l)
                 assert _cmp_transform(inf.level_transform[l], dbg.level_transform[l]) < TOL, (i, l, inf.level_transform[l].tup(), dbg.level_transform[l].tup())
+
+
+def test_a_level_whose_update_goes_nan_is_refused_like_the_reference_refuses_it(gpu_vs, oracle):
+    """391 x 189 gray, three levels (pyramid_min 30 x 43), clip seed 9536: on frame 3 the finest level (cond 6e5) drives the update to NaN.  The
+    reference's displacement12 = std::max(std::max(ul, ur), std::max(ll, lr)) (alignment.cpp:647-649) is then NaN, `NaN < threshold` is false,
+    the level runs out of iterations and AlignNextFrame returns false (:657-667).  The device code used fmax(0, .), which ignores NaN: it
+    reported convergence after 43 iterations and handed back aligned = true with a NaN transform (found by the random sweeps, round 4)."""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(391, 189, 6, seed=9536, channels=1)
+    kw = dict(pyramid_min_width=30, pyramid_min_height=43)
+    for mode in (gpu_vs.SELECT_STL_HOST, gpu_vs.SELECT_DEVICE, gpu_vs.SELECT_STABLE):
+        gpu, cpu, res = _run_both(gpu_vs, oracle, frames, select_mode=mode, **kw)
+        _check_seq(res)
+        ok_g, t_g, inf, ok_c, t_c, dbg = res[3]
+        assert not ok_g and not ok_c and inf.fail_reason == dbg.fail_reason == 2
+        assert list(inf.iterations[:3]) == list(dbg.iterations[:3]) == [64, 4, 6]
+        assert all(np.isnan(t_g.tup())) and all(np.isnan(t_c.tup()))
+        for ok, t, *_ in res:
+            assert not ok or all(np.isfinite(t.tup()))       # no frame is ever reported aligned with a non-finite transform
 
 
 def test_c1_gray_pair_640x480(gpu_vs, oracle):

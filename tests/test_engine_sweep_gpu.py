@@ -264,4 +264,8 @@ def test_random_pitched_and_unaligned_frames_align_like_dense_ones(gpu_vs, seed)
     r = gpu_vs.lib().vs_aligner_align_batch(al.h, C.c_void_p(base), sfs, n, w, h, sp, fmt, mem, C.byref(al.params), out, st)
     assert r >= 0, gpu_vs.lib().vs_last_error()
     for i in range(n):
-        assert bool(st[i]) == bool(st_ref[i]) and out[i].tup() == ts_ref[i].tup(), (i, w, h, ch, bits, sp, sfs, so, on_device)
+        assert bool(st[i]) == bool(st_ref[i]), (i, w, h, ch, bits, sp, sfs, so, on_device)
+        if not st[i] and not all(abs(v) <= 2.0 ** 31 for v in out[i].tup() + ts_ref[i].tup()):
+            continue                                            # (refused after diverging beyond the integer range: see test_random_batch_forms_equal_frame_at_a_time)
+        assert np.array_equal(out[i].tup(), ts_ref[i].tup(), equal_nan=True), (i, w, h, ch, bits, sp, sfs, so, on_device)
+        assert not st[i] or all(np.isfinite(out[i].tup())), i          # (a refused frame's estimate may be NaN; an aligned frame's never)

@@ -1,0 +1,75 @@
+"""No result may depend on memory the library never wrote.  VS_TEST_POISON_ALLOC=<byte> (a test hook in vsi::dev_alloc) fills every fresh device
+allocation with that byte; the same battery of calls runs in one child process per byte and must produce the same digest -- statuses, transforms
+and output frames, bit for bit.  The battery includes the case that made this test necessary (round 4): a Gauss-Newton run that diverges to
+|T| ~ 1e14, whose sampling positions saturate the float -> int conversion; the window arithmetic after it overflowed (undefined behaviour) and the
+compiler's code read the row in FRONT of the image -- whatever the previous owner of the memory had left there."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from video_stabilizer_amd import capi as G, synth
+dig = hashlib.sha256()
+def put(*xs):
+    for x in xs:
+        dig.update(np.ascontiguousarray(x).tobytes() if isinstance(x, np.ndarray) else repr(x).encode())
+def tr(ts): return np.array([t.tup() for t in ts])
+# (1) the diverging clip: 344 x 173 gray, pyramid_min 52 x 15, frame 2 runs away on the 86 x 43 top level
+frames, _ = synth.make_clip(344, 173, 6, seed=9000 + 1776, channels=1)
+kw = dict(pyramid_min_width=52, pyramid_min_height=15)
+dev = torch.from_numpy(frames).to("cuda:0")
+st, ts = G.Aligner(device=0, **kw).align_batch_device(dev.data_ptr(), 6, 344, 173, G.FMT_GRAY8)
+put(st, tr(ts)); div = ts[2].tup()
+a = G.Aligner(device=0, **kw); r = [a.align_next(f) for f in frames]
+put([x[0] for x in r], tr([x[1] for x in r]))
+# (2) random configurations: tiny top levels, every selection mode, 8- and 10-bit, batches and frame at a time, the stabilizer with every warp
+rng = np.random.default_rng(4242)
+for k in range(10):
+    w, h = int(rng.integers(140, 380)), int(rng.integers(100, 260))
+    ch = int(rng.choice([1, 3])); bits = 8 if ch == 1 else int(rng.choice([8, 10]))
+    clip, _ = synth.make_clip(w, h, 7, seed=500 + k, channels=ch, bits=bits, jitter_t=float(rng.choice([1.0, 6.0])))
+    akw = dict(pyramid_min_width=int(rng.integers(9, w // 4)), pyramid_min_height=int(rng.integers(8, h // 4)),
+               smallest_fraction=float(rng.choice([0.5, 0.8, 1.0])), max_iters=int(rng.choice([3, 64])), phase_correlate=int(rng.integers(0, 2)))
+    mode = int(rng.integers(0, 3))
+    st, ts = G.Aligner(device=0, select_mode=mode, **akw).align_batch(clip)
+    put(st, tr(ts))
+    one = G.Aligner(device=0, select_mode=mode, **akw)
+    r = [one.align_next(f) for f in clip]
+    put([x[0] for x in r], tr([x[1] for x in r]))
+    if ch == 3:
+        s = G.Stabilizer(device=0, select_mode=mode, lag=2, crop_pixels=int(rng.integers(0, 9)), warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)),
+                         pyramid_min_width=akw["pyramid_min_width"], pyramid_min_height=akw["pyramid_min_height"])
+        out, has = s.process_batch(clip)
+        put(has, out[np.array(has, bool)])
+    src = rng.integers(0, 256, (int(rng.integers(1, 90)), int(rng.integers(1, 200)), 3), dtype=np.uint8)
+    for m in range(3):
+        put(G.bgr_image_warp(src, G.Transform.of(0.01, -0.02, float(rng.choice([2.5, 1e9, -3e12])), 1.5), m, int(rng.integers(0, 2))))
+print("DIGEST", dig.hexdigest(), "%%.6g" %% div[2])
+"""
+
+
+def _run(byte):
+    env = dict(os.environ)
+    env.pop("VS_TEST_POISON_ALLOC", None)
+    if byte is not None:
+        env["VS_TEST_POISON_ALLOC"] = str(byte)
+    out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+    return line[1], float(line[2])
+
+
+def test_results_do_not_depend_on_what_fresh_allocations_contain(gpu_vs):
+    runs = {b: _run(b) for b in (0, 255, 0x7f)}
+    assert abs(runs[0][1]) > 1e6                                # the battery does contain a run that diverged
+    assert runs[0] == runs[255] == runs[0x7f], runs

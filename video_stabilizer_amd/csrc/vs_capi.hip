@@ -41,8 +41,25 @@ static bool alloc_injected_failure() {
 hipError_t dev_alloc(void** p, size_t bytes) {
     *p = nullptr;
     if (alloc_injected_failure()) return hipErrorOutOfMemory;
-    const hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); }      // (the sticky error belongs to this call, which reports it)
+    // test hook (VS_TEST_POISON_ALLOC=<byte>): every fresh device allocation starts filled with that byte, so that a result which depends on
+    // memory the library never wrote changes with the byte (tests/test_uninitialised_memory_gpu.py)
+    static const int poison = []() { const char* v = getenv("VS_TEST_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
+    static const int only = []() { const char* v = getenv("VS_TEST_POISON_ONLY"); return v ? atoi(v) : 0; }();      // (0: every allocation; k: the k-th only)
+    static std::atomic<int> nth{0};
+    const int k = ++nth;
+    if (e == hipSuccess && poison >= 0 && bytes) {
+        static const long long r_off = []() { const char* v = getenv("VS_TEST_POISON_OFF"); return v ? atoll(v) : 0LL; }();
+        static const long long r_len = []() { const char* v = getenv("VS_TEST_POISON_LEN"); return v ? atoll(v) : -1LL; }();
+        if (only == k && r_len >= 0) {                     // (debugging aid: only bytes [off, off + len) of the k-th allocation get the byte)
+            e = hipMemset(*p, 0, bytes);
+            if (e == hipSuccess && r_off < (long long)bytes) e = hipMemset((char*)*p + r_off, poison, (size_t)std::min<long long>(r_len, (long long)bytes - r_off));
+        } else
+        e = hipMemset(*p, (only == 0 || only == k) ? poison : 0, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (only == k) std::fprintf(stderr, "[poison] allocation %d: %zu bytes\n", k, bytes);
+    }
     return e;
 }
 hipError_t pinned_alloc(void** p, size_t bytes) {

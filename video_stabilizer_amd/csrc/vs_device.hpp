@@ -65,6 +65,12 @@ namespace vsd {
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// floor(position) -> integer pixel index for clamp-to-edge (or constant-border) sampling of an image n pixels wide / high.  v_cvt_i32_f32
+// saturates (NaN -> 0), but the window arithmetic that follows (ix - 1, ix + 2, ...) would then overflow: undefined behaviour, which the compiler
+// had turned into a row index of -1 -- a diverged Gauss-Newton run (|T| ~ 1e14) read the 344 bytes in FRONT of its image (found by the random
+// sweeps + allocation poisoning, round 4).  An index 4 or more outside the image puts every tap of a 4- or 5-tap window on the same border
+// pixel (or outside, for the constant border), so the index is pulled into [-8, n + 8) first: the same taps for every position, no overflow.
+__device__ __forceinline__ int sample_index(float fl, int n) { return clampi((int)fl, -8, n + 7); }
 
 // generators.cpp:31-47: 6th-order even polynomial, Horner in x*x, zero outside |x| < 2.
 __device__ __forceinline__ float lanczos2(float x) {
@@ -144,7 +150,7 @@ __device__ __forceinline__ float lanczos_sample_u8(const uint8_t* __restrict__ i
     float wx[4], wy[4];
     lanczos_weights4(frx, wx);
     lanczos_weights4(fry, wy);
-    int ix = (int)flx, iy = (int)fly;
+    int ix = sample_index(flx, w), iy = sample_index(fly, h);
     int xs[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) xs[r] = clampi(ix + r - 1, 0, w - 1);
@@ -223,13 +229,16 @@ template <typename P>
 __device__ __forceinline__ LanczosFetch lanczos_fetch(P img, int w, int h, int stride, float Wx, float Wy) {
     LanczosFetch f;
     const float flx = floorf(Wx), fly = floorf(Wy);
-    const int ix = (int)flx, iy = (int)fly;
+    const int ix = sample_index(flx, w), iy = sample_index(fly, h);
     f.frx = Wx - flx; f.fry = Wy - fly; f.ix = ix;
     const int xb = clampi(ix - 1, 0, w - 4);                  // window origin, always inside the row
 #pragma unroll
-    for (int ry = 0; ry < 4; ry++)
-        f.r[ry] = load_u32_unaligned(img + (__mul24(clampi(iy + ry - 1, 0, h - 1), stride) + xb));   // (a level image is far below 2^31 bytes,
-                                                                                                        // rows and stride below 2^24: no 64-bit multiply)
+    for (int ry = 0; ry < 4; ry++) {
+        const int row = clampi(iy + ry - 1, 0, h - 1);
+        const int off = __mul24(row, stride) + xb;     // (a level image is far below 2^31 bytes, rows and stride below 2^24: no 64-bit multiply)
+        VS_BOUNDS_CHECK(off + 3, h * stride, 130);
+        f.r[ry] = load_u32_unaligned(img + off);
+    }
     return f;
 }
 // the scalar form of lanczos2_pk (same operations per value)
@@ -612,16 +621,20 @@ __device__ __forceinline__ void warp_corners(const double t[4], int w, int h, do
     warp_center(t, 0.0, y1, cx, cy, c[4], c[5]);
     warp_center(t, x1, y1, cx, cy, c[6], c[7]);
 }
-// max over the four corners of Point::distance (alignment.cpp:647-649).  sqrt is correctly rounded, hence monotone:
-// max_k sqrt(d_k) == sqrt(max_k d_k) bit for bit, so one square root instead of four.
+// max over the four corners of Point::distance, nested as the reference nests it (alignment.cpp:647-649 / 670-672): std::max(std::max(ul, ur),
+// std::max(ll, lr)) with std::max(x, y) = (x < y) ? y : x -- NOT fmax: when the update has gone NaN (a singular level: Hinv and then T are NaN)
+// every distance is NaN, the reference's displacement is NaN, `NaN < threshold` is false and the level runs out of iterations and is REFUSED.
+// fmax(0, NaN) = 0 called that "converged" and the frame came back aligned with a NaN transform (found by the random sweeps, round 4).
+// sqrt is correctly rounded, hence monotone: max_k sqrt(d_k) == sqrt(max_k d_k) bit for bit, so one square root instead of four.
 __device__ __forceinline__ double corner_move(const double a[8], const double b[8]) {
-    double m = 0.0;
+    double d[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        double dx = a[2 * k] - b[2 * k], dy = a[2 * k + 1] - b[2 * k + 1];
-        m = fmax(m, dx * dx + dy * dy);
+        const double dx = a[2 * k] - b[2 * k], dy = a[2 * k + 1] - b[2 * k + 1];
+        d[k] = dx * dx + dy * dy;
     }
-    return sqrt(m);
+    const double u = d[0] < d[1] ? d[1] : d[0], l = d[2] < d[3] ? d[3] : d[2];
+    return sqrt(u < l ? l : u);
 }
 
 }  // namespace vsd

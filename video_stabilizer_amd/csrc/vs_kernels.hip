@@ -852,7 +852,8 @@ __global__ __launch_bounds__(256) void vs_k_image_warp(const uint8_t* __restrict
     float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
     float Wy = B * (float)x + (1.0f + A) * (float)y + TY;
     int fx = (int)floorf(Wx), fy = (int)floorf(Wy);
-    float wx = Wx - (float)fx, wy = Wy - (float)fy;
+    float wx = Wx - (float)fx, wy = Wy - (float)fy;           // generators.cpp:150-153: the fraction comes from the converted index
+    fx = clampi(fx, -8, w + 7); fy = clampi(fy, -8, h + 7);   // (sample_index: the taps below cannot overflow)
     int x0 = clampi(fx, 0, w - 1), x1 = clampi(fx + 1, 0, w - 1);
     const uint8_t* r0 = in + (size_t)clampi(fy, 0, h - 1) * stride;
     const uint8_t* r1 = in + (size_t)clampi(fy + 1, 0, h - 1) * stride;
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
     float Wx = (1.0f + A) * fx - B * fy + TX;
     float Wy = B * fx + (1.0f + A) * fy + TY;
     float flx = floorf(Wx), fly = floorf(Wy);
-    int ix = (int)flx, iy = (int)fly;
+    int ix = sample_index(flx, w), iy = sample_index(fly, h);
     float frx = Wx - flx, fry = Wy - fly;
     float wx[4], wy[4];
     if (MODE == 0) { lanczos_weights4(frx, wx); lanczos_weights4(fry, wy); }

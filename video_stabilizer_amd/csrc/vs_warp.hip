@@ -442,7 +442,7 @@ template <typename T, int MODE, int BORDER>
 __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int w, int h, int stride, float Wx,
                                                   float Wy, float maxv, uint32_t out[3]) {
     float flx = floorf(Wx), fly = floorf(Wy);
-    int ix = (int)flx, iy = (int)fly;
+    int ix = sample_index(flx, w), iy = sample_index(fly, h);
     float frx = Wx - flx, fry = Wy - fly;
     auto fetch = [&](int sx, int sy, int c) -> float {
         if (BORDER == 1) return (sx < 0 || sy < 0 || sx >= w || sy >= h) ? 0.0f : (float)src[(size_t)sy * stride + (size_t)sx * 3 + c];
