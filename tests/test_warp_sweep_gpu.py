@@ -121,3 +121,32 @@ def test_random_pitches_and_unaligned_device_pointers(gpu_vs, oracle, seed):
         assert np.array_equal(rows, exp[i].reshape(h, 3 * w)), (i, w, h, bits, mode, border, sp, dp, so, do, trs[i])
         np.lib.stride_tricks.as_strided(keep[do + i * dfs:], (h, 3 * w), (dp, 1))[...] = False
     assert np.all(got[keep] == dst_fill), "bytes outside the output rows were written"
+
+
+@pytest.mark.parametrize("seed", range(30 * _SCALE))
+def test_non_finite_transforms_stay_inside_their_buffers(gpu_vs, seed):
+    """A transform with NaN / infinite components has no meaningful result (the reference's cast<int>(floor(W)) is undefined there) -- but the call must
+    return, must not touch a byte outside its output rows, and (on the bounds-checked build, where this file also runs) must not index outside its
+    tile.  Every kernel form: the tuned 3-channel kernel in its three modes and depths, the generic kernel, float output, image_warp."""
+    import ctypes as C
+    rng = np.random.default_rng(47000 + seed)
+    w, h = int(rng.integers(1, 200)), int(rng.integers(1, 90))
+    bad = [float("nan"), float("inf"), float("-inf"), 3.0e38, -3.0e38, 1e20]
+    tr = [float(rng.choice(bad)) if rng.random() < 0.6 else float(rng.uniform(-1, 1)) for _ in range(4)]
+    if all(np.isfinite(v) and abs(v) < 1e10 for v in tr):
+        tr[int(rng.integers(0, 4))] = float("nan")
+    t = gpu_vs.Transform.of(*tr)
+    for bits in (8, 16):
+        dt = np.uint8 if bits == 8 else np.uint16
+        for c in (1, 3):
+            src = rng.integers(0, 256, (h, w, c)).astype(dt)
+            for mode in range(3):
+                for border in (0, 1):
+                    pad = 5
+                    dst = np.full((h, w * c + pad), 77, dt)
+                    r = gpu_vs.lib().vs_bgr_image_warp(C.c_void_p(src.ctypes.data), w, h, w * c, c, bits, C.byref(t), mode, border, 255 if bits == 8 else 1023,
+                                                       C.c_void_p(dst.ctypes.data), w * c + pad, gpu_vs.MEM_HOST, None)
+                    assert r >= 0, gpu_vs.lib().vs_last_error()
+                    assert np.all(dst[:, w * c:] == 77), (w, h, c, bits, mode, border, tr)
+            gpu_vs.bgr_image_warp(src, t, 0, 0, f32=True)
+    gpu_vs.image_warp(rng.integers(0, 256, (h, w), dtype=np.uint8), t)
