@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from test_engine_gpu import TOL, _check_seq, _cmp_transform, _run_both
+from test_engine_gpu import TOL, _check_seq, _cmp_transform, _diverged, _run_both
 
 pytestmark = pytest.mark.gpu
 _SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
@@ -300,3 +300,47 @@ def test_extreme_parameters_and_degenerate_frames_match_the_oracle(gpu_vs, oracl
     _check_seq(res)
     for ok_g, t_g, *_ in res:
         assert not ok_g or all(np.isfinite(t_g.tup())), kw           # no frame is ever reported aligned with a non-finite transform
+
+
+@pytest.mark.parametrize("seed", range(36 * _SCALE))
+def test_stabilizer_on_degenerate_sequences_and_deep_formats_matches_the_oracle(gpu_vs, oracle, seed):
+    """processFrame (stabilizer.cpp:9-117) where its failure branches live: clips with flat, noisy, inverted and repeated frames (alignment refused ->
+    the accumulated transform is reset, stabilizer.cpp:25-33), saturated 10- / 12- / 16-bit content, extreme aspect ratios.  Same has-output pattern,
+    same measurement / accumulated transforms, frames within 1 LSB."""
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(135000 + seed)
+    shape = int(rng.integers(0, 3))
+    w, h = [(int(rng.integers(160, 420)), int(rng.integers(120, 300))), (int(rng.integers(700, 1400)), int(rng.integers(48, 80))),
+            (int(rng.integers(64, 100)), int(rng.integers(400, 700)))][shape]
+    bits = int(rng.choice([8, 10, 12, 16]))
+    fmt = {8: gpu_vs.FMT_BGR8, 10: gpu_vs.FMT_BGR10, 12: gpu_vs.FMT_BGR12, 16: gpu_vs.FMT_BGR16_FULL}[bits]
+    ofmt = {8: oracle.FMT_BGR8, 10: oracle.FMT_BGR10, 12: oracle.FMT_BGR12, 16: oracle.FMT_BGR16_FULL}[bits]
+    n = 12
+    clip, _ = synth.make_clip(w, h, n, seed=52000 + seed, channels=3, bits=min(bits, 10), jitter_t=float(rng.choice([1.0, 5.0])))
+    if bits > 10:
+        clip = (clip.astype(np.uint32) << (bits - 10)).clip(0, (1 << bits) - 1).astype(np.uint16)
+    hi = (1 << bits) - 1
+    for i in rng.choice(n, size=int(rng.integers(1, 5)), replace=False):
+        kind = int(rng.integers(0, 5))
+        if kind == 0: clip[i] = int(rng.integers(0, hi + 1))
+        elif kind == 1: clip[i] = rng.integers(0, hi + 1, clip[i].shape).astype(clip.dtype)
+        elif kind == 2: clip[i] = hi - clip[i]
+        elif kind == 3 and i > 0: clip[i] = clip[i - 1]
+        else: clip[i] = hi                                                  # saturated
+    m = min(w, h)
+    kw = dict(lag=int(rng.integers(1, 5)), smoother_memory=int(rng.integers(0, 4)), crop_pixels=int(rng.integers(0, max(1, m // 6))),
+              warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)),
+              pyramid_min_width=max(8, w // int(rng.choice([4, 8, 16]))), pyramid_min_height=max(8, h // int(rng.choice([4, 8, 16]))))
+    g, c = gpu_vs.Stabilizer(device=0, **kw), oracle.Stabilizer(**kw)
+    for i, f in enumerate(clip):
+        og, oc = g.process(f, fmt=fmt), c.process(f, fmt=ofmt)
+        assert (og is None) == (oc is None), (i, kw)
+        mg, ag, sg = g.state()
+        mc, ac, sc = c.state()
+        assert sg == sc, (i, kw)
+        if _diverged(mc) or _diverged(mg):
+            continue                                                        # (a refused frame's diverged estimate: see test_engine_gpu._check_seq)
+        assert _cmp_transform(mg, mc) < TOL and _cmp_transform(ag, ac) < 10 * TOL, (i, kw, mg.tup(), mc.tup(), ag.tup(), ac.tup())
+        if oc is not None:
+            d = np.abs(og.astype(np.int64) - oc.astype(np.int64))
+            assert og.shape == oc.shape and d.max() <= 1 and (d != 0).mean() < 1e-2, (i, kw, int(d.max()), float((d != 0).mean()))
