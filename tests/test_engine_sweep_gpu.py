@@ -344,3 +344,45 @@ def test_stabilizer_on_degenerate_sequences_and_deep_formats_matches_the_oracle(
         if oc is not None:
             d = np.abs(og.astype(np.int64) - oc.astype(np.int64))
             assert og.shape == oc.shape and d.max() <= 1 and (d != 0).mean() < 1e-2, (i, kw, int(d.max()), float((d != 0).mean()))
+
+
+@pytest.mark.parametrize("seed", range(30 * _SCALE))
+def test_one_long_lived_handle_through_random_call_sequences(gpu_vs, seed):
+    """One aligner and one stabilizer handle driven through a random sequence of calls -- frame at a time, batches of changing length (so the per-chunk
+    storage regrows: allocate all -> copy the carry-over frame -> swap), frame sizes and formats that change (the reference restarts its sequence,
+    alignment.cpp:357-367), explicit resets -- must answer every call the way a FRESH handle fed the same frames since the last restart does."""
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(147000 + seed)
+    kw = dict(pyramid_min_width=24, pyramid_min_height=18)
+    skw = dict(lag=int(rng.integers(1, 4)), crop_pixels=int(rng.integers(0, 8)), warp_mode=int(rng.integers(0, 3)), **kw)
+    mode = int(rng.integers(0, 3))
+    A, S = gpu_vs.Aligner(device=0, select_mode=mode, **kw), gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
+    fa = fs = None                                   # the fresh shadows, rebuilt at every restart
+    size = None
+    pos = 0
+    for op in range(14):
+        r = rng.random()
+        if size is None or r < 0.2:                  # a new size / depth: both handles restart by themselves
+            w, h, bits = int(rng.integers(100, 300)), int(rng.integers(80, 200)), int(rng.choice([8, 8, 10]))
+            size = (w, h, bits)
+            clip, _ = synth.make_clip(w, h, 40, seed=77000 + 20 * seed + op, channels=3, bits=bits, jitter_t=2.0)
+            pos = 0
+            fa, fs = gpu_vs.Aligner(device=0, select_mode=mode, **kw), gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
+        elif r < 0.3:
+            A.reset(); S.reset()
+            fa, fs = gpu_vs.Aligner(device=0, select_mode=mode, **kw), gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
+        k = int(rng.choice([1, 1, 2, 5, 11]))
+        if pos + k > len(clip):
+            pos = 0                                  # (the clip wraps: just more frames)
+        fr = clip[pos:pos + k]
+        pos += k
+        if k == 1 and rng.random() < 0.6:
+            got, want = A.align_next(fr[0]), fa.align_next(fr[0])
+            assert got[0] == want[0] and np.array_equal(got[1].tup(), want[1].tup(), equal_nan=True), (op, size)
+            og, ow = S.process(fr[0]), fs.process(fr[0])
+            assert (og is None) == (ow is None) and (og is None or np.array_equal(og, ow)), (op, size)
+        else:
+            (st, ts), (st2, ts2) = A.align_batch(fr), fa.align_batch(fr)
+            assert st == st2 and all(np.array_equal(a.tup(), b.tup(), equal_nan=True) for a, b in zip(ts, ts2)), (op, size, k)
+            (o, hs), (o2, hs2) = S.process_batch(fr), fs.process_batch(fr)
+            assert hs == hs2 and np.array_equal(o[np.array(hs, bool)], o2[np.array(hs2, bool)]), (op, size, k)
