@@ -54,7 +54,22 @@ static int roundtrip(const std::string& path, vsio::Chroma chroma, int bits, int
     return 0;
 }
 
+// io_test --probe <clip>: open the clip and read it to the end like vs_video_test does; prints what happened.  Exit code 0 = read to the end,
+// 2 = refused with an error message; anything else (a signal) is a bug -- tests/test_apps_cpu.py feeds it damaged files.
+static int probe(const std::string& path) {
+    vsio::Reader r;
+    if (!r.open(path)) { std::printf("refused: %s\n", r.error.c_str()); return 2; }
+    if ((size_t)r.fmt.w * r.fmt.h > (size_t)4096 * 4096) { std::printf("header ok: %dx%d %d bit (too large to read here)\n", r.fmt.w, r.fmt.h, r.fmt.bits); return 0; }
+    std::vector<uint16_t> frame(r.fmt.bgr_elems());
+    int n = 0;
+    while (r.next(frame.data())) n++;
+    if (!r.error.empty()) { std::printf("refused after %d frames: %s\n", n, r.error.c_str()); return 2; }
+    std::printf("read %d frames of %dx%d %d bit\n", n, r.fmt.w, r.fmt.h, r.fmt.bits);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2 && std::string(argv[1]) == "--probe") return probe(argv[2]);
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
 
     // colour conversion: grey axis, primaries inside range, exact neutral chroma

@@ -39,6 +39,7 @@ inline void bgr_to_ycbcr(int b, int g, int r, int bits, int& y, int& cb, int& cr
 }
 
 enum class Chroma { Mono, C420, C422, C444 };
+constexpr int kMaxSide = 32768;       // (the engine's tile coordinates are 16-bit; also keeps w * h * 3 * 2 far inside size_t and the (w + 1) / 2 of the chroma planes inside int)
 
 struct Format {
     int w = 0, h = 0;
@@ -62,7 +63,7 @@ inline bool size_from_name(const std::string& path, int& w, int& h) {
     const size_t us = path.rfind('_', dot);
     if (us == std::string::npos) return false;
     int a = 0, b = 0;
-    if (std::sscanf(path.c_str() + us + 1, "%dx%d", &a, &b) != 2 || a <= 0 || b <= 0) return false;
+    if (std::sscanf(path.c_str() + us + 1, "%dx%d", &a, &b) != 2 || a <= 0 || b <= 0 || a > kMaxSide || b > kMaxSide) return false;
     w = a; h = b;
     return true;
 }
@@ -104,7 +105,10 @@ public:
             return true;
         }
         char line[256];
-        if (!read_line(line, sizeof line)) return false;
+        if (!read_line(line, sizeof line)) {            // end of file -- clean only if nothing at all was left
+            if (line[0] != 0) error = "trailing bytes without a FRAME marker";
+            return false;
+        }
         if (std::strncmp(line, "FRAME", 5) != 0) { error = "missing FRAME marker"; return false; }
         const size_t bytes = fmt.frame_samples() * fmt.sample_bytes();
         buf_.resize(bytes);
@@ -118,11 +122,15 @@ private:
     bool read_line(char* line, size_t cap) {
         size_t n = 0;
         int c;
+        bool any = false;
         while ((c = std::fgetc(f_)) != EOF) {
             if (c == '\n') { line[n] = 0; return true; }
+            any = true;
             if (n + 1 < cap) line[n++] = (char)c;
         }
         line[n] = 0;
+        if (any && n == 0) { line[0] = '?'; line[1] = 0; }       // (bytes were there, even if they were NULs: the caller tells a clean end from a damaged one by line[0])
+        else if (any && line[0] == 0) line[0] = '?';
         return false;
     }
     bool parse_y4m_header() {
@@ -157,6 +165,7 @@ private:
             }
         }
         if (fmt.w <= 0 || fmt.h <= 0) { error = "y4m header without W/H"; return false; }
+        if (fmt.w > kMaxSide || fmt.h > kMaxSide) { error = "y4m frame size beyond " + std::to_string(kMaxSide) + " pixels a side"; return false; }
         if (fmt.bits < 8 || fmt.bits > 16) { error = "unsupported y4m sample depth"; return false; }
         return true;
     }
