@@ -375,3 +375,40 @@ def test_bgr_image_warp_window_equals_cropped_full_warp(gpu_vs, dtype, c, mode, 
         with pytest.raises(gpu_vs.VsError):
             gpu_vs.bgr_image_warp_roi_batch(src, ts, bad)
 
+
+
+def test_absurd_extents_and_inconsistent_arguments_are_refused_before_any_work(gpu_vs):
+    """every call below would read or write far outside its (tiny) buffers if it were launched: extents whose products overflow int (w = 2^30 with 4
+    channels: w * channels == 0), negative or zero sizes, strides shorter than a row, windows outside the frame, unknown modes / depths, null pointers.
+    Each must come back VS_ERR_ARG (-1) from the host-side checks."""
+    import ctypes as C
+    L = gpu_vs.lib()
+    buf = np.zeros(4096, np.uint8)
+    p = C.c_void_p(buf.ctypes.data)
+    t = gpu_vs.Transform.of()
+    big = 1 << 30
+    warp = lambda w, h, ss, c, bits, mode, border, ds, src=p, dst=p: L.vs_bgr_image_warp(src, w, h, ss, c, bits, C.byref(t), mode, border, 255, dst, ds, gpu_vs.MEM_HOST, None)
+    bad = [
+        warp(big, 4, 0, 4, 8, 0, 0, 0), warp(big, big, big, 1, 8, 0, 0, big), warp(70000, 2, 70000, 1, 8, 0, 0, 70000),
+        warp(0, 4, 12, 3, 8, 0, 0, 12), warp(4, -1, 12, 3, 8, 0, 0, 12), warp(4, 4, 11, 3, 8, 0, 0, 12), warp(4, 4, 12, 3, 8, 0, 0, 11),
+        warp(4, 4, 12, 3, 12, 0, 0, 12), warp(4, 4, 12, 3, 8, 3, 0, 12), warp(4, 4, 12, 3, 8, 0, 2, 12), warp(4, 4, 20, 5, 8, 0, 0, 20),
+        warp(4, 4, 12, 3, 8, 0, 0, 12, src=None), warp(4, 4, 12, 3, 8, 0, 0, 12, dst=None),
+        L.vs_bgr_image_warp_roi_batch(p, 48, 1, 4, 4, 12, 3, 8, C.byref(t), 0, 0, 255, 2, 2, 3, 3, p, 27, 9, gpu_vs.MEM_HOST, None),      # window leaves the frame
+        L.vs_bgr_image_warp_roi_batch(p, 48, 1, 4, 4, 12, 3, 8, C.byref(t), 0, 0, 255, 0x7fffffff, 0, 2, 2, p, 12, 6, gpu_vs.MEM_HOST, None),
+        L.vs_bgr_image_warp_batch(p, 10, 2, 4, 4, 12, 3, 8, C.byref(t), 0, 0, 255, p, 48, 12, gpu_vs.MEM_HOST, None),                        # frames overlap
+        L.vs_pyr_down(p, big, big, big, p, big // 2, big // 2, big // 2, gpu_vs.MEM_HOST, None),
+        L.vs_pyr_down(p, 8, 8, 4, p, 4, 4, 4, gpu_vs.MEM_HOST, None),
+        L.vs_bgr_to_gray(p, big, 2, 3 * 4, 8, 0, p, 4, gpu_vs.MEM_HOST, None),
+    ]
+    assert bad == [-1] * len(bad), bad
+    al = gpu_vs.Aligner(device=0)
+    out, st = gpu_vs.Transform(), C.c_int32()
+    batch = lambda n, w, h, stride, fmt, fs=0: L.vs_aligner_align_batch(al.h, p, fs, n, w, h, stride, fmt, gpu_vs.MEM_HOST, C.byref(al.params), C.byref(out), C.byref(st))
+    bad = [batch(1, big, big, 0, gpu_vs.FMT_BGR8), batch(1, 70000, 16, 70000, gpu_vs.FMT_GRAY8), batch(1, 7, 64, 7, gpu_vs.FMT_GRAY8), batch(0, 64, 64, 64, gpu_vs.FMT_GRAY8),
+           batch(1, 64, 64, 63, gpu_vs.FMT_GRAY8), batch(1, 64, 64, 64, 99), batch(2, 64, 64, 64, gpu_vs.FMT_GRAY8, fs=100)]
+    assert bad == [-1] * len(bad), bad
+    s = gpu_vs.Stabilizer(device=0)
+    has, ow, oh = C.c_int32(), C.c_int(), C.c_int()
+    proc = lambda n, w, h, stride, fmt: L.vs_stabilizer_process_batch(s.h, p, h * stride, n, w, h, stride, fmt, gpu_vs.MEM_HOST, p, 0, C.byref(has), C.byref(ow), C.byref(oh))
+    bad = [proc(1, big, big, 0, gpu_vs.FMT_BGR8), proc(1, 70000, 70000, 3 * 70000, gpu_vs.FMT_BGR8), proc(1, 64, 64, 64, gpu_vs.FMT_GRAY8), proc(1, 64, 64, 100, gpu_vs.FMT_BGR8)]
+    assert bad == [-1] * len(bad), bad

@@ -110,6 +110,9 @@ using vsi::set_error;
 
 #define VS_TRY(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
 #define VS_ARG(cond) do { if (!(cond)) return set_error(VS_ERR_ARG, "bad argument: %s (%s)", #cond, __func__); } while (0)
+// every image extent an entry point takes: positive and at most 65535 a side (tile coordinates are 16-bit, row offsets are 24-bit multiplies, and
+// the products w * channels / roi.x + roi.w of the checks that follow stay inside int)
+#define VS_DIMS(w, h) VS_ARG((w) > 0 && (h) > 0 && (w) <= 65535 && (h) <= 65535)
 #define VS_TRY_RING(expr) do { int _r = (expr); if (_r != VS_OK) return _r; } while (0)
 
 
@@ -334,6 +337,7 @@ int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stre
 
 int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride, int mem,
                 void* stream) {
+    VS_DIMS(w, h); VS_DIMS(ow, oh);
     VS_ARG(in && out && w > 0 && h > 0 && ow > 0 && oh > 0 && in_stride >= w && out_stride >= ow);
     VS_ARG(2 * ow <= w + 1 && 2 * oh <= h + 1);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -350,6 +354,7 @@ int vs_optimal_dft_size(int n) { return vsp::optimal_dft_size(n); }
 
 int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int stride, int mem, void* stream, float* surface,
                        double* result) {
+    VS_DIMS(w, h);
     VS_ARG(a && b && result && w > 0 && h > 0 && stride >= w);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -382,6 +387,7 @@ int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int str
 }
 
 int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(in && gx && gy && w > 0 && h > 0 && stride >= w);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -397,6 +403,7 @@ int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy
 
 int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy, int mem,
                    void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(gx && gy && lmx && lmy && w > 0 && h > 0 && ts >= 1 && ts <= 64);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -414,6 +421,7 @@ int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint1
 
 int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy, int tx, int ty,
                   float* out_x, float* out_y, int mem, void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(gx && gy && lmx && lmy && out_x && out_y && w > 0 && h > 0 && tx > 0 && ty > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -453,6 +461,7 @@ int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint1
 
 int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm, int tx,
                        int ty, float A, float B, float TX, float TY, uint16_t* out, int mem, void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(tmpl && key && lm && out && w > 0 && h > 0 && stride >= w && tx > 0 && ty > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -471,6 +480,7 @@ int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, in
 int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
                   const uint16_t* sely, int ny, const float* jacx, const float* jacy, float A, float B, float TX, float TY,
                   double* out4, int mem, void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(tmpl && key && out4 && w > 0 && h > 0 && stride >= w && nx >= 0 && ny >= 0);
     VS_ARG((nx == 0 || (selx && jacx)) && (ny == 0 || (sely && jacy)));
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -491,6 +501,7 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
 
 int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out, int ow,
                   int oh, int mem, void* stream) {
+    VS_DIMS(w, h); VS_DIMS(ow, oh);
     VS_ARG(in && out && w > 0 && h > 0 && stride >= w && ow > 0 && oh > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -506,10 +517,11 @@ int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B,
 static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
                            int bits, const vs_transform* t, int mode, int border, int max_value, void* dst,
                            size_t dst_fs, int dst_stride, bool f32out, int mem, hipStream_t s, const vsk::Roi* roi_in = nullptr) {
+    VS_DIMS(w, h);
     VS_ARG(src && dst && t && n_frames >= 1 && w > 0 && h > 0 && channels >= 1 && channels <= 4);
     VS_ARG(bits == 8 || bits == 16);
     const vsk::Roi roi = roi_in ? *roi_in : vsk::Roi{0, 0, w, h};
-    VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.x + roi.w <= w && roi.y + roi.h <= h);
+    VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.w <= w && roi.h <= h && roi.x <= w - roi.w && roi.y <= h - roi.h);   // (no sum that could overflow)
     VS_ARG(src_stride >= w * channels && dst_stride >= roi.w * channels);
     VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST);
     VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
@@ -575,6 +587,7 @@ int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int cha
 
 int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst, int dst_stride,
                    int mem, void* stream) {
+    VS_DIMS(w, h);
     VS_ARG(src && dst && w > 0 && h > 0 && src_stride >= 3 * w && dst_stride >= w && (bits == 8 || bits == 16));
     VS_ARG(shift_to_8 >= 0 && shift_to_8 <= 8);
     if (!vsi::device_ready()) return VS_ERR_HIP;

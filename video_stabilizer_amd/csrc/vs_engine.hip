@@ -1235,6 +1235,7 @@ int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_strid
 static int align_start_impl(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride, int format, int mem,
                             const vs_aligner_params* params, vs_transform* out, int32_t* status, bool async) {
     VS_ARG(a && frames && out && status && n >= 1 && w >= 8 && h >= 8);
+    VS_ARG(w <= 65535 && h <= 65535);                      // (tile coordinates are 16-bit; keeps w * ch and the frame spans below inside their types)
     VS_ARG(vs_format_bits(format) != 0);
     const int ch = format == VS_FMT_GRAY8 ? 1 : 3;
     VS_ARG(stride >= w * ch);
@@ -1617,7 +1618,8 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
                                    int h, int stride, int format, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
                                    int* out_h) {
     VS_ARG(s && frames && out && has_output && out_w && out_h);
-    VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0 && stride >= 3 * w && w > 0 && h > 0);
+    VS_ARG(w > 0 && h > 0 && w <= 65535 && h <= 65535);
+    VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0 && stride >= 3 * w);
     VS_ARG(frame_stride >= (size_t)(h - 1) * stride + (size_t)3 * w);
     vs_aligner* a = s->aligner;
     VS_HIP(hipSetDevice(a->device));
@@ -1669,6 +1671,7 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
     const int slot = threaded_download ? slot_arg : 0;
     VS_ARG(s && frames && out && has_output && out_w && out_h && n >= 1);
     VS_ARG(format != VS_FMT_GRAY8 && vs_format_bits(format) != 0);
+    VS_ARG(w > 0 && h > 0 && w <= 65535 && h <= 65535);
     VS_ARG(stride >= 3 * w);
     const int crop = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
     VS_ARG(w > 2 * crop && h > 2 * crop);
