@@ -1318,7 +1318,7 @@ extern "C" {
 int vs_aligner_align_clips(vs_aligner* a, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip, int w,
                            int h, int stride, int format, int mem, const vs_aligner_params* params, vs_transform* out,
                            int32_t* status) {
-    VS_ARG(a && n_clips >= 1 && frames_per_clip >= 1);
+    VS_ARG(a && n_clips >= 1 && frames_per_clip >= 1 && (long long)n_clips * frames_per_clip <= 0x7fffffff);
     const int r = align_start(a, frames, frame_stride, n_clips * frames_per_clip, frames_per_clip, w, h, stride, format, mem, params, out,
                               status, false);
     return r < 0 ? r : align_finish(a);
