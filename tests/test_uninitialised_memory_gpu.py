@@ -58,11 +58,12 @@ print("DIGEST", dig.hexdigest(), "%%.6g" %% div[2])
 """
 
 
-def _run(byte):
+def _run(byte, **more_env):
     env = dict(os.environ)
     env.pop("VS_TEST_POISON_ALLOC", None)
     if byte is not None:
         env["VS_TEST_POISON_ALLOC"] = str(byte)
+    env.update(more_env)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
@@ -73,3 +74,12 @@ def test_results_do_not_depend_on_what_fresh_allocations_contain(gpu_vs):
     runs = {b: _run(b) for b in (0, 255, 0x7f)}
     assert abs(runs[0][1]) > 1e6                                # the battery does contain a run that diverged
     assert runs[0] == runs[255] == runs[0x7f], runs
+
+
+def test_results_do_not_depend_on_how_host_batches_are_cut_or_overlapped(gpu_vs):
+    """the same battery with the host-side pipelines reshaped: uploads cut into many small chunks (VS_INGEST_CHUNK_BYTES), the stabilizer's overlap of
+    warps and alignment and its prefetch switched off, one time chunk / clip group instead of four -- and freshly allocated memory poisoned throughout"""
+    base = _run(0x55)
+    for env in (dict(VS_INGEST_CHUNK_BYTES="150000"), dict(VS_INGEST_CHUNK_BYTES="1000000", VS_STAB_OVERLAP="0"),
+                dict(VS_STAB_PREFETCH="0", VS_STAB_TIME_CHUNKS="1", VS_STAB_GROUPS="1"), dict(VS_STAB_TIME_CHUNKS="8", VS_STAB_GROUPS="8")):
+        assert _run(0x55, **env) == base, env
