@@ -386,3 +386,22 @@ def test_one_long_lived_handle_through_random_call_sequences(gpu_vs, seed):
             assert st == st2 and all(np.array_equal(a.tup(), b.tup(), equal_nan=True) for a, b in zip(ts, ts2)), (op, size, k)
             (o, hs), (o2, hs2) = S.process_batch(fr), fs.process_batch(fr)
             assert hs == hs2 and np.array_equal(o[np.array(hs, bool)], o2[np.array(hs2, bool)]), (op, size, k)
+
+
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
+def test_tiny_top_levels_and_tie_heavy_frames_match_the_oracle_in_every_selection_mode(gpu_vs, oracle, seed):
+    """the same corner as test_tiny_top_levels_device_selection_equals_host_selection (top levels below 64 tiles, posterised frames) against the
+    ORACLE, in all three selection modes -- the stable rule's side-by-side histograms see the same tiny, tie-heavy tables"""
+    from video_stabilizer_amd import synth
+    rng = np.random.default_rng(171000 + seed)
+    w, h = int(rng.integers(150, 420)), int(rng.integers(100, 280))
+    lv_max = min(int(np.log2(w / 8)), int(np.log2(h / 6)))
+    lv = int(rng.integers(max(2, lv_max - 1), lv_max + 1))
+    kw = dict(pyramid_min_width=max(4, (w >> lv) + 1), pyramid_min_height=max(3, (h >> lv) + 1), smallest_fraction=float(rng.choice([0.5, 0.8, 0.95, 1.0])),
+              max_iters=int(rng.choice([3, 24])))
+    frames, _ = synth.make_clip(w, h, 4, seed=12000 + seed, channels=1, jitter_t=float(rng.choice([1.0, 6.0])))
+    q = int(rng.choice([1, 32, 64]))
+    frames = (frames // q * q).astype(np.uint8)
+    for mode in (gpu_vs.SELECT_STL_HOST, gpu_vs.SELECT_DEVICE, gpu_vs.SELECT_STABLE):
+        gpu, cpu, res = _run_both(gpu_vs, oracle, frames, select_mode=mode, **kw)
+        _check_seq(res)
