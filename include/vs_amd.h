@@ -50,8 +50,13 @@ int vs_format_max_value(int format);
  * VS_WARP_LANCZOS2_FAST: opt-in, the CONTRACTED form of the same sampler -- every Horner step and every tap accumulation a
  * single fma (what the reference's own target string, which carries `fma` and no strict_float, lets its compiler emit), the
  * tap order and the correctly rounded division unchanged; bit-identical to the CPU restatement's VSO_WARP_LANCZOS2_CONTRACTED
- * (np.array_equal, every layout), 1.27x faster at 4K. */
-enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1, VS_WARP_LANCZOS2_FAST = 2 };
+ * (np.array_equal, every layout), 1.27x faster at 4K.
+ * VS_WARP_LANCZOS2_SEP: opt-in, the SEPARABLE form -- the contracted form's weights and taps, summed rows first, then columns,
+ * over the product of the two 1-D weight sums, one correctly rounded reciprocal for all channels (equal to generators.cpp:687-697
+ * in real arithmetic; a reassociation inside the reference's own non-strict_float slack).  Bit-identical to the CPU restatement's
+ * VSO_WARP_LANCZOS2_SEPARABLE; against the UN-contracted order: at most 1 LSB, >= 99.99 % of the samples identical (8- and 10-bit;
+ * SURVEY 8(d)'s integer gate, tests/test_warp_gate_gpu.py). */
+enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1, VS_WARP_LANCZOS2_FAST = 2, VS_WARP_LANCZOS2_SEP = 3 };
 enum { VS_BORDER_CLAMP = 0, VS_BORDER_CONSTANT = 1 };
 /* how the per-level "keep the best 80 %" subset is chosen (alignment.cpp:460-486) */
 enum {

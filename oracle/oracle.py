@@ -51,7 +51,7 @@ class AlignDebug(C.Structure):
                 ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
 
 
-WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED = 0, 1, 2
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED, WARP_LANCZOS2_SEPARABLE = 0, 1, 2, 3
 SELECT_STL, SELECT_STABLE = 0, 1
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1

@@ -152,6 +152,40 @@ inline float lanczos_sample_contracted(const ImageRef<T>& img, float Wx, float W
     return sum_num / sum_den;
 }
 
+/* VSO_WARP_LANCZOS2_SEPARABLE -- the third member of the sampler family (twin of the product's VS_WARP_LANCZOS2_SEP): the same
+ * weights as the contracted form (lanczos2_contracted, generators.cpp:38-46), the same sampling position and the same 4 x 4 live
+ * taps, but the window sum is taken rows first, then columns, and the denominator as the product of the two 1-D weight sums --
+ * sum_{ry,rx} wx*wy*v = sum_ry wy * (sum_rx wx * v) and sum_{ry,rx} wx*wy = (sum wx)(sum wy) in real arithmetic: a reassociation
+ * of generators.cpp:687-697, inside the slack a non-strict_float Halide build has (CMakeLists.txt:151), admitted to benchmarks only
+ * through SURVEY 8(d)'s integer gate against the UN-contracted order (tests/test_warp_gate_*.py).  Written out:
+ *   h[ry]  = fma(wx4, v4, fma(wx3, v3, fma(wx2, v2, wx1 * v1)))          (taps 1..4 of the 5-tap window; tap 0 weighs exactly 0)
+ *   num    = fma(wy4, h4, fma(wy3, h3, fma(wy2, h2, wy1 * h1)))
+ *   den    = ((wx1 + wx2) + (wx3 + wx4)) * ((wy1 + wy2) + (wy3 + wy4))
+ *   result = num * RN(1 / den)                                             (one correctly rounded reciprocal for all channels)
+ * std::fmaf is exact-then-round-once and 1.0f / den is IEEE: the function means the same on every machine. */
+template <typename T, bool CONSTANT_BORDER>
+inline float lanczos_sample_separable(const ImageRef<T>& img, float Wx, float Wy, int c) {
+    float floorWx = std::floor(Wx), floorWy = std::floor(Wy);
+    float fracWx = Wx - floorWx, fracWy = Wy - floorWy;
+    float wx[4], wy[4];
+    for (int u = 0; u < 4; u++) {
+        wx[u] = lanczos2_contracted((float)(u - 1) - fracWx);
+        wy[u] = lanczos2_contracted((float)(u - 1) - fracWy);
+    }
+    int ix = sample_index(floorWx, img.w), iy = sample_index(floorWy, img.h);
+    float hrow[4];
+    for (int ry = 0; ry < 4; ry++) {
+        float v[4];
+        for (int rx = 0; rx < 4; rx++)
+            v[rx] = CONSTANT_BORDER ? img.constant0(ix + rx - 1, iy + ry - 1, c) : img.clamped(ix + rx - 1, iy + ry - 1, c);
+        hrow[ry] = std::fmaf(wx[3], v[3], std::fmaf(wx[2], v[2], std::fmaf(wx[1], v[1], wx[0] * v[0])));
+    }
+    float num = std::fmaf(wy[3], hrow[3], std::fmaf(wy[2], hrow[2], std::fmaf(wy[1], hrow[1], wy[0] * hrow[0])));
+    float den = ((wx[0] + wx[1]) + (wx[2] + wx[3])) * ((wy[0] + wy[1]) + (wy[2] + wy[3]));
+    float r = 1.0f / den;
+    return num * r;
+}
+
 /* image_warp's bilinear sampler (generators.cpp:148-163).  Halide float lerp(a,b,t) is
  * a*(1-t) + b*t. */
 inline float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
@@ -196,6 +230,9 @@ void bgr_warp_impl(const T* src, int w, int h, int src_stride, int channels,
                 else if (mode == VSO_WARP_LANCZOS2_CONTRACTED)
                     v = border == VSO_BORDER_CONSTANT ? lanczos_sample_contracted<T, true>(img, Wx, Wy, c)
                                                       : lanczos_sample_contracted<T, false>(img, Wx, Wy, c);
+                else if (mode == VSO_WARP_LANCZOS2_SEPARABLE)
+                    v = border == VSO_BORDER_CONSTANT ? lanczos_sample_separable<T, true>(img, Wx, Wy, c)
+                                                      : lanczos_sample_separable<T, false>(img, Wx, Wy, c);
                 else
                     v = border == VSO_BORDER_CONSTANT ? bilinear_sample<T, true>(img, Wx, Wy, c)
                                                       : bilinear_sample<T, false>(img, Wx, Wy, c);

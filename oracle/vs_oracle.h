@@ -59,7 +59,7 @@ typedef struct vso_stabilizer_params {
 
 /* VSO_WARP_LANCZOS2_CONTRACTED: the Lanczos2 sampler with the multiply-adds fused where the reference's own target
  * (CMakeLists.txt:151 "fma", no strict_float) lets LLVM fuse them -- the twin of the product's VS_WARP_LANCZOS2_FAST */
-enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1, VSO_WARP_LANCZOS2_CONTRACTED = 2 };
+enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1, VSO_WARP_LANCZOS2_CONTRACTED = 2, VSO_WARP_LANCZOS2_SEPARABLE = 3 };
 enum { VSO_BORDER_CLAMP = 0, VSO_BORDER_CONSTANT = 1 };
 enum { VSO_FMT_GRAY8 = 0, VSO_FMT_BGR8 = 1, VSO_FMT_BGR10 = 2, VSO_FMT_BGR12 = 3, VSO_FMT_BGR16_FULL = 4 };
 /* worker threads for the row-parallel loops of the image-sized stages (CPU-baseline timing only; results do not depend on it) */

@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use
 FMT_BGR16 = 5                                       # first-release format: 10-bit luma (gray >> 2), warp output saturates at 65535
-WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST = 0, 1, 2
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST, WARP_LANCZOS2_SEP = 0, 1, 2, 3
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE, SELECT_STABLE = 0, 1, 2
 BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1

@@ -523,7 +523,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     const vsk::Roi roi = roi_in ? *roi_in : vsk::Roi{0, 0, w, h};
     VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.w <= w && roi.h <= h && roi.x <= w - roi.w && roi.y <= h - roi.h);   // (no sum that could overflow)
     VS_ARG(src_stride >= w * channels && dst_stride >= roi.w * channels);
-    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST);
+    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST || mode == VS_WARP_LANCZOS2_SEP);
     VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
     VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(roi.w, roi.h, dst_stride, channels)));
     if (!vsi::device_ready()) return VS_ERR_HIP;

@@ -140,6 +140,27 @@ __device__ __forceinline__ float lanczos_contracted_combine(const float v[4][4],
     return num / den;
 }
 
+// ---- VS_WARP_LANCZOS2_SEP: the separable member of the sampler family ------------------------------------------------
+// Same weights (lanczos2_fma), sampling position and 4 x 4 live window as the contracted form; the window sum is taken rows first,
+// then columns, the denominator is the product of the two 1-D weight sums, and ONE correctly rounded reciprocal serves every channel:
+//   h[ry] = fma(wx4, v4, fma(wx3, v3, fma(wx2, v2, wx1 * v1)))      num = fma(wy4, h4, fma(wy3, h3, fma(wy2, h2, wy1 * h1)))
+//   den   = ((wx1 + wx2) + (wx3 + wx4)) * ((wy1 + wy2) + (wy3 + wy4))      out = num * RN(1 / den)
+// A reassociation of generators.cpp:687-697 (equal in real arithmetic), inside the slack the reference's own non-strict_float build has;
+// it enters a benchmark only through SURVEY 8(d)'s integer gate against the UN-contracted order (tests/test_warp_gate_gpu.py).  CPU
+// twin: the checker's VSO_WARP_LANCZOS2_SEPARABLE, bit for bit (tests/test_warp_fast_gpu.py).
+__device__ __forceinline__ float lanczos_separable_den(const float wx[4], const float wy[4]) {
+    return ((wx[0] + wx[1]) + (wx[2] + wx[3])) * ((wy[0] + wy[1]) + (wy[2] + wy[3]));
+}
+// one channel: v[ry][rx] = the live 4x4 window as floats; rden = RN(1 / den)
+__device__ __forceinline__ float lanczos_separable_combine(const float v[4][4], const float wx[4], const float wy[4], float rden) {
+    float h[4];
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++)
+        h[ry] = __builtin_fmaf(wx[3], v[ry][3], __builtin_fmaf(wx[2], v[ry][2], __builtin_fmaf(wx[1], v[ry][1], wx[0] * v[ry][0])));
+    const float num = __builtin_fmaf(wy[3], h[3], __builtin_fmaf(wy[2], h[2], __builtin_fmaf(wy[1], h[1], wy[0] * h[0])));
+    return num * rden;
+}
+
 // Lanczos2 sample of a single-channel u8 image with clamp-to-edge addressing:
 // generators.cpp:672-697 (sparse_warpdiff) == :469-498 (sparse_ica).  rx inner, ry outer,
 // separate num / den accumulators from 0, one IEEE divide.

@@ -887,11 +887,12 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
     float frx = Wx - flx, fry = Wy - fly;
     float wx[4], wy[4];
     if (MODE == 0) { lanczos_weights4(frx, wx); lanczos_weights4(fry, wy); }
-    if (MODE == 2) { lanczos_weights4_fma(frx, wx); lanczos_weights4_fma(fry, wy); }
+    if (MODE == 2 || MODE == 3) { lanczos_weights4_fma(frx, wx); lanczos_weights4_fma(fry, wy); }
+    const float rden = MODE == 3 ? 1.0f / lanczos_separable_den(wx, wy) : 0.0f;      // IEEE divide: the correctly rounded reciprocal
     for (int c = 0; c < channels; c++) {
         float v;
-        if (MODE == 2) {
-            // VS_WARP_LANCZOS2_FAST (vs_device.hpp): the contracted sampler, here with float output too
+        if (MODE == 2 || MODE == 3) {
+            // VS_WARP_LANCZOS2_FAST / VS_WARP_LANCZOS2_SEP (vs_device.hpp): the contracted and the separable sampler, here with float output too
             float t[4][4];
 #pragma unroll
             for (int ry = 0; ry < 4; ry++) {
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
                     }
                 }
             }
-            v = lanczos_contracted_combine(t, wx, wy);
+            v = MODE == 3 ? lanczos_separable_combine(t, wx, wy, rden) : lanczos_contracted_combine(t, wx, wy);
         } else if (MODE == 0) {
             float num = 0.0f, den = 0.0f;
 #pragma unroll
@@ -1126,6 +1127,8 @@ static void launch_generic(const T* src, int w, int h, int src_stride, int chann
     else if (mode == 0) VS_LAUNCH(0, 1);
     else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
     else if (mode == 2) VS_LAUNCH(2, 1);
+    else if (mode == 3 && border == 0) VS_LAUNCH(3, 0);
+    else if (mode == 3) VS_LAUNCH(3, 1);
     else if (border == 0) VS_LAUNCH(1, 0);
     else VS_LAUNCH(1, 1);
 #undef VS_LAUNCH

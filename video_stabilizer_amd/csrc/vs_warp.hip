@@ -312,6 +312,11 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
 // operations and their order are fast_pair's (weights: Horner fmas per chain; taps rx inner, ry outer; num = fma(w2d, val, num),
 // den = den + w2d; div3_core; store_u), so the result is bit-identical: the pipelining only decides WHEN an instruction issues.
 // Scheduling fences between the slices keep the compiler from undoing the interleave.
+// (Round 5 tried to leave out the four |x| >= 2 selects per pixel in blocks whose fractions cannot reach them -- one min3 / max3 chain over
+// the block's fractions and a ballot; they fire for frac == 0 and for a fraction rounded up to 1 only, ~8 % of the blocks at 4K.  Both ways
+// to do it lost: two copies of this function behind a wave-uniform branch took the kernel from 78 to 128 VGPRs with 9 spilled (42.1 us per
+// 4K frame instead of 38.3), scalar branches over the select slices cut the straight-line block into pieces the register allocator
+// handles far worse (135 spilled VGPRs).  profiles/r05_warp_sep.md.)
 template <int NPX>
 __device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
                                                     uint32_t (&o)[NPX][3], bool& all_ok) {
@@ -394,6 +399,139 @@ __device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], cons
     }
 }
 
+// RN(1 / den) for den in [0.5, 2): v_rcp, one Newton step, one residual correction.  Equal to the IEEE quotient 1.0f / den for EVERY
+// float of the range (exhaustive: tools/check_rcp.hip, profiles/r05_check_rcp.txt; the compiler's own expansion makes a second
+// correction and scales / fixes up for the operands outside it).  The separable sampler's den = (sum wx)(sum wy) lies in [0.9995, 1.039]
+// for every fraction in [0, 1] (the same tool walks all 2^30 + 1 of them), so no range test guards the call.
+__device__ __forceinline__ float rcp_rn(float den) {
+    float r = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const float tt = __builtin_fmaf(-den, r, 1.0f);
+    return __builtin_fmaf(tt, r, r);
+}
+
+// VS_WARP_LANCZOS2_SEP of one output pixel, straight-line (the what-if builds and VS_WARP_FAST_PIPE=0): num = {numB, numG, numR, den}
+__device__ __forceinline__ void sep_pixel(const lds_f4 t, const f2 fr, float num[4]) {
+    float wx[4], wy[4];
+    lanczos_weights4_fma(fr.x, wx);
+    lanczos_weights4_fma(fr.y, wy);
+    float h[4][3];
+#pragma unroll
+    for (int ry = 0; ry < 4; ry++) {
+#pragma unroll
+        for (int rx = 0; rx < 4; rx++) {
+            const f4 val = t[ry * WS_RS + rx];
+            const float vc[3] = {val.x, val.y, val.z};
+#pragma unroll
+            for (int c = 0; c < 3; c++) h[ry][c] = rx == 0 ? wx[0] * vc[c] : __builtin_fmaf(wx[rx], vc[c], h[ry][c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        num[c] = __builtin_fmaf(wy[3], h[3][c], __builtin_fmaf(wy[2], h[2][c], __builtin_fmaf(wy[1], h[1][c], wy[0] * h[0][c])));
+    num[3] = lanczos_separable_den(wx, wy);
+}
+
+// VS_WARP_LANCZOS2_SEP for the RB = 4 pixels of a lane, software-pipelined like fast_rows_pipelined: stage k interleaves, slice by slice
+// (16 slices, one tap each), the taps of pixel k (3 fmas per tap into the row sums h, 3 more after a row's fourth tap into num), the
+// weight chains of pixel k + 1, the denominator and its reciprocal of pixel k, and the scaling / store conversion of pixel k - 1.  Per
+// pixel: 72 weight-chain operations, 7 for den, 5 for RN(1 / den), 48 + 12 tap fmas, 3 products, 9 store conversions = 156 against the
+// contracted form's 179 -- bit-identical to lanczos_separable_combine / the oracle's
+// VSO_WARP_LANCZOS2_SEPARABLE (the pipelining only decides WHEN an instruction issues).  num[k] = {numB, numG, numR, den}; all_ok is
+// not touched (rcp_rn: den cannot leave its range).
+template <int NPX>
+__device__ __forceinline__ void sep_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
+                                                   uint32_t (&o)[NPX][3], bool& all_ok) {
+    constexpr int NV = 8, AHEAD = VS_WARP_PIPE_AHEAD;
+    static_assert(AHEAD >= 1 && AHEAD < NV && 16 % NV == 0, "ring of eight tap registers");
+    const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
+    f4 vals[NV];
+    float wgt[2][8];                 // finished weights: wgt[k & 1] belongs to pixel k (x taps 1..4, then y taps 1..4)
+    float wx_[8], wx2[8];            // the chains under construction: arguments, their squares (values in wgt[(k + 1) & 1])
+    float h[3] = {0.f, 0.f, 0.f};    // the row sums of the current source row
+    float rc[2] = {0.f, 0.f};        // RN(1 / den): rc[k & 1] belongs to pixel k
+    float sx_ = 0.f, r_ = 0.f, qv[3] = {0.f, 0.f, 0.f};
+    auto w_slice = [&](int j, int kk) {
+        float (&v)[8] = wgt[kk & 1];
+        const float f = (j == 0) ? fr[kk].x : fr[kk].y;
+        if (j < 2) {
+            const int b = 4 * j;
+            wx_[b + 0] = -1.0f - f; wx_[b + 1] = 0.0f - f; wx_[b + 2] = 1.0f - f; wx_[b + 3] = 2.0f - f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { wx2[b + c] = wx_[b + c] * wx_[b + c]; v[b + c] = 0.000858519f; }
+        } else if (j < 14) {
+            const int step = (j - 2) >> 1, b = 4 * ((j - 2) & 1);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[b + c] = __builtin_fmaf(v[b + c], wx2[b + c], C[step]);
+        } else {
+            const int b = 4 * (j - 14);                      // |x| >= 2 can only happen for taps 1 (-1-frac) and 4 (2-frac)
+            v[b + 0] = fabsf(wx_[b + 0]) >= 2.0f ? 0.0f : v[b + 0];
+            v[b + 3] = fabsf(wx_[b + 3]) >= 2.0f ? 0.0f : v[b + 3];
+        }
+    };
+    // den = (sum wx)(sum wy) of pixel kk and its correctly rounded reciprocal (rcp_rn), 12 instructions in 5 slices
+    auto r_slice = [&](int j, int kk) {
+        const float (&v)[8] = wgt[kk & 1];
+        const float den = num[kk][3];
+        if (j == 0) sx_ = (v[0] + v[1]) + (v[2] + v[3]);
+        else if (j == 1) num[kk][3] = sx_ * ((v[4] + v[5]) + (v[6] + v[7]));
+        else if (j == 3) r_ = __builtin_amdgcn_rcpf(den);
+        else if (j == 6) {
+            const float e = __builtin_fmaf(-den, r_, 1.0f);
+            r_ = __builtin_fmaf(e, r_, r_);
+        } else if (j == 9) {
+            const float tt = __builtin_fmaf(-den, r_, 1.0f);
+            rc[kk & 1] = __builtin_fmaf(tt, r_, r_);
+        }
+    };
+    // scaling + store conversion of pixel kk (3 products, 3 x store_u)
+    auto d_slice = [&](int j, int kk) {
+        if (j == 2 || j == 4 || j == 6) {
+            const int c = (j - 2) >> 1;
+            qv[c] = num[kk][c] * rc[kk & 1];
+        } else if (j == 8 || j == 10 || j == 12) {
+            const int c = (j - 8) >> 1;
+            o[kk][c] = store_u(qv[c], maxv);
+        }
+    };
+    auto issue = [&](int j, int kk) {
+        const int jj = j + AHEAD, kt = kk + (jj >> 4), tj = jj & 15;
+        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * WS_RS + (tj & 3)];
+    };
+#pragma unroll
+    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * WS_RS + (j & 3)];
+#pragma unroll
+    for (int j = 0; j < 16; j++) w_slice(j, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k <= NPX; k++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (k < NPX) {
+                issue(j, k);
+                const f4 val = vals[j % NV];
+                const int rx = j & 3, ry = j >> 2;
+                const float wxv = wgt[k & 1][rx];
+                if (rx == 0) { h[0] = wxv * val.x; h[1] = wxv * val.y; h[2] = wxv * val.z; }
+                else { h[0] = __builtin_fmaf(wxv, val.x, h[0]); h[1] = __builtin_fmaf(wxv, val.y, h[1]); h[2] = __builtin_fmaf(wxv, val.z, h[2]); }
+                // the tile's trailing 1.0 is not used by this form; the empty statement keeps that quarter of the in-flight ds_read_b128's
+                // destination allocated until here (a recycled quarter makes the hardware drain the LDS queue, see fast_rows_pipelined)
+                asm volatile("" :: "v"(val.w));
+                if (rx == 3) {
+                    const float wyv = wgt[k & 1][4 + ry];
+                    if (ry == 0) { num[k][0] = wyv * h[0]; num[k][1] = wyv * h[1]; num[k][2] = wyv * h[2]; }
+                    else { num[k][0] = __builtin_fmaf(wyv, h[0], num[k][0]); num[k][1] = __builtin_fmaf(wyv, h[1], num[k][1]); num[k][2] = __builtin_fmaf(wyv, h[2], num[k][2]); }
+                }
+                if (k + 1 < NPX) w_slice(j, k + 1);
+                r_slice(j, k);
+            }
+            if (k >= 1) d_slice(j, k - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // image_warp's bilinear (generators.cpp:148-163) per channel; t = staged pixel (iy, ix)
 __device__ __forceinline__ void sample_bilinear(lds_f4 t, f2 fr, float q[3]) {
     const f4 a0 = t[0], a1 = t[1], b0 = t[WS_RS], b1 = t[WS_RS + 1];
@@ -464,17 +602,18 @@ __device__ __forceinline__ void warp_pixel_global(const T* __restrict__ src, int
             }
 #pragma unroll
         for (int c = 0; c < 3; c++) out[c] = store_u(num[c] / den, maxv);
-    } else if (MODE == 2) {
+    } else if (MODE == 2 || MODE == 3) {
         float wx[4], wy[4];
         lanczos_weights4_fma(frx, wx);
         lanczos_weights4_fma(fry, wy);
+        const float rden = MODE == 3 ? 1.0f / lanczos_separable_den(wx, wy) : 0.0f;
         for (int c = 0; c < 3; c++) {
             float v[4][4];
 #pragma unroll
             for (int ry = 0; ry < 4; ry++)
 #pragma unroll
                 for (int rx = 0; rx < 4; rx++) v[ry][rx] = fetch(ix + rx - 1, iy + ry - 1, c);
-            out[c] = store_u(lanczos_contracted_combine(v, wx, wy), maxv);
+            out[c] = store_u(MODE == 3 ? lanczos_separable_combine(v, wx, wy, rden) : lanczos_contracted_combine(v, wx, wy), maxv);
         }
     } else {
 #pragma unroll
@@ -514,7 +653,7 @@ __device__ __forceinline__ FillItem fill_item(int lane, int slot) {
 }
 
 template <typename T, int MODE, int BORDER>
-__global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
+__global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAVES : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
@@ -820,6 +959,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
 #endif
     if (MODE == 2 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
         fast_rows_pipelined<RB>(t_all, fr_all, maxv, num, o, all_ok);
+    } else if (MODE == 3 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
+        sep_rows_pipelined<RB>(t_all, fr_all, maxv, num, o, all_ok);
     } else
 #pragma unroll
     for (int kp = 0; kp < RB; kp += 2) {
@@ -833,6 +974,13 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
                 all_ok = all_ok && (num[kp + j][3] > 0.5f && num[kp + j][3] < 2.0f);
                 if (VS_WARP_WHATIF & 4) { q[j][0] = num[kp + j][0]; q[j][1] = num[kp + j][1]; q[j][2] = num[kp + j][2] + num[kp + j][3]; }
                 else div3_core(num[kp + j][0], num[kp + j][1], num[kp + j][2], num[kp + j][3], q[j]);
+            }
+        } else if (MODE == 3) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                sep_pixel(t[j], fr[j], num[kp + j]);
+                const float r = rcp_rn(num[kp + j][3]);
+                q[j][0] = num[kp + j][0] * r; q[j][1] = num[kp + j][1] * r; q[j][2] = num[kp + j][2] * r;
             }
         } else if (MODE == 2) {
             fast_pair(t, fr, &num[kp]);
@@ -862,7 +1010,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? VS_WARP_FAST_MINWAVES : (raw_tile_
         }
         if (MODE == 2 && VS_WARP_FAST_SCHED >= 1) __builtin_amdgcn_sched_barrier(0);   // keeps the second pair's 32 LDS reads (128 VGPRs) behind the first pair
     }
-    if (MODE != 1 && !VS_WARP_WHATIF && __any(!all_ok)) {
+    if (MODE != 1 && MODE != 3 && !VS_WARP_WHATIF && __any(!all_ok)) {
         // a weight sum outside (0.5, 2): cannot happen for frac in [0,1]; kept so that the result is operator/ whatever the input
 #pragma unroll
         for (int k = 0; k < RB; k++) {
@@ -1003,6 +1151,8 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
         else if (mode == 0) VS_LAUNCH(0, 1);
         else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
         else if (mode == 2) VS_LAUNCH(2, 1);
+        else if (mode == 3 && border == 0) VS_LAUNCH(3, 0);
+        else if (mode == 3) VS_LAUNCH(3, 1);
         else if (border == 0) VS_LAUNCH(1, 0);
         else VS_LAUNCH(1, 1);
     }
