@@ -3,7 +3,9 @@
 // grid_search_align.cpp:159-210 -- independent workers, nothing shared but a work counter).
 //
 //   vs_many_clips [--devices a,b,...|all] [--clips 64] [--frames 120] [--size 1920x1080] [--steps 3] [--min-width 256]
-//                 [--exact] [--no-warp]
+//                 [--warp-mode separable|contracted|exact] [--exact] [--no-warp] [--no-rccl]
+// (--warp-mode: the member of the Lanczos2 sampler family, default separable = bench.py's `value`; --exact = --warp-mode exact.
+//  VS_MANY_CLIPS_TEST_FAIL_SLOT=g in the environment makes slot g fail on purpose: the exit code must say so, tests/test_apps_gpu.py.)
 //
 // One thread per device slot (a device may be listed twice: the one-GPU box rehearses the split that way).  Clip i belongs to
 // slot i mod G -- the same static round robin as bench.py's ranks --; a slot's clips sit back to back in its HBM.  The timed step
@@ -71,7 +73,8 @@ bool parse_devices(const std::string& list, std::vector<int>& out) {
 int main(int argc, char** argv) {
     std::vector<int> devices = {0};
     int clips = 64, frames = 120, w = 1920, h = 1080, steps = 3, min_width = 256;
-    bool exact = false, warp = true, use_rccl = true;
+    bool warp = true, use_rccl = true;
+    std::string warp_mode = "separable";
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -82,13 +85,17 @@ int main(int argc, char** argv) {
         else if (a == "--steps") { if (!(v = next())) return 1; steps = std::atoi(v); }
         else if (a == "--min-width") { if (!(v = next())) return 1; min_width = std::atoi(v); }
         else if (a == "--size") { if (!(v = next()) || std::sscanf(v, "%dx%d", &w, &h) != 2) { std::fprintf(stderr, "Error: --size WxH\n"); return 1; } }
-        else if (a == "--exact") exact = true;
+        else if (a == "--exact") warp_mode = "exact";
+        else if (a == "--warp-mode") { if (!(v = next())) return 1; warp_mode = v; if (warp_mode == "sep") warp_mode = "separable"; if (warp_mode == "fast") warp_mode = "contracted"; }
         else if (a == "--no-warp") warp = false;
         else if (a == "--no-rccl") use_rccl = false;
-        else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--exact] [--no-warp] [--no-rccl]\n", argv[0]); return 1; }
+        else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--warp-mode separable|contracted|exact] [--no-warp] [--no-rccl]\n", argv[0]); return 1; }
     }
     const int G = (int)devices.size();
     if (clips < 1 || frames < 2 || steps < 1 || w < 64 || h < 64) { std::fprintf(stderr, "Error: bad sizes\n"); return 1; }
+    if (warp_mode != "separable" && warp_mode != "contracted" && warp_mode != "exact") { std::fprintf(stderr, "Error: --warp-mode separable|contracted|exact\n"); return 1; }
+    const char* fail_env = std::getenv("VS_MANY_CLIPS_TEST_FAIL_SLOT");
+    const int fail_slot = fail_env ? std::atoi(fail_env) : -1;
     for (int d : devices) if (d < 0 || d >= vs_device_count()) { std::fprintf(stderr, "Error: no HIP device %d\n", d); return 1; }
     if (vs_abi_version() != VS_ABI_VERSION) { std::fprintf(stderr, "Error: libvs_amd ABI %d, built for %d\n", vs_abi_version(), VS_ABI_VERSION); return 1; }
 
@@ -135,7 +142,7 @@ int main(int argc, char** argv) {
 
     std::vector<SlotResult> res((size_t)G);
     Barrier barrier(G);
-    const int mode = exact ? VS_WARP_LANCZOS2 : VS_WARP_LANCZOS2_FAST;
+    const int mode = warp_mode == "exact" ? VS_WARP_LANCZOS2 : (warp_mode == "contracted" ? VS_WARP_LANCZOS2_FAST : VS_WARP_LANCZOS2_SEP);
     auto slot = [&](int g) {
         SlotResult& r = res[(size_t)g];
         const int dev = devices[(size_t)g];
@@ -171,6 +178,7 @@ int main(int argc, char** argv) {
             }
             return good;
         };
+        if (g == fail_slot) fail("slot " + std::to_string(g) + " fails on purpose (VS_MANY_CLIPS_TEST_FAIL_SLOT)");
         if (mine > 0 && r.error.empty()) { step(); (void)hipDeviceSynchronize(); }          // warm: allocations, clocks
         barrier.wait();
         const auto t0 = std::chrono::steady_clock::now();
@@ -238,7 +246,7 @@ int main(int argc, char** argv) {
     std::printf("{\"program\": \"vs_many_clips\", \"host\": \"C++ threads, one per device slot\", \"devices\": [");
     for (int g = 0; g < G; g++) std::printf("%s%d", g ? ", " : "", devices[(size_t)g]);
     std::printf("], \"clips\": %d, \"frames_per_clip\": %d, \"width\": %d, \"height\": %d, \"steps\": %d, \"warp\": \"%s\", \"scaling\": \"strong\", ", clips, frames, w, h,
-                steps, warp ? (exact ? "lanczos2" : "lanczos2 contracted") : "none");
+                steps, warp ? (warp_mode == "exact" ? "lanczos2" : (warp_mode == "contracted" ? "lanczos2 contracted" : "lanczos2 separable")) : "none");
     std::printf("\"value\": %.2f, \"unit\": \"aligned frames/s\", \"frames_per_s\": %.2f, \"seconds\": %.5f, \"per_slot_seconds\": [", total_aligned / slowest,
                 total_frames / slowest, slowest);
     for (int g = 0; g < G; g++) std::printf("%s%.5f", g ? ", " : "", res[(size_t)g].seconds);

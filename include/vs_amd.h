@@ -233,9 +233,9 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
 /* Test hook, not part of the reference's surface: fault injection for the library's own device / pinned-host allocations.
  * vs_test_fail_alloc(k), k > 0: the k-th allocation the library makes from now on (any handle, any thread) fails once with
  * out-of-memory, and the call it belongs to returns VS_ERR_HIP; k = 0 disarms.  Returns the number of allocations made since the
- * previous call of this function.  The environment variable VS_TEST_FAIL_ALLOC=k arms it at load time for programs that cannot
+ * previous call of this function.  The environment variable VS_TEST_FAIL_ALLOC=k (honoured only together with VS_TEST_HOOKS=1) arms it at load time for programs that cannot
  * call it.  tests/test_alloc_failure_gpu.py walks k over every allocation of the engine-level calls. */
-/* VS_TEST_POISON_ALLOC=<byte> in the environment (read once): every fresh device allocation starts filled with that byte, so that a result
+/* VS_TEST_POISON_ALLOC=<byte> in the environment (read once; honoured only together with VS_TEST_HOOKS=1): every fresh device allocation starts filled with that byte, so that a result
  * which depends on memory the library never wrote changes with the byte (tests/test_uninitialised_memory_gpu.py). */
 int vs_test_fail_alloc(int k);
 
@@ -253,6 +253,11 @@ int vs_debug_bounds_selftest(void);
  * with 12-byte accesses per lane, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for the warp
  * kernel's access width (tools/calibrate_counters.py). */
 int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stream);
+/* Profiling aid: the shader clock as a kernel sees it.  Launches one VALU-bound probe kernel (2048 workgroups of dependent fmas,
+ * ~0.3 ms) on `stream` of the current device and returns delta s_memtime / delta s_memrealtime x 100 MHz of its first wave in
+ * *shader_mhz (MI355X_MICROARCH.md: the pair of counters that shows DVFS give-back); synchronises the stream.  bench.py issues it
+ * directly behind its timed loop, so the figure is the clock the timed kernels ran at. */
+int vs_shader_clock_probe(void* stream, double* shader_mhz);
 
 /* ------------------------------------------------------------------------------------------
  * Engine level: VideoAligner (alignment.hpp:51-99) and VideoStabilizer (stabilizer.hpp:32-56)

@@ -192,9 +192,11 @@ inline float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 
 template <typename T, bool CONSTANT_BORDER>
 inline float bilinear_sample(const ImageRef<T>& img, float Wx, float Wy, int c) {
-    int fx = sat_int(std::floor(Wx)), fy = sat_int(std::floor(Wy));
-    float wx = Wx - (float)fx, wy = Wy - (float)fy;           /* (the fraction comes from the converted index: generators.cpp:150-153) */
-    fx = clampi(fx, -8, img.w + 7); fy = clampi(fy, -8, img.h + 7);
+    /* generators.cpp:150-153 takes the fraction from the converted index, W - float(int(floor(W))): equal to W - floor(W) for every position
+     * inside the int range and undefined outside it; W - floor(W) is defined everywhere, and it is what every kernel of the product uses */
+    float flx = std::floor(Wx), fly = std::floor(Wy);
+    float wx = Wx - flx, wy = Wy - fly;
+    int fx = sample_index(flx, img.w), fy = sample_index(fly, img.h);
     float x0y0, x1y0, x0y1, x1y1;
     if (CONSTANT_BORDER) {
         x0y0 = img.constant0(fx, fy, c); x1y0 = img.constant0(fx + 1, fy, c);

@@ -189,6 +189,6 @@ def test_environment_variable_arms_the_hook():
             "except capi.VsError as e:\n"
             "    print('FAILED', e)\n"
             "st, ts = a.align_batch(f); print('THEN', sum(st))\n") % root
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VS_TEST_FAIL_ALLOC="3"), capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VS_TEST_FAIL_ALLOC="3", VS_TEST_HOOKS="1"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "FAILED" in out.stdout and "out of memory" in out.stdout.lower() and "THEN" in out.stdout, out.stdout

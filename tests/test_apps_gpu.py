@@ -279,6 +279,17 @@ def test_many_clips_cpp_harness_splits_clips_over_device_slots(gpu_vs, clip):
     assert one["aggregate"].startswith("rccl") and one["aggregate_note"] == ""
     assert two["aggregate"] == "host-side sums" and "more than once" in two["aggregate_note"]
     for j in (one, two):
-        assert j["value"] > 0 and j["scaling"] == "strong" and j["seconds"] == max(j["per_slot_seconds"]) and j["warp"] == "lanczos2 contracted"
+        assert j["value"] > 0 and j["scaling"] == "strong" and j["seconds"] == max(j["per_slot_seconds"]) and j["warp"] == "lanczos2 separable"
+    # eight slots -- the shape of the driver's 8-GPU run -- on the one device: BASELINE configs[3]'s 64 clips, 8 per slot, eight per-slot
+    # seconds, one JSON line; eight RCCL ranks cannot share a GPU, so the report falls back to the host-side sums and says so
+    raw8 = run("vs_many_clips", "--clips", 64, "--frames", 3, "--size", "640x360", "--steps", 2, "--min-width", 64, "--devices", "0,0,0,0,0,0,0,0")
+    assert len(raw8.strip().splitlines()) == 1
+    eight = json.loads(raw8.strip())
+    assert eight["devices"] == [0] * 8 and eight["per_slot_clips"] == [8] * 8 and len(eight["per_slot_seconds"]) == 8
+    assert eight["aligned_per_step"] == 64 * 2 and eight["aggregate"] == "host-side sums" and "more than once" in eight["aggregate_note"]
+    # a slot that fails ends the program with an error naming it, whatever the other seven did
+    bad = subprocess.run([os.path.join(BIN, "vs_many_clips"), "--clips", "64", "--frames", "3", "--size", "640x360", "--steps", "1", "--min-width", "64",
+                          "--devices", "0,0,0,0,0,0,0,0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, VS_MANY_CLIPS_TEST_FAIL_SLOT="5"))
+    assert bad.returncode == 1 and "slot 5 fails on purpose" in bad.stderr and "{" not in bad.stdout
     out = subprocess.run([os.path.join(BIN, "vs_many_clips"), "--devices", "0,9"], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "no HIP device 9" in out.stderr

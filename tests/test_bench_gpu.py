@@ -44,28 +44,36 @@ def test_bench_line_contract(gpu_vs):
     # the parity gate that rides on the CPU baseline: the timed GPU path against the oracle on the clip's first frames
     p = j["parity"]
     assert p["pass"] is True and p["status_equal"] and p["iterations_equal"] and p["transform_max_abs_diff"] <= 1e-4
-    assert p["warp_pixels_equal"] is True and p["contracted_warp_pixels_equal"] is True and p["frames"] == 8
-    # the north star's own operating point: 32 x 4K frames, isolated, exact and contracted arithmetic
-    for name in ("exact", "contracted"):
+    assert p["warp_pixels_equal"] is True and p["contracted_warp_pixels_equal"] is True and p["separable_warp_pixels_equal"] is True and p["frames"] == 8
+    # the north star's own operating point: 32 x 4K frames, isolated, every member of the sampler family
+    for name in ("exact", "contracted", "separable"):
         q = j["roofline_4k"][name]
         assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["frames_per_launch"] == 32
         assert abs(q["frac"] - q["achieved"] / q["peak"]) < 1e-3 and q["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 32
-    assert j["roofline_4k"]["contracted"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
-    # `value` runs the contracted sampler; the un-contracted figure rides beside it, and the gate that admits the former is in the line
-    assert "contracted" in j["config"]["warp"] and "contracted" in r["kernel"] and j["config"]["select_mode_in_force"] == 1
-    assert j["exact_warp"]["value"] > 0 and "contracted_warp" not in j and j["stable_select"]["value"] > 0
-    g = p["contracted_vs_exact"]
-    assert g["pass"] is True and g["max_abs_diff_lsb"] <= 1 and g["least_identical_fraction"] >= 0.9999
-    assert any("3840x2160" in f for f in g["frames"]) and sum("1920x1080" in f for f in g["frames"]) >= 2
+    assert j["roofline_4k"]["separable"]["achieved"] > j["roofline_4k"]["contracted"]["achieved"] > j["roofline_4k"]["exact"]["achieved"]
+    # `value` runs the separable sampler and says so; the un-contracted and the contracted figures ride beside it, and the gates that admit
+    # the two reassociated forms are in the line
+    assert j["value_warp_mode"] == "separable" and "separable" in j["config"]["warp"] and "separable" in r["kernel"]
+    assert j["config"]["select_mode_in_force"] == 1
+    assert j["exact_warp"]["value"] > 0 and j["contracted_warp"]["value"] > 0 and "separable_warp" not in j and j["stable_select"]["value"] > 0
+    for key in ("separable_vs_exact", "contracted_vs_exact"):
+        g = p[key]
+        assert g["pass"] is True and g["max_abs_diff_lsb"] <= 1 and g["least_identical_fraction"] >= 0.9999, key
+        assert sum("1920x1080" in f for f in g["frames"]) >= 2
+    assert any("3840x2160" in f for f in p["separable_vs_exact"]["frames"])
+    # measurement hygiene: an untimed pre-roll of >= 150 ms, the driver's loop three times (value = the median), the shader clock
+    sp = j["value_spread"]
+    assert sp["repeats"] == 3 and len(sp["values"]) == 3 and sp["values"] == sorted(sp["values"]) and sp["values"][1] == j["value"]
+    assert j["preroll"]["seconds"] >= 0.15 and j["preroll"]["steps"] >= 4 and 500 < j["shader_clock_mhz"] < 3500
     # the 4K half of the metric (BASELINE configs[2]) in the same line
     c3 = j["c3"]
     assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
     assert c3["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120 and "gn" in c3["stages"]
-    assert c3["exact_warp"]["value"] > 0 and c3["contracted_vs_exact"]["pass"] is True
+    assert c3["exact_warp"]["value"] > 0 and c3["contracted_warp"]["value"] > 0 and c3["separable_vs_exact"]["pass"] is True
     # BASELINE configs[4]: 4K 10-bit, full stabilizer loop (2 of the 8 clips per GPU here)
     c5 = j["c5"]
     assert "error" not in c5 and c5["value"] > 0 and c5["dtype"] == "u16" and c5["frames_per_step"] == 2 * 60
-    assert c5["outputs_per_step"] == 2 * 50 and c5["exact_warp"]["value"] > 0
+    assert c5["outputs_per_step"] == 2 * 50 and c5["exact_warp"]["value"] > 0 and c5["contracted_warp"]["value"] > 0 and "property-checked" in c5["note"]
     # the reference's per-frame call pattern on host frames, beside the oracle making the same calls
     for res in ("1080p", "2160p"):
         d = j["drop_in"][res]
@@ -80,26 +88,48 @@ def test_bench_line_contract(gpu_vs):
     assert hf["identical_to_device_resident"] is True and hf["value"] > 0 and 0 < hf["of_pinned_h2d"] <= 1.05
 
 
-def test_bench_spawns_its_own_ranks(gpu_vs):
-    """`bench.py --gpus 2` with no launcher in the environment starts both ranks itself (gloo here: two ranks share the one
-    GPU of the box; the real run is nccl = RCCL with one GPU per rank) and rank 0 reports n_gpus == 2."""
+RANKS = 5      # the box's process guard allows six GPU processes at once; this pytest process is one of them
+
+
+def _spawn(extra_env=None, clips=64, frames=4):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0",
-                          "--c4-clips", "5", "--c4-frames", "6"],
-                         capture_output=True, text=True, timeout=600, env=env)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(RANKS), "--frames", "6", "--steps", "2", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-roofline-4k", "--no-host-fed", "--dist-backend", "gloo", "--device", "0",
+                           "--c4-clips", str(clips), "--c4-frames", str(frames), "--c4-strong"],
+                          capture_output=True, text=True, timeout=900, env=env)
+
+
+def test_bench_spawns_its_own_ranks(gpu_vs):
+    """`bench.py --gpus N` with no launcher in the environment starts the ranks itself (gloo here: the ranks share the one GPU of the box;
+    the real run is nccl = RCCL with one GPU per rank) and rank 0 reports the whole job.  Five ranks -- as many as the box's process
+    guard leaves room for; the eight-rank case of the same launcher loop runs on the CPU (tests/test_dist_cpu.py) -- with BASELINE
+    configs[3]'s 64 clips as the strong-scaling leg."""
+    out = _spawn()
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1                                          # one line for the whole job
     assert out.stdout.strip() == lines[0]                           # ... and nothing else on stdout (library banners go to stderr)
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dist_backend"] == "gloo"
-    assert j["aligned_per_step"] == 2 * 5                           # both ranks' clips are counted
-    # N > 1, default workload: BASELINE configs[3] as a strong-scaling leg beside the weak `value` (here 5 clips of 6 frames:
-    # clip i -> rank i mod 2), with every rank's seconds
+    assert j["n_gpus"] == RANKS and j["rccl_ranks"] == RANKS and j["dist_backend"] == "gloo"
+    assert j["aligned_per_step"] == RANKS * 5                       # every rank's clip is counted
+    assert len(j["value_spread"]["values"]) == 3
+    # N > 1, default workload: BASELINE configs[3] as a strong-scaling leg beside the weak `value`: 64 clips, clip i -> rank i mod N,
+    # with every rank's seconds
     s = j["c4_strong"]
-    assert s["scaling"] == "strong" and s["clips_total"] == 5 and s["clips_per_rank"] == [3, 2] and len(s["per_rank_seconds"]) == 2
+    assert s["scaling"] == "strong" and s["clips_total"] == 64 and s["clips_per_rank"] == [13, 13, 13, 13, 12] and len(s["per_rank_seconds"]) == RANKS
     assert s["value"] > 0 and all(x > 0 for x in s["per_rank_seconds"])
+
+
+def test_a_failing_rank_ends_the_job_with_its_exit_code(gpu_vs):
+    """rank 3 dies right after the process group is up; the others would wait in the first barrier for the collective's timeout: the
+    launcher loop stops them, the job's exit code is the failing rank's, and no report line is printed"""
+    import time
+    t0 = time.perf_counter()
+    out = _spawn({"VS_BENCH_TEST_FAIL_RANK": "3"}, clips=5, frames=4)
+    assert out.returncode == 7, (out.returncode, out.stderr[-1500:])
+    assert "rank 3 ended with exit code 7" in out.stderr and "{" not in out.stdout
+    assert time.perf_counter() - t0 < 300
 
 
 def test_bench_two_ranks_gloo_rehearsal(gpu_vs):

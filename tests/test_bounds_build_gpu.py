@@ -59,7 +59,7 @@ def test_selection_warp_phase_and_config_tests_pass_on_the_bounds_build_with_a_c
     global scratch, sixteen pairs with helper workgroups (exchange arrays), a 4K frame and the 10-bit stabilizer share at full size.
     (The WHOLE -m gpu suite has been run against this build once per round: profiles/r04_bounds_build.md.)"""
     # (every fresh device allocation of these runs starts filled with 0xA5: nothing compared against the oracle may depend on it)
-    env = dict(os.environ, VS_AMD_LIB=bounds_lib, VS_BOUNDS_BUILD="1", VS_TEST_POISON_ALLOC="165")
+    env = dict(os.environ, VS_AMD_LIB=bounds_lib, VS_BOUNDS_BUILD="1", VS_TEST_POISON_ALLOC="165", VS_TEST_HOOKS="1")
     runs = [(["tests/test_select_gpu.py", "tests/test_select_stable_gpu.py", "tests/test_warp_fast_gpu.py", "tests/test_phase_gpu.py",
               "tests/test_warp_sweep_gpu.py", "tests/test_kernel_chain_sweep_gpu.py", "tests/test_engine_sweep_gpu.py"], None),
             (["tests/test_latency_mode_gpu.py", "tests/test_configs_gpu.py"],

@@ -188,3 +188,71 @@ def test_spawn_ranks_environment(tmp_path, monkeypatch):
     seen = [open(tmp_path / ("r%d" % r)).read().split() for r in range(3)]
     assert [s[0] for s in seen] == ["0", "1", "2"] and [s[1] for s in seen] == ["0", "1", "2"]
     assert {s[2] for s in seen} == {"3"} and {s[3] for s in seen} == {"127.0.0.1"} and len({s[4] for s in seen}) == 1
+
+
+EIGHT_WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, %r)
+from video_stabilizer_amd import dist as D
+world, rank, local = D.env_world()
+d = D.init("gloo", rank, world)
+if os.environ.get("VS_TEST_FAIL_RANK", "") == str(rank):
+    os._exit(7)                                     # a rank that dies after the group is up: the launcher must end the job with ITS code
+mine = D.shard_clips(64, rank, world)               # BASELINE configs[3]: 64 clips, clip i -> rank i mod N
+D.barrier()
+t0 = time.perf_counter()
+time.sleep(0.02 * (1 + rank %% 3))
+D.barrier()
+dt = time.perf_counter() - t0
+secs, frames, aligned = D.aggregate(dt, 120 * len(mine), 119 * len(mine))
+per_rank = D.gather_seconds(dt)
+if rank == 0:
+    print(json.dumps({"clips_per_rank": [len(D.shard_clips(64, r, world)) for r in range(world)], "mine": mine, "secs": secs, "frames": frames,
+                      "aligned": aligned, "per_rank": per_rank}))
+d.destroy_process_group()
+'''
+
+
+def _launch_eight(tmp_path, fail_rank=None):
+    """eight ranks through bench.py's own launcher loop (spawn_ranks watches every child; the first failing rank ends the job)"""
+    import importlib.util
+    script = tmp_path / "e.py"
+    script.write_text(EIGHT_WORKER % ROOT)
+    driver = tmp_path / "drive.py"
+    driver.write_text(
+        "import sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "bench.__file__ = %r\n"                      # spawn_ranks starts `python <bench.__file__> argv`: point it at the stand-in worker
+        "sys.exit(bench.spawn_ranks(8, []))\n" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if fail_rank is not None:
+        env["VS_TEST_FAIL_RANK"] = str(fail_rank)
+    return subprocess.run([sys.executable, str(driver)], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_eight_ranks_meet_before_the_first_real_eight_gpu_run(tmp_path):
+    """The driver's 8-GPU run must not be the first time eight ranks meet.  The GPU box allows six GPU processes, so the eight-rank case
+    runs here on the CPU: the launcher loop of bench.py (spawn_ranks), the gloo group, the clip split of BASELINE configs[3]
+    (64 clips -> 8 per rank), barrier-bracketed timing, aggregate() and gather_seconds() with eight ranks, one JSON line from rank 0."""
+    import json
+    out = _launch_eight(tmp_path)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # (gloo's own banner is kept off stdout by bench.py itself: tests/test_bench_gpu.py)
+    j = json.loads(lines[0])
+    assert j["clips_per_rank"] == [8] * 8 and j["mine"] == list(range(0, 64, 8))
+    assert j["frames"] == 64 * 120 and j["aligned"] == 64 * 119
+    assert len(j["per_rank"]) == 8 and all(x > 0 for x in j["per_rank"]) and abs(max(j["per_rank"]) - j["secs"]) < 1e-12
+
+
+def test_a_failing_rank_ends_the_eight_rank_job_with_its_exit_code(tmp_path):
+    """rank 5 dies after the process group is up; ranks 0-4, 6, 7 are waiting in a barrier that will never complete: the launcher stops
+    them and the job's exit code is rank 5's -- within seconds, not after a collective's timeout"""
+    import time
+    t0 = time.perf_counter()
+    out = _launch_eight(tmp_path, fail_rank=5)
+    assert out.returncode == 7, (out.returncode, out.stderr[-1000:])
+    assert "rank 5 ended with exit code 7" in out.stderr
+    assert "{" not in out.stdout                                     # no half-finished report line
+    assert time.perf_counter() - t0 < 120

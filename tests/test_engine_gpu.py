@@ -207,6 +207,28 @@ def test_too_few_levels_is_an_error(gpu_vs):
         gpu.align_next(np.zeros((480, 640), np.uint8))
 
 
+def test_a_call_rejected_for_its_arguments_leaves_the_sequence_alone(gpu_vs, oracle):
+    """The reference resets its aligner only when a kernel stage fails (alignment.cpp:357-367).  A call this library REJECTS before touching
+    the handle (a stride below w * channels: VS_ERR_ARG) is not such a failure: the next frame is still aligned to the frame before the
+    rejected call, exactly as in an uninterrupted sequence."""
+    import ctypes as C
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(480, 270, 4, seed=73, channels=3)
+    gpu, cpu = gpu_vs.Aligner(device=0), oracle.Aligner()
+    want = [cpu.align_next(f) for f in frames]
+    got = [gpu.align_next(frames[0]), gpu.align_next(frames[1])]
+    t = gpu_vs.Transform()
+    r = gpu_vs.lib().vs_aligner_align_next(gpu.h, frames[2].ctypes.data_as(C.c_void_p), 480, 270, 480 * 3 - 1, gpu_vs.FMT_BGR8, gpu_vs.MEM_HOST,
+                                           C.byref(gpu.params), C.byref(t))
+    assert r == -1, r                                                    # VS_ERR_ARG
+    got += [gpu.align_next(frames[2]), gpu.align_next(frames[3])]
+    for i, ((ok_g, t_g), (ok_c, t_c)) in enumerate(zip(got, want)):
+        assert ok_g == ok_c, i
+        if ok_c:
+            assert _cmp_transform(t_g, t_c) < TOL, i
+    assert got[2][0]                                                     # frame 2 aligned to frame 1: the sequence was not restarted
+
+
 def test_10bit_bgr_alignment(gpu_vs, oracle):
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(480, 270, 4, seed=71, channels=3, bits=10)

@@ -391,7 +391,7 @@ def test_absurd_extents_and_inconsistent_arguments_are_refused_before_any_work(g
     bad = [
         warp(big, 4, 0, 4, 8, 0, 0, 0), warp(big, big, big, 1, 8, 0, 0, big), warp(70000, 2, 70000, 1, 8, 0, 0, 70000),
         warp(0, 4, 12, 3, 8, 0, 0, 12), warp(4, -1, 12, 3, 8, 0, 0, 12), warp(4, 4, 11, 3, 8, 0, 0, 12), warp(4, 4, 12, 3, 8, 0, 0, 11),
-        warp(4, 4, 12, 3, 12, 0, 0, 12), warp(4, 4, 12, 3, 8, 3, 0, 12), warp(4, 4, 12, 3, 8, 0, 2, 12), warp(4, 4, 20, 5, 8, 0, 0, 20),
+        warp(4, 4, 12, 3, 12, 0, 0, 12), warp(4, 4, 12, 3, 8, 99, 0, 12), warp(4, 4, 12, 3, 8, -1, 0, 12), warp(4, 4, 12, 3, 8, 0, 2, 12), warp(4, 4, 20, 5, 8, 0, 0, 20),
         warp(4, 4, 12, 3, 8, 0, 0, 12, src=None), warp(4, 4, 12, 3, 8, 0, 0, 12, dst=None),
         L.vs_bgr_image_warp_roi_batch(p, 48, 1, 4, 4, 12, 3, 8, C.byref(t), 0, 0, 255, 2, 2, 3, 3, p, 27, 9, gpu_vs.MEM_HOST, None),      # window leaves the frame
         L.vs_bgr_image_warp_roi_batch(p, 48, 1, 4, 4, 12, 3, 8, C.byref(t), 0, 0, 255, 0x7fffffff, 0, 2, 2, p, 12, 6, gpu_vs.MEM_HOST, None),

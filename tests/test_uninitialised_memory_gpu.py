@@ -63,6 +63,7 @@ def _run(byte, **more_env):
     env.pop("VS_TEST_POISON_ALLOC", None)
     if byte is not None:
         env["VS_TEST_POISON_ALLOC"] = str(byte)
+        env["VS_TEST_HOOKS"] = "1"
     env.update(more_env)
     out = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

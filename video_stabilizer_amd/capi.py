@@ -87,6 +87,7 @@ SIGNATURES = {
     "vs_debug_bounds_check": (_i32, []),
     "vs_debug_bounds_selftest": (_i32, []),
     "vs_device_count": (_i32, []),
+    "vs_shader_clock_probe": (_i32, [C.c_void_p, C.POINTER(C.c_double)]),
     "vs_stream_retire": (_i32, [_vp]),
     "vs_format_bits": (_i32, [_i32]),
     "vs_format_max_value": (_i32, [_i32]),
@@ -194,6 +195,13 @@ def _c(a, dtype):
 
 def device_count():
     return lib().vs_device_count()
+
+
+def shader_clock_probe(stream=None):
+    """shader clock in MHz as a VALU-bound probe kernel on `stream` sees it (s_memtime / s_memrealtime)"""
+    mhz = C.c_double(0.0)
+    _check(lib().vs_shader_clock_probe(C.c_void_p(stream) if stream else None, C.byref(mhz)))
+    return mhz.value
 
 
 def debug_bounds_check():

@@ -32,8 +32,14 @@ bool device_ready() {
 // g_alloc_count counts the library's allocations since the last vs_test_fail_alloc call; the one that brings it to
 // g_alloc_fail_at fails with hipErrorOutOfMemory (once: the count moves on).  VS_TEST_FAIL_ALLOC=k arms it from the
 // environment for programs that cannot call the hook.
+// The ENVIRONMENT-driven hooks (VS_TEST_FAIL_ALLOC, VS_TEST_POISON_*) are honoured only when VS_TEST_HOOKS=1 is set as well: a stray
+// variable in a production environment must not make a real allocation fail or cost every allocation a memset.
+static const char* test_env(const char* name) {
+    static const bool on = []() { const char* h = getenv("VS_TEST_HOOKS"); return h && atoi(h) == 1; }();
+    return on ? getenv(name) : nullptr;
+}
 std::atomic<long long> g_alloc_count{0};
-std::atomic<long long> g_alloc_fail_at{[]() { const char* e = getenv("VS_TEST_FAIL_ALLOC"); return e ? atoll(e) : 0LL; }()};
+std::atomic<long long> g_alloc_fail_at{[]() { const char* e = test_env("VS_TEST_FAIL_ALLOC"); return e ? atoll(e) : 0LL; }()};
 static bool alloc_injected_failure() {
     const long long k = ++g_alloc_count;
     return k == g_alloc_fail_at.load(std::memory_order_relaxed);
@@ -45,13 +51,13 @@ hipError_t dev_alloc(void** p, size_t bytes) {
     if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); }      // (the sticky error belongs to this call, which reports it)
     // test hook (VS_TEST_POISON_ALLOC=<byte>): every fresh device allocation starts filled with that byte, so that a result which depends on
     // memory the library never wrote changes with the byte (tests/test_uninitialised_memory_gpu.py)
-    static const int poison = []() { const char* v = getenv("VS_TEST_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
-    static const int only = []() { const char* v = getenv("VS_TEST_POISON_ONLY"); return v ? atoi(v) : 0; }();      // (0: every allocation; k: the k-th only)
+    static const int poison = []() { const char* v = test_env("VS_TEST_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
+    static const int only = []() { const char* v = test_env("VS_TEST_POISON_ONLY"); return v ? atoi(v) : 0; }();      // (0: every allocation; k: the k-th only)
     static std::atomic<int> nth{0};
     const int k = ++nth;
     if (e == hipSuccess && poison >= 0 && bytes) {
-        static const long long r_off = []() { const char* v = getenv("VS_TEST_POISON_OFF"); return v ? atoll(v) : 0LL; }();
-        static const long long r_len = []() { const char* v = getenv("VS_TEST_POISON_LEN"); return v ? atoll(v) : -1LL; }();
+        static const long long r_off = []() { const char* v = test_env("VS_TEST_POISON_OFF"); return v ? atoll(v) : 0LL; }();
+        static const long long r_len = []() { const char* v = test_env("VS_TEST_POISON_LEN"); return v ? atoll(v) : -1LL; }();
         if (only == k && r_len >= 0) {                     // (debugging aid: only bytes [off, off + len) of the k-th allocation get the byte)
             e = hipMemset(*p, 0, bytes);
             if (e == hipSuccess && r_off < (long long)bytes) e = hipMemset((char*)*p + r_off, poison, (size_t)std::min<long long>(r_len, (long long)bytes - r_off));
@@ -59,6 +65,7 @@ hipError_t dev_alloc(void** p, size_t bytes) {
         e = hipMemset(*p, (only == 0 || only == k) ? poison : 0, bytes);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (only == k) std::fprintf(stderr, "[poison] allocation %d: %zu bytes\n", k, bytes);
+        if (e != hipSuccess) { (void)hipFree(*p); *p = nullptr; (void)hipGetLastError(); }     // the contract: *p is nullptr on failure
     }
     return e;
 }
@@ -332,6 +339,45 @@ int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stre
     VS_ARG(src_dev && dst_dev && bytes >= 12);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     VS_HIP(vsk::calib_copy12(src_dev, dst_dev, bytes, (hipStream_t)stream));
+    return VS_OK;
+}
+
+// the shader clock from inside a kernel: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+__global__ __launch_bounds__(256) void vs_k_clock_probe(unsigned long long* out, float seed, int iters) {
+    float a0 = seed + (float)threadIdx.x, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f;
+    const float m = 0.999999f, c = 1.0e-7f;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c); a2 = __builtin_fmaf(a2, m, c); a3 = __builtin_fmaf(a3, m, c);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (a0 + a1 + a2 + a3 == 12345.678f) out[2] = 1;                  // keeps the chains alive
+}
+
+int vs_shader_clock_probe(void* stream, double* shader_mhz) {
+    VS_ARG(shader_mhz);
+    if (!vsi::device_ready()) return VS_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* d = nullptr;
+    VS_HIP(vsi::dev_alloc((void**)&d, 4 * sizeof(unsigned long long)));
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(vs_k_clock_probe, dim3(2048), dim3(256), 0, s, d, 1.0f, 3000);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    VS_HIP(e);
+    *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return VS_OK;
 }
 

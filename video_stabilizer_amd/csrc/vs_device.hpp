@@ -70,7 +70,10 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 // had turned into a row index of -1 -- a diverged Gauss-Newton run (|T| ~ 1e14) read the 344 bytes in FRONT of its image (found by the random
 // sweeps + allocation poisoning, round 4).  An index 4 or more outside the image puts every tap of a 4- or 5-tap window on the same border
 // pixel (or outside, for the constant border), so the index is pulled into [-8, n + 8) first: the same taps for every position, no overflow.
-__device__ __forceinline__ int sample_index(float fl, int n) { return clampi((int)fl, -8, n + 7); }
+// The clamp happens in the float domain, BEFORE the conversion (a float -> int conversion of a value outside the int range, of an infinity or of
+// a NaN is undefined in C++ whatever the hardware instruction does): fl is a floor() result, i.e. an integer, and n + 7 < 2^24 is exact in fp32, so
+// for every finite fl this is clampi(int(fl), -8, n + 7); NaN -> 0 as in the oracle's sat_int().
+__device__ __forceinline__ int sample_index(float fl, int n) { return (fl == fl) ? (int)fminf(fmaxf(fl, -8.0f), (float)(n + 7)) : 0; }
 
 // generators.cpp:31-47: 6th-order even polynomial, Horner in x*x, zero outside |x| < 2.
 __device__ __forceinline__ float lanczos2(float x) {

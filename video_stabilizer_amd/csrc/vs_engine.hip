@@ -1190,6 +1190,7 @@ static void align_close_clips(vs_aligner* a) {
 // (alignment.cpp:357-367: LastWidth = -1, so the next AlignNextFrame re-initialises).  Device buffers stay as they are.
 static void align_failed(vs_aligner* a) {
     a->seq = 0;
+    (void)hipStreamSynchronize(a->stream);                 // nothing of the failed call is still running when its events go back to the pool
     a->ck.open = false;
     for (vs_aligner::Span& sp : a->spans) { a->event_pool.push_back(sp.a); a->event_pool.push_back(sp.b); }
     a->spans.clear();
@@ -1201,7 +1202,9 @@ static int align_start(vs_aligner* a, const void* frames, size_t frame_stride, i
     a->started_result = 0;
     if (clip_frames > 0) { a->seq = 0; a->clip_len = clip_frames; a->started_clips = true; }
     const int r = align_start_impl(a, frames, frame_stride, n, w, h, stride, format, mem, params, out, status, async);
-    if (r < 0) { a->started = false; align_close_clips(a); align_failed(a); }
+    // a call REJECTED for its arguments (VS_ERR_ARG: every such test precedes the first touch of the handle's state) leaves the running
+    // sequence alone -- the reference resets only when a kernel stage fails (alignment.cpp:357-367); any later error ends it
+    if (r < 0) { a->started = false; align_close_clips(a); if (r != VS_ERR_ARG) align_failed(a); }
     return r;
 }
 static int align_finish(vs_aligner* a) {

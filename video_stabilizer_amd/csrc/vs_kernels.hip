@@ -851,9 +851,11 @@ __global__ __launch_bounds__(256) void vs_k_image_warp(const uint8_t* __restrict
     if (x >= ow) return;
     float Wx = (1.0f + A) * (float)x - B * (float)y + TX;
     float Wy = B * (float)x + (1.0f + A) * (float)y + TY;
-    int fx = (int)floorf(Wx), fy = (int)floorf(Wy);
-    float wx = Wx - (float)fx, wy = Wy - (float)fy;           // generators.cpp:150-153: the fraction comes from the converted index
-    fx = clampi(fx, -8, w + 7); fy = clampi(fy, -8, h + 7);   // (sample_index: the taps below cannot overflow)
+    // generators.cpp:150-153 takes the fraction from the converted index, W - float(int(floor(W))): the same value as W - floor(W) for every
+    // position inside the int range, and undefined outside it -- every sampler here and in the oracle uses W - floor(W), defined everywhere
+    const float flx = floorf(Wx), fly = floorf(Wy);
+    float wx = Wx - flx, wy = Wy - fly;
+    int fx = sample_index(flx, w), fy = sample_index(fly, h);  // (the taps below cannot overflow)
     int x0 = clampi(fx, 0, w - 1), x1 = clampi(fx + 1, 0, w - 1);
     const uint8_t* r0 = in + (size_t)clampi(fy, 0, h - 1) * stride;
     const uint8_t* r1 = in + (size_t)clampi(fy + 1, 0, h - 1) * stride;

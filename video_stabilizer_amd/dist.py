@@ -36,7 +36,7 @@ def report_device():
     return _REPORT_DEVICE
 
 
-def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, _probe_backend=None, _fail_probe_on_rank=None):
+def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=120, _probe_backend=None, _fail_probe_on_rank=None):
     """"if RCCL init fails on the box, fall back to host-side aggregation and say so" -- decided by ALL ranks
     together, never by each rank for itself.
 
@@ -46,8 +46,16 @@ def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, 
        and the first collective are where a broken RCCL setup shows.  Whatever happens is caught, per rank.
     3. The ranks all-reduce (MIN) their "RCCL ok" flags over gloo.  All ones: the report collectives (aggregate, gather_seconds,
        barrier) run over RCCL on every rank.  Anything else: over gloo on every rank, and every rank gets every failing rank's
-       reason for the report line.  A rank whose probe hangs is cut off by the probe's own timeout; the others wait for it at the
-       flag all-reduce, so the outcome is still common to all.
+       reason for the report line.
+    A probe that HANGS (a peer never joins the communicator) must end in a Python exception on the waiting ranks, not in the NCCL
+    watchdog's default action, which is to abort the process: the sub-group is therefore created with TORCH_NCCL_BLOCKING_WAIT=1 and
+    TORCH_NCCL_ASYNC_ERROR_HANDLING=0 in the environment (set here, before the first NCCL group exists; a launcher's own setting
+    wins), and the probe is an async all-reduce waited for with an explicit timeout (work.wait(timeout)), which raises in that mode.
+    The waiting ranks then reach the flag all-reduce with "not ok" and the outcome is common to all.  What has been EXERCISED: RCCL up
+    on one rank; both ranks of a two-rank job on one GPU refused by RCCL (symmetric failure -> gloo on both); a failure injected on one
+    of three gloo ranks standing in for the probe (tests/test_dist_cpu.py).  An asymmetric failure of real RCCL across GPUs has not
+    been available to test: if the flag all-reduce itself cannot complete (a rank died), the job ends with a non-zero exit code and
+    the message below rather than a fallback.
     -> (dist, backend in use: "nccl" | "gloo", None or the reason).  (_probe_backend / _fail_probe_on_rank: test hooks.)"""
     global _REPORT_GROUP, _REPORT_DEVICE
     import datetime
@@ -56,6 +64,9 @@ def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, 
     _REPORT_GROUP, _REPORT_DEVICE = None, None
     if backend != "nccl":
         return init(backend, rank, world, device_id), backend, None
+    # a timed-out wait raises (blocking-wait mode) instead of the watchdog aborting the process; read when the first NCCL group is made
+    os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     init("gloo", rank, world)
     why, group = None, None
     try:
@@ -63,7 +74,9 @@ def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, 
         if _fail_probe_on_rank is not None and rank == _fail_probe_on_rank:
             raise RuntimeError("probe failure injected on rank %d" % rank)
         t = torch.ones(1, dtype=torch.int64, device=device_id if _probe_backend is None else None)
-        dist.all_reduce(t, group=group)
+        work = dist.all_reduce(t, group=group, async_op=True)
+        if not work.wait(datetime.timedelta(seconds=probe_seconds)):
+            raise RuntimeError("probe all-reduce did not complete within %d s" % probe_seconds)
         if t.is_cuda:
             torch.cuda.synchronize()
         if int(t.item()) != world:
@@ -72,7 +85,11 @@ def init_with_fallback(backend, rank, world, device_id=None, probe_seconds=300, 
         why = "rank %d: %s: %s" % (rank, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
     # ---- agreement over the host-side channel ----
     flag = torch.tensor([0 if why else 1], dtype=torch.int64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    try:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    except Exception as e:          # noqa: BLE001 -- a rank is gone: no common decision can be reached
+        raise SystemExit("dist.init_with_fallback: rank %d could not agree with the other ranks over gloo (%s: %s); this rank's own RCCL probe: %s"
+                         % (rank, type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "", why or "ok"))
     if int(flag.item()) == 1:
         _REPORT_GROUP, _REPORT_DEVICE = group, (device_id if _probe_backend is None else None)
         return dist, "nccl", None
