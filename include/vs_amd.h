@@ -55,8 +55,15 @@ int vs_format_max_value(int format);
  * over the product of the two 1-D weight sums, one correctly rounded reciprocal for all channels (equal to generators.cpp:687-697
  * in real arithmetic; a reassociation inside the reference's own non-strict_float slack).  Bit-identical to the CPU restatement's
  * VSO_WARP_LANCZOS2_SEPARABLE; against the UN-contracted order: at most 1 LSB, >= 99.99 % of the samples identical (8- and 10-bit;
- * SURVEY 8(d)'s integer gate, tests/test_warp_gate_gpu.py). */
-enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1, VS_WARP_LANCZOS2_FAST = 2, VS_WARP_LANCZOS2_SEP = 3 };
+ * SURVEY 8(d)'s integer gate, tests/test_warp_gate_gpu.py).
+ * VS_WARP_BILINEAR_CV: cv::warpAffine(INTER_LINEAR) as the reference's stabilizer calls it (stabilizer.cpp:97-99 ->
+ * imgproc.cpp:446-484): OpenCV 4.x's classic FIXED-POINT path -- the matrix inverted in double, source coordinates in 1/32 pixel
+ * (AB_BITS 10, INTER_BITS 5), 15-bit integer weights, (sum + 2^14) >> 15 for 8-bit samples (float weights and cvRound for 16-bit
+ * containers).  Integer work: bit-identical to the CPU restatement's VSO_WARP_BILINEAR_CV, no tolerance.  "Parity unpinned
+ * (OpenCV version)": the reference installs libopencv-dev unpinned and OpenCV is not in this image; the restatement follows the
+ * published 4.5 / 4.6 source.  IN THIS MODE `t` IS THE TRANSFORM HANDED TO warpBySimilarityTransform -- the FORWARD map, which
+ * cv::warpAffine inverts itself (every other mode takes the sampling map); integer output only (no _f32 form). */
+enum { VS_WARP_LANCZOS2 = 0, VS_WARP_BILINEAR = 1, VS_WARP_LANCZOS2_FAST = 2, VS_WARP_LANCZOS2_SEP = 3, VS_WARP_BILINEAR_CV = 4 };
 enum { VS_BORDER_CLAMP = 0, VS_BORDER_CONSTANT = 1 };
 /* how the per-level "keep the best 80 %" subset is chosen (alignment.cpp:460-486) */
 enum {
@@ -132,6 +139,10 @@ int vs_tile_size(int w, int h);
  * sparse: imgproc.cpp:69-75 / 98-103 (centre w/2,h/2).  warp: imgproc.cpp:125-131 (centre (w-1)/2,(h-1)/2) */
 void vs_ul_params_sparse(const vs_transform* t, int w, int h, float out4[4]);
 void vs_ul_params_warp(const vs_transform* t, int w, int h, float out4[4]);
+/* VS_WARP_BILINEAR_CV: the 2x3 matrix of warpBySimilarityTransform(t) for a w x h frame (imgproc.cpp:457-466), inverted the way
+ * cv::warpAffine inverts a matrix given without WARP_INVERSE_MAP (double precision, OpenCV's operation order): row-major
+ * {M0, M1, M2; M3, M4, M5}, the map from an output pixel to its source position. */
+void vs_cv_inverse_matrix(const vs_transform* t, int w, int h, double out6[6]);
 /* L1SmootherCenter, smoother.hpp:10-30 / smoother.cpp:67-127 */
 typedef struct vs_smoother vs_smoother;
 vs_smoother* vs_smoother_create(int lag_behind, int lag_ahead, double lambda);

@@ -51,7 +51,7 @@ class AlignDebug(C.Structure):
                 ("phase_dx", C.c_double), ("phase_dy", C.c_double), ("phase_response", C.c_double)]
 
 
-WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED, WARP_LANCZOS2_SEPARABLE = 0, 1, 2, 3
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_CONTRACTED, WARP_LANCZOS2_SEPARABLE, WARP_BILINEAR_CV = 0, 1, 2, 3, 4
 SELECT_STL, SELECT_STABLE = 0, 1
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1
@@ -87,6 +87,7 @@ def lib():
         "vso_image_warp": (None, [vp, i32, i32, i32, f32, f32, f32, f32, vp, i32, i32]),
         "vso_ul_params_sparse": (None, [TP, i32, i32, vp]),
         "vso_ul_params_warp": (None, [TP, i32, i32, vp]),
+        "vso_cv_inverse_matrix": (None, [TP, i32, i32, vp]),
         "vso_bgr_image_warp": (None, [vp, i32, i32, i32, i32, i32, TP, i32, i32, i32, vp, i32]),
         "vso_bgr_image_warp_f32": (None, [vp, i32, i32, i32, i32, i32, TP, i32, i32, vp, i32]),
         "vso_bgr_to_gray": (None, [vp, i32, i32, i32, i32, i32, vp, i32]),
@@ -231,6 +232,13 @@ def ul_params_sparse(t, w, h):
 def ul_params_warp(t, w, h):
     out = np.empty(4, np.float32)
     lib().vso_ul_params_warp(C.byref(t), w, h, _p(out))
+    return out
+
+
+def cv_inverse_matrix(t, w, h):
+    """VSO_WARP_BILINEAR_CV's output -> source matrix for the FORWARD transform t (imgproc.cpp:457-466 + cv::warpAffine's inversion)"""
+    out = np.empty(6, np.float64)
+    lib().vso_cv_inverse_matrix(C.byref(t), w, h, _p(out))
     return out
 
 

@@ -210,6 +210,92 @@ inline float bilinear_sample(const ImageRef<T>& img, float Wx, float Wy, int c) 
     return lerpf(top, bottom, wy);
 }
 
+/* ---- VSO_WARP_BILINEAR_CV: cv::warpAffine(INTER_LINEAR) as the reference's stabilizer calls it ------------------------------------
+ * imgproc.cpp:446-484 warpBySimilarityTransform hands cv::warpAffine the FORWARD matrix of the transform WITHOUT WARP_INVERSE_MAP, INTER_LINEAR,
+ * BORDER_CONSTANT, value 0.  OpenCV is not in this image and the reference does not pin its version (README.md:22: apt libopencv-dev), so what
+ * follows restates the PUBLISHED algorithm of OpenCV 4.x's classic path (modules/imgproc/src/imgwarp.cpp: cv::warpAffine, WarpAffineInvoker,
+ * remapBilinear; 4.5.4 / 4.6.0 are what Ubuntu 22.04 / 24.04 ship) -- "parity unpinned (OpenCV version)" like every other OpenCV stand-in:
+ *   1. the 2x3 matrix is inverted in double precision, in OpenCV's own operation order (D = M0 M4 - M1 M3, ...);
+ *   2. source coordinates are FIXED POINT: AB_BITS = 10, adelta[x] = cvRound(M0 x 1024), bdelta[x] = cvRound(M3 x 1024), per row
+ *      X0 = cvRound((M1 y + M2) 1024) + 16, Y0 likewise (round_delta = 1024 / 32 / 2), X = (X0 + adelta[x]) >> 5: 1/32-pixel positions,
+ *      sx = saturate_cast<short>(X >> 5), fx = X & 31 (INTER_BITS = 5);
+ *   3. 8-bit samples: four integer weights (32 - fx)(32 - fy) 32, ... (BilinearTab_i: the float products of 1/32 fractions times 2^15 are
+ *      exact integers, they sum to 2^15 without the table's fix-up), result = (sum w v + 2^14) >> 15 (FixedPtCast<int, uchar, 15>);
+ *      16-bit containers: float weights w = a b / 1024 (exact), result = saturate_cast<ushort>(v00 w00 + v01 w01 + v10 w10 + v11 w11),
+ *      the products and sums in float, left to right, cvRound (remapBilinear<Cast<float, ushort>, float>; exact for samples below 2^14);
+ *   4. taps outside the frame read the border value 0 (BORDER_CONSTANT) or the nearest edge pixel (VSO_BORDER_CLAMP = BORDER_REPLICATE).
+ * The transform is the one handed to warpBySimilarityTransform -- the FORWARD map; every other mode of this file takes the sampling map.
+ * cvRound is round-half-to-even (lrint under the default rounding mode); a coordinate outside the int range saturates here (x86's cvtsd2si
+ * returns INT_MIN there -- no frame of any size gets near it).  The integer stages are exact: the product is held to this bit for bit. */
+inline int cv_round_sat(double v) {
+    if (!(v == v)) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return -2147483647 - 1;
+    return (int)std::nearbyint(v);
+}
+/* imgproc.cpp:457-466 + cv::warpAffine's inversion; Minv maps an output pixel to its source position */
+void cv_inverse_matrix(const vso_transform* t, int w, int h, double M[6]) {
+    double cx = (w - 1) * 0.5, cy = (h - 1) * 0.5;
+    double tx_ul = t->TX - t->A * cx + t->B * cy;
+    double ty_ul = t->TY - t->B * cx - t->A * cy;
+    M[0] = 1.0 + t->A; M[1] = -t->B; M[2] = tx_ul;
+    M[3] = t->B;       M[4] = 1.0 + t->A; M[5] = ty_ul;
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+template <typename T>
+void cv_warp_impl(const T* src, int w, int h, int src_stride, int channels, const vso_transform* t, int border, int max_value,
+                  T* dst, int dst_stride) {
+    double M[6];
+    cv_inverse_matrix(t, w, h, M);
+    const int AB_BITS = 10, INTER_BITS = 5, AB_SCALE = 1 << AB_BITS, TAB = 1 << INTER_BITS, round_delta = AB_SCALE / TAB / 2;
+    std::vector<int> adelta((size_t)w), bdelta((size_t)w);
+    for (int x = 0; x < w; x++) {
+        adelta[(size_t)x] = cv_round_sat(M[0] * x * AB_SCALE);
+        bdelta[(size_t)x] = cv_round_sat(M[3] * x * AB_SCALE);
+    }
+    auto tap = [&](int xx, int yy, int c) -> int {
+        if (border == VSO_BORDER_CONSTANT) {
+            if (xx < 0 || yy < 0 || xx >= w || yy >= h) return 0;
+        } else { xx = clampi(xx, 0, w - 1); yy = clampi(yy, 0, h - 1); }
+        return (int)src[(size_t)yy * src_stride + (size_t)xx * channels + c];
+    };
+    vso_parallel_rows(h, 8, [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; y++) {
+        const int X0 = (int)((unsigned)cv_round_sat((M[1] * y + M[2]) * AB_SCALE) + (unsigned)round_delta);
+        const int Y0 = (int)((unsigned)cv_round_sat((M[4] * y + M[5]) * AB_SCALE) + (unsigned)round_delta);
+        for (int x = 0; x < w; x++) {
+            const int X = (int)((unsigned)X0 + (unsigned)adelta[(size_t)x]) >> (AB_BITS - INTER_BITS);
+            const int Y = (int)((unsigned)Y0 + (unsigned)bdelta[(size_t)x]) >> (AB_BITS - INTER_BITS);
+            const int sx = clampi(X >> INTER_BITS, -32768, 32767), sy = clampi(Y >> INTER_BITS, -32768, 32767);   /* saturate_cast<short> */
+            const int fx = X & (TAB - 1), fy = Y & (TAB - 1);
+            const int a0 = TAB - fx, a1 = fx, b0 = TAB - fy, b1 = fy;
+            for (int c = 0; c < channels; c++) {
+                const int v00 = tap(sx, sy, c), v01 = tap(sx + 1, sy, c), v10 = tap(sx, sy + 1, c), v11 = tap(sx + 1, sy + 1, c);
+                int r;
+                if (sizeof(T) == 1) {
+                    const int acc = v00 * (a0 * b0 * 32) + v01 * (a1 * b0 * 32) + v10 * (a0 * b1 * 32) + v11 * (a1 * b1 * 32);
+                    r = (acc + (1 << 14)) >> 15;
+                } else {
+                    const float w00 = (float)(a0 * b0) * (1.0f / 1024.0f), w01 = (float)(a1 * b0) * (1.0f / 1024.0f);
+                    const float w10 = (float)(a0 * b1) * (1.0f / 1024.0f), w11 = (float)(a1 * b1) * (1.0f / 1024.0f);
+                    const float sum = (float)v00 * w00 + (float)v01 * w01 + (float)v10 * w10 + (float)v11 * w11;
+                    r = (int)std::nearbyint(sum);
+                }
+                r = r < 0 ? 0 : (r > max_value ? max_value : r);
+                dst[(size_t)y * dst_stride + (size_t)x * channels + c] = (T)r;
+            }
+        }
+    }
+    });
+}
+
 template <typename T>
 void bgr_warp_impl(const T* src, int w, int h, int src_stride, int channels,
                    const vso_transform* t, int mode, int border, int max_value,
@@ -468,8 +554,15 @@ void vso_ul_params_warp(const vso_transform* t, int w, int h, float out4[4]) {
     out4[0] = (float)t->A; out4[1] = (float)t->B; out4[2] = (float)tx_ul; out4[3] = (float)ty_ul;
 }
 
+void vso_cv_inverse_matrix(const vso_transform* t, int w, int h, double M[6]) { cv_inverse_matrix(t, w, h, M); }
+
 void vso_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits, const vso_transform* t,
                         int mode, int border, int max_value, void* dst, int dst_stride) {
+    if (mode == VSO_WARP_BILINEAR_CV) {                     /* t is the FORWARD transform (see cv_warp_impl) */
+        if (bits == 8) cv_warp_impl<uint8_t>((const uint8_t*)src, w, h, src_stride, channels, t, border, max_value, (uint8_t*)dst, dst_stride);
+        else cv_warp_impl<uint16_t>((const uint16_t*)src, w, h, src_stride, channels, t, border, max_value, (uint16_t*)dst, dst_stride);
+        return;
+    }
     if (bits == 8)
         bgr_warp_impl<uint8_t>((const uint8_t*)src, w, h, src_stride, channels, t, mode, border, max_value,
                                (uint8_t*)dst, nullptr, dst_stride);
@@ -1070,8 +1163,9 @@ int vso_stabilizer_process(vso_stabilizer* s, const void* frame, int w, int h, i
             vso_transform correction = vso_transform_inverse(&newAccum);
             vso_transform sampling = vso_transform_inverse(&correction);
             std::vector<uint8_t> warped((size_t)w * h * 3 * esz);
-            vso_bgr_image_warp(frameToStabilize.data(), w, h, w * 3, 3, bits, &sampling, s->params.warp_mode,
-                               s->params.warp_border, (1 << depth) - 1, warped.data(), w * 3);
+            /* (VSO_WARP_BILINEAR_CV restates cv::warpAffine itself, inversion included: it takes the correction as the reference hands it over) */
+            vso_bgr_image_warp(frameToStabilize.data(), w, h, w * 3, 3, bits, s->params.warp_mode == VSO_WARP_BILINEAR_CV ? &correction : &sampling,
+                               s->params.warp_mode, s->params.warp_border, (1 << depth) - 1, warped.data(), w * 3);
             int c = s->params.crop_pixels > 0 ? s->params.crop_pixels : 0;
             int ow = w - 2 * c, oh = h - 2 * c;
             for (int y = 0; y < oh; y++)

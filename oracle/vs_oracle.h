@@ -59,7 +59,8 @@ typedef struct vso_stabilizer_params {
 
 /* VSO_WARP_LANCZOS2_CONTRACTED: the Lanczos2 sampler with the multiply-adds fused where the reference's own target
  * (CMakeLists.txt:151 "fma", no strict_float) lets LLVM fuse them -- the twin of the product's VS_WARP_LANCZOS2_FAST */
-enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1, VSO_WARP_LANCZOS2_CONTRACTED = 2, VSO_WARP_LANCZOS2_SEPARABLE = 3 };
+enum { VSO_WARP_LANCZOS2 = 0, VSO_WARP_BILINEAR = 1, VSO_WARP_LANCZOS2_CONTRACTED = 2, VSO_WARP_LANCZOS2_SEPARABLE = 3,
+       VSO_WARP_BILINEAR_CV = 4 /* cv::warpAffine(INTER_LINEAR) fixed point; takes the FORWARD transform (vs_oracle.cpp cv_warp_impl) */ };
 enum { VSO_BORDER_CLAMP = 0, VSO_BORDER_CONSTANT = 1 };
 enum { VSO_FMT_GRAY8 = 0, VSO_FMT_BGR8 = 1, VSO_FMT_BGR10 = 2, VSO_FMT_BGR12 = 3, VSO_FMT_BGR16_FULL = 4 };
 /* worker threads for the row-parallel loops of the image-sized stages (CPU-baseline timing only; results do not depend on it) */
@@ -71,6 +72,7 @@ void vso_aligner_params_default(vso_aligner_params* p);
 void vso_stabilizer_params_default(vso_stabilizer_params* p);
 
 /* ---- kernels (generators.cpp) -------------------------------------------------------- */
+void vso_cv_inverse_matrix(const vso_transform* t, int w, int h, double M[6]);   /* imgproc.cpp:457-466 + cv::warpAffine's inversion */
 float vso_lanczos2(float x);                                                /* generators.cpp:31-47 */
 void vso_pyr_down(const uint8_t* in, int w, int h, int in_stride,
                   uint8_t* out, int ow, int oh, int out_stride);           /* :56-92 */

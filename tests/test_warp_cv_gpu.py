@@ -1,0 +1,128 @@
+"""VS_WARP_BILINEAR_CV = cv::warpAffine(INTER_LINEAR) as the reference's stabilizer calls it (stabilizer.cpp:97-99 -> imgproc.cpp:446-484),
+OpenCV 4.x's fixed-point path, against its CPU twin (oracle/vs_oracle.cpp cv_warp_impl) -- integer work: np.array_equal everywhere, no
+tolerance.  The twin itself is held against an independent numpy coding of the same published algorithm in
+tests/test_bilinear_vs_opencv_fixed_point.py; both are the builder's reading of OpenCV ("parity unpinned (OpenCV version)").
+In this mode the transform argument is the FORWARD map handed to warpBySimilarityTransform (cv::warpAffine inverts it itself)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TRANSFORMS = [(0.004, -0.003, 2.25, -1.5), (-0.01, 0.02, -7.75, 3.125), (0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 3.0, -2.0), (0.0007, 0.0019, 0.5, 0.5),
+              (0.0, 0.0, 1.0 / 64, -1.0 / 64), (-0.002, 0.0015, -6.4, 3.3)]
+
+
+@pytest.mark.parametrize("border", [0, 1])
+def test_cv_mode_8bit_bgr_equals_the_twin(gpu_vs, oracle, border):
+    """the tuned kernel (byte tile in LDS, v_dot2_u32_u16 taps): whole frames, a batch, both borders"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(640, 360, len(TRANSFORMS), seed=5, channels=3)
+    ts = [gpu_vs.Transform.of(*tr) for tr in TRANSFORMS]
+    got = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_BILINEAR_CV, border=border)
+    for i, tr in enumerate(TRANSFORMS):
+        want = oracle.bgr_image_warp(frames[i], oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border)
+        assert np.array_equal(got[i], want), (tr, border, int(np.abs(got[i].astype(int) - want.astype(int)).max()))
+        one = gpu_vs.bgr_image_warp(frames[i], ts[i], mode=gpu_vs.WARP_BILINEAR_CV, border=border)
+        assert np.array_equal(one, want), (tr, border)
+
+
+def test_cv_mode_is_the_forward_map_cv_warp_affine_inverts(gpu_vs, oracle):
+    """warpBySimilarityTransform(src, T) moves content BY T (cv::warpAffine without WARP_INVERSE_MAP): a pure translation by (+5, +7)
+    puts source pixel (x, y) at (x + 5, y + 7)"""
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    out = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(0.0, 0.0, 5.0, 7.0), mode=gpu_vs.WARP_BILINEAR_CV, border=gpu_vs.BORDER_CONSTANT)
+    assert np.array_equal(out[7:, 5:], src[:-7, :-5]) and not out[:7].any() and not out[:, :5].any()
+
+
+def test_cv_mode_ragged_sizes_unaligned_rows_windows(gpu_vs, oracle):
+    rng = np.random.default_rng(21)
+    for (h, w) in [(17, 65), (33, 130), (32, 64), (5, 7), (70, 201), (1, 1), (40, 63)]:
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for tr in TRANSFORMS[:2] + [(0.0, 0.0, 0.25, -0.75)]:
+            for border in (0, 1):
+                got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=border)
+                want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border)
+                assert np.array_equal(got, want), (h, w, tr, border)
+    # an output window equals the same rows / columns cut out of the whole warp (the stabilizer's crop)
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(480, 270, 2, seed=9, channels=3)
+    ts = [gpu_vs.Transform.of(*TRANSFORMS[0]), gpu_vs.Transform.of(*TRANSFORMS[6])]
+    full = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_BILINEAR_CV, border=1)
+    for roi in [(32, 32, 416, 206), (1, 3, 77, 40), (100, 50, 64, 32)]:
+        win = gpu_vs.bgr_image_warp_roi_batch(frames, ts, roi, mode=gpu_vs.WARP_BILINEAR_CV, border=1)
+        x, y, rw, rh = roi
+        assert np.array_equal(win, full[:, y:y + rh, x:x + rw]), roi
+
+
+def test_cv_mode_large_rotation_and_zoom_take_the_global_path(gpu_vs, oracle):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(320, 240, 1, seed=9, channels=3)
+    for tr in [(-0.2, 0.6, 4.0, -3.0), (1.5, 0.0, 0.0, 0.0), (-0.7, 0.1, 30.0, 10.0), (0.0, 0.0, 40000.0, 0.0), (0.0, 0.0, -1e7, 3e6)]:
+        for border in (0, 1):
+            got = gpu_vs.bgr_image_warp(frames[0], gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=border)
+            want = oracle.bgr_image_warp(frames[0], oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border)
+            assert np.array_equal(got, want), (tr, border)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 4])
+def test_cv_mode_other_channel_counts(gpu_vs, oracle, channels):
+    rng = np.random.default_rng(channels)
+    src = rng.integers(0, 256, (120, 200, channels), dtype=np.uint8)
+    for tr in TRANSFORMS[:3]:
+        got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=1)
+        assert np.array_equal(got, oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=1)), (channels, tr)
+
+
+@pytest.mark.parametrize("bits,hi", [(10, 1023), (16, 65535)])
+def test_cv_mode_16bit_containers(gpu_vs, oracle, bits, hi):
+    """remapBilinear<Cast<float, ushort>>: float weights (exact), float products and sums left to right, cvRound"""
+    from video_stabilizer_amd import synth
+    f10, _ = synth.make_clip(320, 200, 1, seed=11, channels=3, bits=10)
+    src = f10[0] if bits == 10 else (f10[0].astype(np.uint32) * 64 + 37).astype(np.uint16)
+    for tr in TRANSFORMS[:4]:
+        for border in (0, 1):
+            got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=border, max_value=hi)
+            want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border, max_value=hi)
+            assert np.array_equal(got, want), (bits, tr, border)
+
+
+def test_cv_mode_4k_frame(gpu_vs, oracle):
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(3840, 2160, 1, seed=2, channels=3)
+    t = (0.0012, -0.0017, 3.3, -2.7)
+    oracle.set_threads(8)
+    try:
+        want = oracle.bgr_image_warp(frames[0], oracle.Transform.of(*t), oracle.WARP_BILINEAR_CV, border=1)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(gpu_vs.bgr_image_warp(frames[0], gpu_vs.Transform.of(*t), mode=gpu_vs.WARP_BILINEAR_CV, border=1), want)
+
+
+def test_cv_mode_has_no_float_output_and_the_inverse_matrix_is_opencvs(gpu_vs, oracle):
+    src = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(gpu_vs.VsError):
+        gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(), mode=gpu_vs.WARP_BILINEAR_CV, f32=True)
+    # the host-side inversion is cv::warpAffine's, operation for operation: equal to the oracle's doubles bit for bit
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        tr = (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-50, 50), rng.uniform(-50, 50))
+        w, h = int(rng.integers(8, 4000)), int(rng.integers(8, 2200))
+        assert np.array_equal(gpu_vs.cv_inverse_matrix(gpu_vs.Transform.of(*tr), w, h), oracle.cv_inverse_matrix(oracle.Transform.of(*tr), w, h))
+
+
+def test_stabilizer_with_the_references_own_warp(gpu_vs, oracle):
+    """VideoStabilizer::processFrame with warp_mode = VS_WARP_BILINEAR_CV: the correction goes to the warp as the reference hands it to
+    cv::warpAffine (stabilizer.cpp:97-99); every output frame equals the oracle's"""
+    from video_stabilizer_amd import synth
+    frames, _ = synth.make_clip(480, 270, 16, seed=31, channels=3)
+    g = gpu_vs.Stabilizer(device=0, warp_mode=gpu_vs.WARP_BILINEAR_CV, lag=3)
+    c = oracle.Stabilizer(warp_mode=oracle.WARP_BILINEAR_CV, lag=3)
+    outs = 0
+    for f in frames:
+        a, b = g.process(f), c.process(f)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a, b)
+            outs += 1
+    assert outs == 16 - 3

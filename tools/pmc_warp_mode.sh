@@ -15,7 +15,7 @@ def counters(d):
     agg, ids = collections.defaultdict(float), set()
     for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "warp_c3" in r["Kernel_Name"]:
+            if "bgr_warp_c" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
     n = max(1, len(ids))
     return {k: v / n for k, v in agg.items()}

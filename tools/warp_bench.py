@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Isolated timing of bgr_image_warp (HIP events on the launch stream, frames resident in HBM).
-usage: python tools/warp_bench.py [--w 3840 --h 2160 --frames 16 --reps 20 --mode lanczos2|bilinear|fast|sep --bits 8|16]"""
+usage: python tools/warp_bench.py [--w 3840 --h 2160 --frames 16 --reps 20 --mode lanczos2|bilinear|fast|sep|cv --bits 8|16]"""
 import argparse
 import json
 import os
@@ -30,7 +30,7 @@ def main():
     dst = torch.empty_like(src)
     tr = [float(v) for v in args.transform.split(",")]
     ts = [capi.Transform.of(tr[0], tr[1], tr[2] + 0.37 * i, tr[3] - 0.21 * i) for i in range(n)]
-    mode = {"lanczos2": capi.WARP_LANCZOS2, "bilinear": capi.WARP_BILINEAR, "fast": capi.WARP_LANCZOS2_FAST, "sep": capi.WARP_LANCZOS2_SEP}[args.mode]
+    mode = {"lanczos2": capi.WARP_LANCZOS2, "bilinear": capi.WARP_BILINEAR, "fast": capi.WARP_LANCZOS2_FAST, "sep": capi.WARP_LANCZOS2_SEP, "cv": capi.WARP_BILINEAR_CV}[args.mode]
     border = capi.BORDER_CLAMP if args.border == "clamp" else capi.BORDER_CONSTANT
     st = torch.cuda.current_stream()
     mv = 255 if args.bits == 8 else 1023

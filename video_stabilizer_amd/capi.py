@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use
 FMT_BGR16 = 5                                       # first-release format: 10-bit luma (gray >> 2), warp output saturates at 65535
-WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST, WARP_LANCZOS2_SEP = 0, 1, 2, 3
+WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST, WARP_LANCZOS2_SEP, WARP_BILINEAR_CV = 0, 1, 2, 3, 4
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE, SELECT_STABLE = 0, 1, 2
 BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1
@@ -105,6 +105,7 @@ SIGNATURES = {
     "vs_tile_size": (_i32, [_i32, _i32]),
     "vs_ul_params_sparse": (None, [_TP, _i32, _i32, _vp]),
     "vs_ul_params_warp": (None, [_TP, _i32, _i32, _vp]),
+    "vs_cv_inverse_matrix": (None, [_TP, _i32, _i32, _vp]),
     "vs_smoother_create": (_vp, [_i32, _i32, _f64]),
     "vs_smoother_destroy": (None, [_vp]),
     "vs_smoother_update": (_i32, [_vp, _TP, _TP]),
@@ -270,6 +271,13 @@ def ul_params_sparse(t, w, h):
 def ul_params_warp(t, w, h):
     out = np.empty(4, np.float32)
     lib().vs_ul_params_warp(C.byref(t), w, h, _p(out))
+    return out
+
+
+def cv_inverse_matrix(t, w, h):
+    """VS_WARP_BILINEAR_CV's output -> source matrix for the FORWARD transform t (cv::warpAffine's inversion of imgproc.cpp:457-466's matrix)"""
+    out = np.empty(6, np.float64)
+    lib().vs_cv_inverse_matrix(C.byref(t), w, h, _p(out))
     return out
 
 

@@ -569,11 +569,41 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     const vsk::Roi roi = roi_in ? *roi_in : vsk::Roi{0, 0, w, h};
     VS_ARG(roi.x >= 0 && roi.y >= 0 && roi.w >= 1 && roi.h >= 1 && roi.w <= w && roi.h <= h && roi.x <= w - roi.w && roi.y <= h - roi.h);   // (no sum that could overflow)
     VS_ARG(src_stride >= w * channels && dst_stride >= roi.w * channels);
-    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST || mode == VS_WARP_LANCZOS2_SEP);
+    VS_ARG(mode == VS_WARP_LANCZOS2 || mode == VS_WARP_BILINEAR || mode == VS_WARP_LANCZOS2_FAST || mode == VS_WARP_LANCZOS2_SEP || mode == VS_WARP_BILINEAR_CV);
     VS_ARG(border == VS_BORDER_CLAMP || border == VS_BORDER_CONSTANT);
+    if (mode == VS_WARP_BILINEAR_CV && f32out) return set_error(VS_ERR_UNSUPPORTED, "VS_WARP_BILINEAR_CV has integer outputs only (cv::warpAffine on 8- / 16-bit frames)");
     VS_ARG(n_frames == 1 || (src_fs >= img_span(w, h, src_stride, channels) && dst_fs >= img_span(roi.w, roi.h, dst_stride, channels)));
     if (!vsi::device_ready()) return VS_ERR_HIP;
     const size_t esz = bits / 8, osz = f32out ? 4 : esz;
+    if (mode == VS_WARP_BILINEAR_CV) {
+        // cv::warpAffine's own arithmetic: t[i] is the FORWARD transform; its inverted matrix (six doubles = three ring slots per frame)
+        // is what the kernels take
+        VS_ARG(max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535));
+        ParamRing* ring = param_ring();
+        if (!ring) return set_error(VS_ERR_UNSUPPORTED, "no current HIP device with index < 16");
+        Staged a, o;
+        const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
+        VS_TRY(a.in(src, in_bytes, mem, s));
+        VS_TRY(o.out_image(dst, (size_t)roi.w * channels * esz, (size_t)roi.h, (size_t)dst_stride * esz, (size_t)n_frames, dst_fs * esz, mem));
+        const int per_call = (int)(ParamRing::kSlots / 2 / 3);             // frames whose matrices fit one upload of the ring (half its slots per call)
+        std::vector<double> Mv((size_t)std::min(n_frames, per_call) * 6 + 2);   // (+2: an upload is counted in 16-byte slots)
+        for (int f0 = 0; f0 < n_frames; f0 += per_call) {
+            const int nf = std::min(per_call, n_frames - f0);
+            for (int i = 0; i < nf; i++) vs_cv_inverse_matrix(&t[f0 + i], w, h, &Mv[(size_t)i * 6]);
+            float4* mdev = nullptr;
+            VS_TRY(ring->upload((const float*)Mv.data(), ((size_t)nf * 6 * sizeof(double) + 15) / 16, s, &mdev));
+            const char* sp = (const char*)a.dev + (size_t)f0 * src_fs * esz;
+            char* dp = (char*)o.dev + (size_t)f0 * dst_fs * esz;
+            hipError_t e = hipErrorNotSupported;
+            if (channels == 3) e = vsk::bgr_warp_cv_c3(sp, w, h, src_stride, bits, (const double*)mdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+            if (e == hipErrorNotSupported)
+                e = vsk::bgr_warp_cv_generic(sp, w, h, src_stride, channels, bits, (const double*)mdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+            VS_HIP(e);
+            VS_TRY(ring->fence(mdev, s));
+        }
+        VS_TRY(o.finish(s));
+        return finish_host(mem, s);
+    }
     // kernel parameters of every frame, then (tuned 3-channel kernel) the extents its tile prologue uses: one upload of 2n float4
     static const bool host_extents = []() { const char* e = getenv("VS_WARP_HOST_EXTENTS"); return e ? atoi(e) != 0 : true; }();
     const bool tuned = channels == 3 && !f32out && max_value >= 0 && max_value <= (bits == 8 ? 255 : 65535);

@@ -164,6 +164,19 @@ __device__ __forceinline__ float lanczos_separable_combine(const float v[4][4], 
     return num * rden;
 }
 
+// ---- VS_WARP_BILINEAR_CV: cv::warpAffine's fixed-point coordinates (OpenCV 4.x imgwarp.cpp, AB_BITS = 10, INTER_BITS = 5) -------------------
+// cvRound = round half to even; a value outside the int range saturates (as the oracle's cv_round_sat; no frame gets near it)
+__device__ __forceinline__ int cv_round_sat(double v) {
+    v = fmin(fmax(rint(v), -2147483648.0), 2147483647.0);
+    return (v == v) ? (int)v : 0;
+}
+// adelta[x] / bdelta[x]: cvRound(m * x * 1024) -- the product m * x rounds to double before the scaling (exact), as in the source
+__device__ __forceinline__ int cv_delta(double m, int x) { return cv_round_sat(m * (double)x * 1024.0); }
+// X0 / Y0 of a row: cvRound((m_y * y + m_t) * 1024) + round_delta (16), two's-complement wrap like the int arithmetic it restates
+__device__ __forceinline__ int cv_row_origin(double my, double mt, int y) {
+    return (int)((unsigned)cv_round_sat((my * (double)y + mt) * 1024.0) + 16u);
+}
+
 // Lanczos2 sample of a single-channel u8 image with clamp-to-edge addressing:
 // generators.cpp:672-697 (sparse_warpdiff) == :469-498 (sparse_ica).  rx inner, ry outer,
 // separate num / den accumulators from 0, one IEEE divide.

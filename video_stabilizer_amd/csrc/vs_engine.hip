@@ -1791,8 +1791,10 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
                 s->frames.pop_front();
                 // :97-99: warpBySimilarityTransform(frame, accum^-1); cv::warpAffine without WARP_INVERSE_MAP
                 // inverts the matrix it is given (imgproc.cpp:472), so the sampling map is (accum^-1)^-1.
+                // (VS_WARP_BILINEAR_CV is cv::warpAffine itself, inversion included: it takes the correction as the reference hands it over)
                 vs_transform correction = vs_transform_inverse(&na);
-                jobs.push_back(Job{src.ptr, vs_transform_inverse(&correction), i, src.owned ? src.ptr : nullptr});
+                jobs.push_back(Job{src.ptr, s->params.warp_mode == VS_WARP_BILINEAR_CV ? correction : vs_transform_inverse(&correction), i,
+                                   src.owned ? src.ptr : nullptr});
                 has_output[i] = 1;
             }
         }

@@ -149,6 +149,25 @@ void vs_ul_params_warp(const vs_transform* t, int w, int h, float out4[4]) {
     out4[3] = static_cast<float>(t->TY - t->B * cx - t->A * cy);
 }
 
+// imgproc.cpp:457-466 (the forward matrix of warpBySimilarityTransform) + cv::warpAffine's own inversion of a matrix given without
+// WARP_INVERSE_MAP (OpenCV 4.x imgwarp.cpp: D = M0 M4 - M1 M3; D = D != 0 ? 1./D : 0; ... -- restated from the published source, in its
+// operation order; this file compiles with -ffp-contract=off, so every product and sum rounds where OpenCV's x86-64 baseline build rounds)
+void vs_cv_inverse_matrix(const vs_transform* t, int w, int h, double M[6]) {
+    const double cx = (w - 1) * 0.5, cy = (h - 1) * 0.5;
+    const double tx_ul = t->TX - t->A * cx + t->B * cy;
+    const double ty_ul = t->TY - t->B * cx - t->A * cy;
+    M[0] = 1.0 + t->A; M[1] = -t->B; M[2] = tx_ul;
+    M[3] = t->B;       M[4] = 1.0 + t->A; M[5] = ty_ul;
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+
 // smoother.cpp:18-65
 void vs_tvl1_smooth(const double* data, int n, double lambda, int iterations, double* x) {
     if (n <= 0) return;

@@ -958,6 +958,45 @@ __global__ __launch_bounds__(256) void vs_k_bgr_warp_generic(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// VS_WARP_BILINEAR_CV (general path): cv::warpAffine(INTER_LINEAR)'s fixed-point bilinear, one thread per output pixel, any channel
+// count, u8 (integer weights, (sum + 2^14) >> 15) or u16 containers (float weights, cvRound).  Restates OpenCV 4.x imgwarp.cpp
+// (WarpAffineInvoker + remapBilinear) exactly as the oracle's cv_warp_impl does; M = the frame's output -> source matrix.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BORDER>
+__global__ __launch_bounds__(256) void vs_k_bgr_warp_cv_generic(const T* __restrict__ src, int w, int h, int src_stride, int channels,
+                                                                const double* __restrict__ minv, int max_value, T* __restrict__ dst,
+                                                                int dst_stride, size_t src_fs, size_t dst_fs, vsk::Roi roi) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= roi.w) return;
+    const double* M = minv + 6 * (size_t)blockIdx.z;
+    src += blockIdx.z * src_fs;
+    dst += blockIdx.z * dst_fs;
+    const int fx_ = x + roi.x, fy_ = y + roi.y;                       // full-frame coordinate of this window pixel
+    const int X = (int)((unsigned)cv_row_origin(M[1], M[2], fy_) + (unsigned)cv_delta(M[0], fx_)) >> 5;
+    const int Y = (int)((unsigned)cv_row_origin(M[4], M[5], fy_) + (unsigned)cv_delta(M[3], fx_)) >> 5;
+    const int sx = clampi(X >> 5, -32768, 32767), sy = clampi(Y >> 5, -32768, 32767);      // saturate_cast<short>
+    const int a1 = X & 31, b1 = Y & 31, a0 = 32 - a1, b0 = 32 - b1;
+    auto tap = [&](int xx, int yy, int c) -> int {
+        if (BORDER == 1) { if (xx < 0 || yy < 0 || xx >= w || yy >= h) return 0; }
+        else { xx = clampi(xx, 0, w - 1); yy = clampi(yy, 0, h - 1); }
+        return (int)src[(size_t)yy * src_stride + (size_t)xx * channels + c];
+    };
+    for (int c = 0; c < channels; c++) {
+        const int v00 = tap(sx, sy, c), v01 = tap(sx + 1, sy, c), v10 = tap(sx, sy + 1, c), v11 = tap(sx + 1, sy + 1, c);
+        int r;
+        if (sizeof(T) == 1) {
+            r = (v00 * (a0 * b0 * 32) + v01 * (a1 * b0 * 32) + v10 * (a0 * b1 * 32) + v11 * (a1 * b1 * 32) + (1 << 14)) >> 15;
+        } else {
+            const float k = 1.0f / 1024.0f;
+            const float sum = (float)v00 * ((float)(a0 * b0) * k) + (float)v01 * ((float)(a1 * b0) * k) + (float)v10 * ((float)(a0 * b1) * k) +
+                              (float)v11 * ((float)(a1 * b1) * k);
+            r = (int)rintf(sum);
+        }
+        dst[(size_t)y * dst_stride + (size_t)x * channels + c] = (T)min(max(r, 0), max_value);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Counter calibration: a plain copy with the warp kernel's access width (12 bytes per lane,
 // global_load/store_dwordx3).  MI355X_MICROARCH.md says FETCH_SIZE is only calibrated for 16-byte
 // streams on gfx950 and asks for a known-byte-count run in the kernel's own access pattern.
@@ -1146,6 +1185,18 @@ hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int c
         if (f32out) launch_generic<uint16_t, true>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
         else launch_generic<uint16_t, false>((const uint16_t*)src, w, h, src_stride, channels, params_dev, mode, border, max_value, dst, dst_stride, n_frames, src_fs, dst_fs, roi, s);
     }
+    return hipGetLastError();
+}
+
+hipError_t bgr_warp_cv_generic(const void* src, int w, int h, int src_stride, int channels, int bits, const double* minv_dev, int border,
+                               int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
+    dim3 grid(cdiv(roi.w, 256), roi.h, n_frames), block(256);
+#define VS_LAUNCH(T, Bd) \
+    hipLaunchKernelGGL((vs_k_bgr_warp_cv_generic<T, Bd>), grid, block, 0, s, (const T*)src, w, h, src_stride, channels, minv_dev, max_value, (T*)dst, \
+                       dst_stride, src_fs, dst_fs, roi)
+    if (bits == 8) { if (border == 0) VS_LAUNCH(uint8_t, 0); else VS_LAUNCH(uint8_t, 1); }
+    else { if (border == 0) VS_LAUNCH(uint16_t, 0); else VS_LAUNCH(uint16_t, 1); }
+#undef VS_LAUNCH
     return hipGetLastError();
 }
 

@@ -51,6 +51,13 @@ hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int c
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, const float4* extents_dev,
                        int mode, int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi,
                        hipStream_t s);
+// VS_WARP_BILINEAR_CV (cv::warpAffine's fixed-point bilinear): minv_dev = n_frames x 6 doubles, the output -> source matrix of each frame
+// (vs_cv_inverse_matrix).  Generic: any channel count, u8 / u16 containers; tuned (vs_warp.hip): interleaved 8-bit BGR saturating at 255,
+// hipErrorNotSupported for anything else
+hipError_t bgr_warp_cv_generic(const void* src, int w, int h, int src_stride, int channels, int bits, const double* minv_dev, int border,
+                               int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s);
+hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int border, int max_value, void* dst,
+                          int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s);
 // host side of the tuned kernel's tile prologue: per frame {lo_x, hi_x, lo_y, hi_y} from the kernel parameters {A, B, TX, TY}, for the
 // tile of the kernel that bgr_warp_c3 launches for (bits, mode)
 void bgr_warp_c3_extents(const float* P4, int n_frames, Roi roi, int bits, int mode, float* E4);

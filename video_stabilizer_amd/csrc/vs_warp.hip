@@ -1106,6 +1106,213 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// VS_WARP_BILINEAR_CV on interleaved 8-bit BGR: cv::warpAffine(INTER_LINEAR) as the reference's stabilizer calls it (stabilizer.cpp:97-99
+// -> imgproc.cpp:446-484), OpenCV 4.x's classic fixed-point path restated (oracle/vs_oracle.cpp cv_warp_impl has the derivation): source
+// coordinates in 1/32 pixel from integer adds, four integer weights a b (a, b in 0..32), result = (sum a b v + 512) >> 10 -- the same
+// integer as OpenCV's (sum 32 a b v + 2^14) >> 15.  Integer work end to end, so the kernel is counted in instructions, not in roundings:
+//   * one workgroup = one 64 x 32 output tile; the source footprint goes into LDS as BYTES, one dword {B,G,R,0} per pixel (the byte
+//     tile of the float bilinear kernel: 14 KB, 8 workgroups per CU), borders resolved in the copy;
+//   * per tile a lane computes its column's adelta / bdelta (two double products, cvRound) once, and lanes 0..31 the row origins X0 / Y0
+//     of the tile's 32 rows; a row's origin reaches the other lanes as a scalar (v_readlane): per pixel the position is two integer adds;
+//   * per pixel and channel: two v_perm_b32 put the channel's bytes of a window row side by side as a u16 pair {v(x), v(x + 1)}, two
+//     v_dot2_u32_u16 against the row's weight pair {a0 b, a1 b} accumulate the four taps on top of the rounding constant, one shift.
+//     27 vector instructions per pixel in the sampler against the float bilinear's ~70.
+// Tiles whose footprint does not fit the window (large rotation / zoom) take a per-pixel global path in the same kernel.
+// ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef VS_WARP_CV_TILE_H
+#define VS_WARP_CV_TILE_H 64             // output rows per workgroup (a multiple of 32: the row-origin table is filled 32 rows per wave pass)
+#endif
+constexpr int CV_TH = VS_WARP_CV_TILE_H, CV_RPW = CV_TH / 4, CV_WS_H = CV_TH + 8;
+static_assert(CV_TH % 32 == 0 && CV_TH <= 64, "row-origin table: 32 rows per pass, X0 | Y0 in one wave");
+constexpr int CV_FILL_SLOTS = (CV_WS_H / 4 * (WS_W / 4) + 63) / 64;
+static_assert(CV_WS_H / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
+
+template <int BORDER>
+__device__ __forceinline__ void cv_pixel_global(const uint8_t* __restrict__ src, int w, int h, int stride, int X, int Y, uint32_t out[3]) {
+    const int sx = clampi(X >> 5, -32768, 32767), sy = clampi(Y >> 5, -32768, 32767);      // saturate_cast<short>
+    const int a1 = X & 31, b1 = Y & 31, a0 = 32 - a1, b0 = 32 - b1;
+    auto tap = [&](int xx, int yy, int c) -> int {
+        if (BORDER == 1) { if (xx < 0 || yy < 0 || xx >= w || yy >= h) return 0; }
+        else { xx = clampi(xx, 0, w - 1); yy = clampi(yy, 0, h - 1); }
+        return (int)src[(size_t)yy * stride + (size_t)xx * 3 + c];
+    };
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        out[c] = (uint32_t)((tap(sx, sy, c) * (a0 * b0) + tap(sx + 1, sy, c) * (a1 * b0) + tap(sx, sy + 1, c) * (a0 * b1) + tap(sx + 1, sy + 1, c) * (a1 * b1) + 512) >> 10);
+}
+
+// (Measured and dropped, profiles/r05_warp_cv.md: workgroups that walk several tiles with the next tile's tables computed and its source loads
+// in flight -- in registers -- while the current tile is sampled: no gain at any number of tiles per workgroup, and the registers it holds cost
+// occupancy (13.4 us per 4K frame against 11.5); fill items dealt over the tile's own column groups instead of the window's 20: no change.)
+template <int BORDER>
+__global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
+                                                             const double* __restrict__ minv, uint8_t* __restrict__ dst, int dst_stride,
+                                                             size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
+                                                             int chunk, vsk::Roi roi) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV_WS_H * WS_RS8];     // B | G << 8 | R << 16 per staged source pixel
+    // the tile's fixed-point coordinate tables: adelta[64] | bdelta[64] | X0[CV_TH] | Y0[CV_TH].  The double-precision evaluations behind them
+    // (cvRound of a double product: ~10 fp64 instructions each, at a fraction of the fp32 rate) are the expensive part of a tile's prologue,
+    // so each is made ONCE per workgroup -- wave 0 the column deltas a, wave 1 the column deltas b, waves 2 (and 3) the row origins -- and
+    // read back by everyone after a barrier (computed per wave they were a third of the kernel's time)
+    __shared__ __attribute__((aligned(16))) int cv_tab[128 + 2 * CV_TH];
+    // XCD-aware tile order, as in vs_k_bgr_warp_c3: every XCD walks one contiguous run of tiles in raster order
+    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
+    const int frame = blockIdx.y;
+    const double* M = minv + 6 * (size_t)frame;
+    src += (size_t)frame * src_fs;
+    dst += (size_t)frame * dst_fs;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);
+    const int txi = tl - tyi * tiles_x;
+    const int x0 = txi * WT_W, y0 = tyi * CV_TH;
+    const int nx = min(WT_W, roi.w - x0), ny = min(CV_TH, roi.h - y0);             // live columns / rows of this tile (>= 1)
+    const int x = x0 + lane;
+    // columns / rows beyond the window repeat its last column / row (masked at the store)
+    const int fxq = min(x, roi.w - 1) + roi.x;
+    if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
+    else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
+    else if (wv - 2 < CV_TH / 32) {                        // wave 2 (and wave 3 of a 64-row tile): 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63
+        const int r = 32 * (wv - 2) + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
+        cv_tab[128 + (lane < 32 ? 0 : CV_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+    }
+    __syncthreads();
+    const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
+    // source footprint: X0[y] and adelta[x] are monotone (cvRound of a monotone function), so the extremes sit at the tile's corners
+    const long long adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
+    const long long bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
+    const long long XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
+    const long long YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH + ny - 1]);
+    const long long mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
+    const long long mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
+    // (|position| < 2^14 pixels in 10-bit fixed point: no wrap in X0 + adelta, no saturate_cast<short> at work, window arithmetic in range)
+    bool fits = mnX > -(1LL << 24) && mxX < (1LL << 24) && mnY > -(1LL << 24) && mxY < (1LL << 24);
+    int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
+    if (fits) {
+        sx_lo = (int)(mnX >> 10) & ~3;                         // first staged column: a multiple of 4 pixels (12 bytes)
+        const int sx_hi = (int)(mxX >> 10) + 1;
+        sy_lo = (int)(mnY >> 10);
+        const int sy_hi = (int)(mxY >> 10) + 1;
+        rows = sy_hi - sy_lo + 1;
+        groups = (sx_hi - sx_lo + 4) >> 2;
+        fits = groups <= WS_W / 4 && rows <= CV_WS_H;
+    }
+    const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)src_stride) & 3) == 0;                      // uniform
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (fits && !(VS_WARP_WHATIF & 2)) {
+        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;
+        u32x3 q[CV_FILL_SLOTS];
+        FillItem it[CV_FILL_SLOTS];
+        bool live[CV_FILL_SLOTS], direct[CV_FILL_SLOTS];
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {              // every load is issued before the first tile write
+            it[s] = fill_item(lane, wv + 4 * s);
+            live[s] = it[s].row < rows && it[s].g < groups;
+            const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+            direct[s] = live[s] && (interior || (src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h));
+            if (direct[s]) q[s] = *(const u32x3*)(src + (size_t)sy * src_stride + (size_t)sx * 3);
+        }
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            u32x4 px;
+            if (direct[s]) {                                    // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
+                px.x = q[s].x & 0x00ffffffu;
+                px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
+                px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
+                px.w = q[s].z >> 8;
+            } else {                                            // the frame's rim, an unaligned frame: pixel by pixel, the border rule applied here
+                const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+                uint32_t d[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int pxi = sx + k;
+                    if (BORDER == 1 && (sy < 0 || sy >= h || pxi < 0 || pxi >= w)) d[k] = 0u;
+                    else {
+                        const uint8_t* qq = src + (size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(pxi, 0, w - 1) * 3;
+                        d[k] = (uint32_t)qq[0] | ((uint32_t)qq[1] << 8) | ((uint32_t)qq[2] << 16);
+                    }
+                }
+                px = u32x4{d[0], d[1], d[2], d[3]};
+            }
+            VS_BOUNDS_CHECK(it[s].row * WS_RS8 + 4 * it[s].g + 3, CV_WS_H * WS_RS8, 211);
+            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, CV_WS_H * WS_RS8 - 3)) = px;
+        }
+    }
+    __syncthreads();
+
+    const int yw = y0 + wv * CV_RPW;                         // first row of this wave
+    if (yw >= roi.h) return;                                 // wave-uniform
+    const int m = lane & 3;
+    const bool rows_aligned = ((((uintptr_t)dst) | (uintptr_t)dst_stride) & 3) == 0;                      // uniform
+    const bool lane_in = x < roi.w, quad_in = (x | 3) < roi.w;
+    const uint32_t sel = quad_sel(m);
+    const uint32_t loff = (uint32_t)(x & ~3) * 3u + 4u * (uint32_t)m;
+    // one output pixel from the byte tile: LDS byte address of staged pixel (sy, sx) = 4 * ((sy - sy_lo) * WS_RS8 + (sx - sx_lo)).
+    // Instruction diet (tools/ubench_int.hip, profiles/r05_ubench_int.txt: three-operand integer instructions -- v_perm, v_dot2, v_mad_u32_u24,
+    // v_bfe, v_add3, v_lshl_or, and v_mul_u32_u24 -- issue at 4.2-4.35 cycles per wave per SIMD, two-operand shifts / and / add at 2.3-2.6): the
+    // weights are OpenCV's own 15-bit ones, 32 a b (<= 32768: a u16), so that fy enters as (Ys & 0x3e0) = 32 fy without a bit-field extract
+    // and the top row's pair is (apair << 10) - bottom pair instead of a second multiply; result = (sum + 2^14) >> 15 as in the source.
+    const int base4 = -4 * (sy_lo * WS_RS8 + sx_lo);
+    auto sample = [&](uint32_t Xs, uint32_t Ys) -> uint32_t {
+        const uint32_t fx = (Xs >> 5) & 31u, fy32 = Ys & 0x3e0u;
+        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * WS_RS8) + ((((int)Xs >> 8) & ~3) + base4), 4 * (CV_WS_H * WS_RS8 - (WS_RS8 + 2)), 212);
+        const __attribute__((address_space(3))) uint32_t* t = (const __attribute__((address_space(3))) uint32_t*)((const __attribute__((address_space(3))) char*)tile_raw + off);
+        if (VS_WARP_WHATIF & 1) return t[0] + fx + fy32;                    // (analysis: one LDS read, no arithmetic)
+        const uint32_t p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+        const uint32_t apair = fx * 0xffffu + 32u;                          // (32 - fx) | fx << 16
+        const uint32_t wb = apair * fy32, wt = (apair << 10) - wb;          // {32 a0 b1 | 32 a1 b1 << 16}, {32 a0 b0 | 32 a1 b0 << 16}: each <= 32768, no borrow between the halves
+        uint32_t o[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const uint32_t selc = 0x0c040c00u + 0x00010001u * (uint32_t)c;  // {byte c of the left pixel, 0, byte c of the right pixel, 0}
+            const uint32_t top = __builtin_amdgcn_perm(p01, p00, selc), bot = __builtin_amdgcn_perm(p11, p10, selc);
+            o[c] = udot2(bot, wb, udot2(top, wt, 1u << 14));                // bits 15..22 = the sample
+        }
+        return ((o[0] >> 15) & 0xffu) | ((o[1] >> 7) & 0xff00u) | ((o[2] << 1) & 0xff0000u);
+    };
+    if (fits && rows_aligned && nx == WT_W && yw + CV_RPW <= roi.h) {
+        // the common case -- the tile fits its window, whole quads, whole rows: all rows are sampled in ONE basic block (the stores sit behind
+        // a single lane mask afterwards), so that the scheduler can run the rows' LDS reads ahead of the previous rows' arithmetic
+        uint32_t d[CV_RPW];
+#pragma unroll
+        for (int k = 0; k < CV_RPW; k++)
+            d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k] + (uint32_t)ad, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd), sel);
+        if (m < 3 && (!(VS_WARP_WHATIF & 8) || d[0] == 0x12345678u)) {
+#pragma unroll
+            for (int k = 0; k < CV_RPW; k++) VS_STORE32((uint32_t*)(dst + (size_t)(yw + k) * dst_stride + loff), d[k]);   // (uniform row base + lane offset)
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int k = 0; k < CV_RPW; k++) {
+        const int y = yw + k;
+        if (y >= roi.h) break;                               // wave-uniform
+        const uint32_t Xs = (uint32_t)cv_tab[128 + wv * CV_RPW + k] + (uint32_t)ad, Ys = (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd;
+        uint32_t p = 0u;
+        if (!fits) {
+            uint32_t o[3] = {0u, 0u, 0u};
+            if (lane_in) cv_pixel_global<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, o);
+            p = o[0] | (o[1] << 8) | (o[2] << 16);
+        } else p = sample(Xs, Ys);
+        const uint32_t d = quad_pack_bgr(p, sel);            // every lane of the wave takes part in the shuffle
+        uint8_t* orow = dst + (size_t)y * dst_stride;
+        if (rows_aligned && quad_in) {
+            if (m < 3) VS_STORE32((uint32_t*)(orow + loff), d);
+        } else if (lane_in) {
+            orow[(size_t)x * 3] = (uint8_t)p;
+            orow[(size_t)x * 3 + 1] = (uint8_t)(p >> 8);
+            orow[(size_t)x * 3 + 2] = (uint8_t)(p >> 16);
+        }
+    }
+}
+
 }  // namespace
 
 VS_BOUNDS_TU(vs_bounds_fetch_warp)
@@ -1168,6 +1375,29 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
                                   n_frames, src_fs, dst_fs, (float)max_value, roi, s);
     return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint16_t*)dst, dst_stride,
                                n_frames, src_fs, dst_fs, (float)max_value, roi, s);
+}
+
+hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int border, int max_value, void* dst,
+                          int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
+    if (bits != 8 || max_value != 255) return hipErrorNotSupported;          // (results never exceed 255: the weights sum to 1024)
+    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + CV_TH - 1) / CV_TH;
+    const long long tpf = (long long)tiles_x * tiles_y;
+    if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
+    const int chunk = (int)((tpf + 7) / 8);
+    const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {         // gridDim.y limit
+        const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+        dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
+        const uint8_t* sp = (const uint8_t*)src + (size_t)f0 * src_fs;
+        uint8_t* dp = (uint8_t*)dst + (size_t)f0 * dst_fs;
+        if (border == 0)
+            hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<0>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
+                               tiles_x, magic, (int)tpf, chunk, roi);
+        else
+            hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<1>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
+                               tiles_x, magic, (int)tpf, chunk, roi);
+    }
+    return hipGetLastError();
 }
 
 // The per-frame extents the tuned kernel's tile prologue adds to the position of a tile's origin (see the kernel): for the kernel

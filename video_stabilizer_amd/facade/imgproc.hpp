@@ -216,10 +216,11 @@ inline bool ImageWarp(BIn& input, const SimilarityTransform& transform, BOut& ou
 // imgproc.cpp:446-484 warpBySimilarityTransform on an interleaved BGR image (h x w x 3, u8).  OpenCV's warpAffine
 // without WARP_INVERSE_MAP inverts the matrix it is given (imgproc.cpp:472), i.e. it samples the source at
 // transform^-1; bgr_image_warp takes the sampling map, so it receives transform.inverse().  The reference's
-// interpolation is OpenCV's fixed-point bilinear with a black border; `mode` picks this build's sampler.
+// interpolation is OpenCV's fixed-point bilinear with a black border: VS_WARP_BILINEAR_CV restates exactly that (cv::warpAffine's own
+// matrix inversion included, so that mode receives `transform` itself); the default stays this build's float bilinear (generators.cpp:148-163).
 inline bool warpBySimilarityTransform(const uint8_t* src_bgr, int w, int h, const SimilarityTransform& transform, uint8_t* dst_bgr,
                                       int mode = VS_WARP_BILINEAR, int border = VS_BORDER_CONSTANT) {
-    const SimilarityTransform sampling = transform.inverse();
+    const SimilarityTransform sampling = mode == VS_WARP_BILINEAR_CV ? transform : transform.inverse();
     return vs_bgr_image_warp(src_bgr, w, h, w * 3, 3, 8, &sampling.c(), mode, border, 255, dst_bgr, w * 3, VS_MEM_HOST, nullptr) == 0;
 }
 
@@ -244,7 +245,7 @@ inline cv::Mat warpBySimilarityTransform(const cv::Mat& src, const SimilarityTra
                                          int border = VS_BORDER_CONSTANT) {
     vs::require_bgr8(src, "warpBySimilarityTransform");
     cv::Mat dst(src.rows, src.cols, CV_8UC3);
-    const SimilarityTransform sampling = transform.inverse();
+    const SimilarityTransform sampling = mode == VS_WARP_BILINEAR_CV ? transform : transform.inverse();
     if (vs_bgr_image_warp(src.data, src.cols, src.rows, vs::mat_stride_elems(src), 3, 8, &sampling.c(), mode, border, 255, dst.data,
                           vs::mat_stride_elems(dst), VS_MEM_HOST, nullptr) != 0)
         throw std::runtime_error(std::string("vs_bgr_image_warp: ") + vs_last_error());
