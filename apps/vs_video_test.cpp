@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
         vs_stabilizer_params params;
         vs_stabilizer_params_default(&params);
         params.crop_pixels = crop;                         // 0: disable crop so we can see what it is doing (video_test.cpp:55)
-        if (bilinear) params.warp_mode = VS_WARP_BILINEAR;    // the default (the reference's INTER_LINEAR)
+        if (bilinear) params.warp_mode = VS_WARP_BILINEAR;    // the Halide sampler's float lerp (the default is cv::warpAffine's fixed-point bilinear, VS_WARP_BILINEAR_CV)
         if (lanczos2) params.warp_mode = VS_WARP_LANCZOS2;
         int failed = 0;
         for (const auto& name : clips) {

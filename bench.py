@@ -307,6 +307,7 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     out = {}
     for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted"),
                             ("separable", capi.WARP_LANCZOS2_SEP, "separable"),
+                            ("bilinear_cv", capi.WARP_BILINEAR_CV, "bilinear_cv"),
                             ("bilinear", capi.WARP_BILINEAR, "bilinear"), ("bilinear_10bit", capi.WARP_BILINEAR, "bilinear_10bit")):
         bits = 16 if name == "bilinear_10bit" else 8
         if bits == 16:                                       # 10-bit frames in 16-bit containers (configs[4]'s format): twice the bytes per pixel
@@ -351,8 +352,20 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR, 10-bit)"}
             continue
+        if name == "bilinear_cv":
+            # the stabilizer's DEFAULT sampler = the reference's own warp (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99 -> imgproc.cpp:472):
+            # OpenCV's fixed-point bilinear restated, integer work end to end; bound by how its memory operations are structured, not by
+            # instructions (what-if builds: profiles/r05_warp_cv.md)
+            pc, _ = load_profile("r05_pmc_bilinear_cv.json")
+            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3<clamp> (byte tile, v_dot2_u32_u16 taps)", "bound": "hbm", "binding": "memory structure (loads 3.7 us + "
+                         "stores 2.4 us + arithmetic 1.1 us of 11.5 per 4K frame: profiles/r05_warp_cv.md)", "valu_instr_per_px": pc.get("valu_instr_per_px"),
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
+                         "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR_CV: OpenCV 4.x's published fixed-point path, parity "
+                                   "unpinned (OpenCV version)); transforms = forward maps, as warpBySimilarityTransform hands them to cv::warpAffine"}
+            continue
         if name == "bilinear":
-            # the stabilizer's DEFAULT sampler (cv::warpAffine INTER_LINEAR in the reference, imgproc.cpp:472): 88 vector instructions per
+            # the Halide sampler's float lerp (generators.cpp:148-163; the stabilizer's default until round 5): 88 vector instructions per
             # pixel (counted: profiles/r04_pmc_bilinear.json), VALU-issue-bound like the Lanczos kernels (profiles/r04_ab_warp_bilinear.md)
             out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "valu", "valu_instr_per_px": 87.8,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -433,9 +446,10 @@ def drop_in(capi, dev_index, frames_host, params_kw, calls=48, cpu_budget_s=6.0)
 
     res["align_next"] = timed(lambda: capi.Aligner(device=dev_index, **params_kw), lambda h, f: h.align_next(f)[0], 3)
     res["align_next"]["what"] = "vs_aligner_align_next per frame (alignment.hpp:55-58); results = frames aligned"
-    # library defaults = the reference's processFrame: bilinear, black border, crop 32, lag 10 (stabilizer.hpp:13-30)
+    # library defaults = the reference's processFrame: cv::warpAffine's bilinear, black border, crop 32, lag 10 (stabilizer.hpp:13-30)
     res["process_frame"] = timed(lambda: capi.Stabilizer(device=dev_index, **params_kw), lambda h, f: h.process(f) is not None, 14)
-    res["process_frame"]["what"] = "vs_stabilizer_process per frame, library defaults (bilinear like cv::warpAffine INTER_LINEAR, stabilizer.hpp:39); results = frames returned"
+    res["process_frame"]["what"] = ("vs_stabilizer_process per frame, library defaults (VS_WARP_BILINEAR_CV: cv::warpAffine's fixed-point INTER_LINEAR as "
+                                    "stabilizer.cpp:97-99 calls it); results = frames returned")
     res["process_frame_lanczos2"] = timed(lambda: capi.Stabilizer(device=dev_index, warp_mode=capi.WARP_LANCZOS2_FAST, warp_border=capi.BORDER_CLAMP, **params_kw),
                                           lambda h, f: h.process(f) is not None, 14)
     res["process_frame_lanczos2"]["what"] = "the same with bgr_image_warp Lanczos2 (contracted), clamp border"

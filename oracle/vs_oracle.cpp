@@ -386,7 +386,7 @@ void vso_stabilizer_params_default(vso_stabilizer_params* p) {
     vso_aligner_params_default(&p->aligner);
     p->lag = 10; p->smoother_memory = 5; p->lambda = 4.0; p->enable_smoother = 1; p->crop_pixels = 32;
     p->min_disp = 48.0; p->max_disp = 64.0; p->min_decay = 0.9; p->max_decay = 0.7;
-    p->warp_mode = VSO_WARP_BILINEAR; p->warp_border = VSO_BORDER_CONSTANT;   /* imgproc.cpp:472-481: INTER_LINEAR, BORDER_CONSTANT */
+    p->warp_mode = VSO_WARP_BILINEAR_CV; p->warp_border = VSO_BORDER_CONSTANT;   /* imgproc.cpp:472-481: cv::warpAffine INTER_LINEAR, BORDER_CONSTANT */
 }
 
 float vso_lanczos2(float x) { return lanczos2(x); }

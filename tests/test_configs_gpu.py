@@ -81,7 +81,7 @@ def test_c5_10bit_stabilizer_clips_match_one_oracle_stabilizer_per_clip(gpu_vs, 
     # VideoStabilizerParams defaults: lag 10, smoother 5, crop 32, and the reference's bilinear warp; "lanczos2" = bgr_image_warp
     kw = {} if sampler == "default" else dict(warp_mode=gpu_vs.WARP_LANCZOS2)
     g = gpu_vs.Stabilizer(device=0, **kw)
-    assert g.params.warp_mode == (gpu_vs.WARP_BILINEAR if sampler == "default" else gpu_vs.WARP_LANCZOS2)
+    assert g.params.warp_mode == (gpu_vs.WARP_BILINEAR_CV if sampler == "default" else gpu_vs.WARP_LANCZOS2)
     out, has = g.process_clips(np.concatenate(clips, 0), n_clips)
     produced = 0
     for c in range(n_clips):

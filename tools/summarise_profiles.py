@@ -15,7 +15,7 @@ SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2
 DST = os.path.join(ROOT, "profiles")
 RN = sys.argv[2] if len(sys.argv) > 2 else "r02"        # round prefix of the files written
 SECOND = "fast" if RN == "r02" else "contracted"        # round 3: VS_WARP_LANCZOS2_FAST is the contracted form of the sampler
-VALUE_FORM = SECOND if RN >= "r04" else "exact"         # round 4: bench.py's `value` runs the contracted form
+VALUE_FORM = "separable" if RN >= "r05" else (SECOND if RN >= "r04" else "exact")   # round 4: bench.py's `value` runs the contracted form, round 5: the separable one
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
@@ -53,7 +53,7 @@ out = {"_comment": "vs_k_bgr_warp_c3<u8> on MI355X, rocprofv3 --pmc passes of to
                    "cycles_per_valu_instr = SIMD cycles of the dispatch / VALU instructions, to hold against the issue costs of "
                    "profiles/r02_ubench_mix.txt.  "
                    "lds_frac = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs)."}
-for name, m in (("exact", "lanczos2"), (SECOND, "fast")):
+for name, m in (("exact", "lanczos2"), (SECOND, "fast")) + ((("separable", "sep"),) if RN >= "r05" else ()):
     a, b = counters("pmcA_" + m), counters("pmcB_" + m)
     fz, wz = counters("pmcF_" + m)["FETCH_SIZE"], counters("pmcW_" + m)["WRITE_SIZE"]
     cyc = b["GRBM_GUI_ACTIVE"] / N_XCD
@@ -74,13 +74,19 @@ for name, m in (("exact", "lanczos2"), (SECOND, "fast")):
 json.dump(out, open(os.path.join(DST, RN + "_warp_pmc.json"), "w"), indent=1)
 
 fz, wz = counters("pmcF_c2")["FETCH_SIZE"], counters("pmcW_c2")["WRITE_SIZE"]
-tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2" + (" contracted" if RN >= "r04" else "") + ",clamp> per launch of 240 x 1080p frames (" + RN + " kernel), separate "
+tr = {"_comment": "HBM-side traffic of vs_k_bgr_warp_c3<u8,lanczos2" + (" separable" if RN >= "r05" else (" contracted" if RN >= "r04" else "")) + ",clamp> per launch of 240 x 1080p frames (" + RN + " kernel), separate "
                   "--pmc FETCH_SIZE / WRITE_SIZE passes, counter unit KiB, FETCH_SIZE doubled (see " + RN + "_warp_pmc.json).",
       "c2_1080p_240_frames": {"fetch_size_kib_raw": int(fz), "write_size_kib": int(wz), "traffic_bytes": int((2 * fz + wz) * 1024),
                               "algorithmic_bytes": 1920 * 1080 * 3 * 2 * 240},
       "c3_4k_32_frames": {"fetch_size_kib_raw": out[VALUE_FORM]["fetch_size_kib_raw_32_frames"], "write_size_kib": out[VALUE_FORM]["write_size_kib_32_frames"],
                           "traffic_bytes": out[VALUE_FORM]["traffic_bytes_per_frame"] * 32, "algorithmic_bytes": 3840 * 2160 * 3 * 2 * 32,
                           "kernel_form": VALUE_FORM}}
+try:
+    fz, wz = counters("pmcF_cv", "bgr_warp_c")["FETCH_SIZE"], counters("pmcW_cv", "bgr_warp_c")["WRITE_SIZE"]
+    tr["bilinear_cv_4k_32_frames"] = {"fetch_size_kib_raw": int(fz), "write_size_kib": int(wz), "traffic_bytes": int((2 * fz + wz) * 1024),
+                                      "algorithmic_bytes": 3840 * 2160 * 3 * 2 * 32, "kernel": "vs_k_bgr_warp_cv_c3 (VS_WARP_BILINEAR_CV)"}
+except Exception:
+    pass
 json.dump(tr, open(os.path.join(DST, RN + "_traffic.json"), "w"), indent=1)
 for f in ("host_fed_1080p.json", "host_fed_4k.json", "latency_1080p.json", "latency_4k.json", "latency_cpp.txt", "step_trace_shared.md",
           "step_trace_exclusive.md", "pmc_align_summary.txt", "stats_c2x.json", "many_clips_cpp.jsonl"):

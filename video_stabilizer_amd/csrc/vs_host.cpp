@@ -64,9 +64,10 @@ void vs_stabilizer_params_default(vs_stabilizer_params* p) {
     p->max_disp = 64.0;
     p->min_decay = 0.9;
     p->max_decay = 0.7;
-    // the reference warps with cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT) (imgproc.cpp:472-481): a drop-in user gets the
-    // same sampler class by default; VS_WARP_LANCZOS2 (the north star's bgr_image_warp) is one field away
-    p->warp_mode = VS_WARP_BILINEAR;
+    // the reference warps with cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT) (stabilizer.cpp:97-99 -> imgproc.cpp:472-481): a drop-in
+    // user gets that arithmetic by default (OpenCV's fixed-point bilinear restated: VS_WARP_BILINEAR_CV); VS_WARP_BILINEAR (the Halide
+    // sampler's float lerp) and the Lanczos2 family (the north star's bgr_image_warp) are one field away
+    p->warp_mode = VS_WARP_BILINEAR_CV;
     p->warp_border = VS_BORDER_CONSTANT;
 }
 

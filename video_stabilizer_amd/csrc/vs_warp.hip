@@ -1108,16 +1108,18 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // VS_WARP_BILINEAR_CV on interleaved 8-bit BGR: cv::warpAffine(INTER_LINEAR) as the reference's stabilizer calls it (stabilizer.cpp:97-99
-// -> imgproc.cpp:446-484), OpenCV 4.x's classic fixed-point path restated (oracle/vs_oracle.cpp cv_warp_impl has the derivation): source
-// coordinates in 1/32 pixel from integer adds, four integer weights a b (a, b in 0..32), result = (sum a b v + 512) >> 10 -- the same
-// integer as OpenCV's (sum 32 a b v + 2^14) >> 15.  Integer work end to end, so the kernel is counted in instructions, not in roundings:
-//   * one workgroup = one 64 x 32 output tile; the source footprint goes into LDS as BYTES, one dword {B,G,R,0} per pixel (the byte
-//     tile of the float bilinear kernel: 14 KB, 8 workgroups per CU), borders resolved in the copy;
-//   * per tile a lane computes its column's adelta / bdelta (two double products, cvRound) once, and lanes 0..31 the row origins X0 / Y0
-//     of the tile's 32 rows; a row's origin reaches the other lanes as a scalar (v_readlane): per pixel the position is two integer adds;
+// -> imgproc.cpp:446-484), OpenCV 4.x's classic fixed-point path restated (the CPU restatement's cv_warp_impl carries the derivation): the
+// matrix inverted in double precision, source coordinates in 1/32 pixel from integer adds (AB_BITS 10, INTER_BITS 5), four 15-bit integer
+// weights 32 a b (a, b in 0..32), result = (sum + 2^14) >> 15.  Integer work end to end:
+//   * one workgroup = one 64 x 64 output tile; the source footprint goes into LDS as BYTES, one dword {B,G,R,0} per pixel (the byte tile of
+//     the float bilinear kernel: 26 KB, 6 workgroups per CU), borders resolved in the copy;
+//   * per tile the column deltas adelta / bdelta (two double products, cvRound) and the row origins X0 / Y0 are computed ONCE per workgroup
+//     (one wave each) into LDS tables: per pixel the position is two integer adds;
 //   * per pixel and channel: two v_perm_b32 put the channel's bytes of a window row side by side as a u16 pair {v(x), v(x + 1)}, two
-//     v_dot2_u32_u16 against the row's weight pair {a0 b, a1 b} accumulate the four taps on top of the rounding constant, one shift.
-//     27 vector instructions per pixel in the sampler against the float bilinear's ~70.
+//     v_dot2_u32_u16 against the row's weight pair accumulate the four taps on top of the rounding constant; ~44 vector instructions per
+//     64 pixels in all against the float bilinear's 88.
+// 4K: 11.5 us per frame = 0.54 of the HBM peak (float bilinear 15.5 = 0.40); the what-if builds say the rest is how the memory operations are
+// structured, not instructions (profiles/r05_warp_cv.md).
 // Tiles whose footprint does not fit the window (large rotation / zoom) take a per-pixel global path in the same kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
 #ifndef VS_WARP_CV_TILE_H

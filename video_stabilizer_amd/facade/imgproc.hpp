@@ -217,9 +217,10 @@ inline bool ImageWarp(BIn& input, const SimilarityTransform& transform, BOut& ou
 // without WARP_INVERSE_MAP inverts the matrix it is given (imgproc.cpp:472), i.e. it samples the source at
 // transform^-1; bgr_image_warp takes the sampling map, so it receives transform.inverse().  The reference's
 // interpolation is OpenCV's fixed-point bilinear with a black border: VS_WARP_BILINEAR_CV restates exactly that (cv::warpAffine's own
-// matrix inversion included, so that mode receives `transform` itself); the default stays this build's float bilinear (generators.cpp:148-163).
+// matrix inversion included, so that mode receives `transform` itself) and is the default; VS_WARP_BILINEAR is the Halide sampler's float
+// lerp (generators.cpp:148-163), the VS_WARP_LANCZOS2 family bgr_image_warp.
 inline bool warpBySimilarityTransform(const uint8_t* src_bgr, int w, int h, const SimilarityTransform& transform, uint8_t* dst_bgr,
-                                      int mode = VS_WARP_BILINEAR, int border = VS_BORDER_CONSTANT) {
+                                      int mode = VS_WARP_BILINEAR_CV, int border = VS_BORDER_CONSTANT) {
     const SimilarityTransform sampling = mode == VS_WARP_BILINEAR_CV ? transform : transform.inverse();
     return vs_bgr_image_warp(src_bgr, w, h, w * 3, 3, 8, &sampling.c(), mode, border, 255, dst_bgr, w * 3, VS_MEM_HOST, nullptr) == 0;
 }
@@ -240,8 +241,8 @@ inline void require_bgr8(const cv::Mat& m, const char* who) {
 inline int mat_stride_elems(const cv::Mat& m) { return (int)(m.step / m.elemSize1()); }
 }  // namespace vs
 
-// imgproc.hpp:97 / imgproc.cpp:446-484.  Same defaults as the reference's call: bilinear, black border.
-inline cv::Mat warpBySimilarityTransform(const cv::Mat& src, const SimilarityTransform& transform, int mode = VS_WARP_BILINEAR,
+// imgproc.hpp:97 / imgproc.cpp:446-484.  Same defaults as the reference's call: cv::warpAffine's bilinear, black border.
+inline cv::Mat warpBySimilarityTransform(const cv::Mat& src, const SimilarityTransform& transform, int mode = VS_WARP_BILINEAR_CV,
                                          int border = VS_BORDER_CONSTANT) {
     vs::require_bgr8(src, "warpBySimilarityTransform");
     cv::Mat dst(src.rows, src.cols, CV_8UC3);

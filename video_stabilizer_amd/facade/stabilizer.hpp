@@ -14,7 +14,7 @@ struct VideoStabilizerParams {
     int crop_pixels = 32;
     double min_disp = 48.0, max_disp = 64.0;
     double min_decay = 0.9, max_decay = 0.7;
-    int warp_mode = VS_WARP_BILINEAR;     // cv::warpAffine(INTER_LINEAR) in the reference (imgproc.cpp:472); VS_WARP_LANCZOS2 = bgr_image_warp
+    int warp_mode = VS_WARP_BILINEAR_CV;  // cv::warpAffine(INTER_LINEAR) as the reference calls it (imgproc.cpp:472), fixed point; VS_WARP_LANCZOS2* = bgr_image_warp
     int warp_border = VS_BORDER_CONSTANT;
 };
 
