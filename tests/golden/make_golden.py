@@ -102,12 +102,26 @@ def warp_modes_fixture():
     np.savez_compressed(os.path.join(HERE, "warp_modes_96x64.npz"), **d)
 
 
+def warp_modes_r05_fixture():
+    """round 5: the separable member of the Lanczos2 family (VSO_WARP_LANCZOS2_SEPARABLE) and cv::warpAffine's fixed-point bilinear
+    (VSO_WARP_BILINEAR_CV: the transform is the FORWARD map there), 8- and 10-bit, both borders; the same frames and transform as the round-4 file"""
+    r4 = np.load(os.path.join(HERE, "warp_modes_96x64.npz"))
+    d = {"tw": r4["tw"]}
+    for border in (0, 1):
+        for name, mode in (("sep", O.WARP_LANCZOS2_SEPARABLE), ("cv", O.WARP_BILINEAR_CV)):
+            d["u8_%s_b%d" % (name, border)] = O.bgr_image_warp(r4["bgr8"], O.Transform.of(*r4["tw"]), mode, border)
+            d["u10_%s_b%d" % (name, border)] = O.bgr_image_warp(r4["bgr10"], O.Transform.of(*r4["tw"]), mode, border, max_value=1023)
+    np.savez_compressed(os.path.join(HERE, "warp_modes_r05_96x64.npz"), **d)
+
+
 if __name__ == "__main__":
-    if "--only-new" not in sys.argv:                # (the first three files are frozen: regenerate them only on purpose)
+    if "--only-new" not in sys.argv and "--only-r05" not in sys.argv:   # (the first three files are frozen: regenerate them only on purpose)
         kernels_fixture()
         aligner_fixture()
         stabilizer_fixture()
-    warp_modes_fixture()
+    if "--only-r05" not in sys.argv:
+        warp_modes_fixture()
+    warp_modes_r05_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -122,6 +122,31 @@ def test_oracle_reproduces_warp_modes_fixture(oracle):
     assert int(d["u10_m1_b0"].max()) > 255                  # (really 10-bit content)
 
 
+def _warp_modes_r05_outputs(m, d4, d5):
+    T = m.Transform.of
+    sep = getattr(m, "WARP_LANCZOS2_SEPARABLE", None) or m.WARP_LANCZOS2_SEP                # the oracle's / the product's name of mode 3
+    out = {}
+    for border in (0, 1):
+        for name, mode in (("sep", sep), ("cv", m.WARP_BILINEAR_CV)):
+            out["u8_%s_b%d" % (name, border)] = m.bgr_image_warp(d4["bgr8"], T(*d5["tw"]), mode, border)
+            out["u10_%s_b%d" % (name, border)] = m.bgr_image_warp(d4["bgr10"], T(*d5["tw"]), mode, border, max_value=1023)
+    return out
+
+
+def test_oracle_reproduces_warp_modes_r05_fixture(oracle):
+    """round-5 fixture: the separable Lanczos2 twin and cv::warpAffine's fixed-point bilinear, 8- and 10-bit, both borders"""
+    d4, d5 = np.load(os.path.join(G, "warp_modes_96x64.npz")), np.load(os.path.join(G, "warp_modes_r05_96x64.npz"))
+    for k, v in _warp_modes_r05_outputs(oracle, d4, d5).items():
+        assert np.array_equal(v, d5[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_matches_warp_modes_r05_fixture(gpu_vs):
+    d4, d5 = np.load(os.path.join(G, "warp_modes_96x64.npz")), np.load(os.path.join(G, "warp_modes_r05_96x64.npz"))
+    for k, v in _warp_modes_r05_outputs(gpu_vs, d4, d5).items():
+        assert np.array_equal(v, d5[k]), k
+
+
 @pytest.mark.gpu
 def test_gpu_matches_warp_modes_fixture(gpu_vs):
     d = np.load(os.path.join(G, "warp_modes_96x64.npz"))

@@ -400,6 +400,71 @@ def test_contracted_lanczos2_twin_equals_a_literal_restatement_with_exact_fma(or
     assert np.abs(ei - ki).max() <= 1
 
 
+def test_separable_lanczos2_twin_equals_a_literal_restatement_with_exact_fma(oracle):
+    # VSO_WARP_LANCZOS2_SEPARABLE = the contracted weights (fma Horner, generators.cpp:38-46) and the 4 x 4 live taps of generators.cpp:684-697,
+    # summed rows first, then columns: h[ry] = fma(wx4, v4, fma(wx3, v3, fma(wx2, v2, wx1 * v1))), num = fma(wy4, h4, ... wy1 * h1),
+    # den = ((wx1 + wx2) + (wx3 + wx4)) * ((wy1 + wy2) + (wy3 + wy4)), out = num * RN(1 / den).  Restated here with an fma and a reciprocal that
+    # are exact by construction (rationals, one rounding each), independent of std::fmaf, of the C compiler's divide and of the machine.
+    from fractions import Fraction as F
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return _round_f32(F(float(a)) * F(float(b)) + F(float(c)))
+
+    def lz(x):
+        x = f32(x)
+        x2 = f32(x * x)
+        v = f32(0.000858519)
+        for c in (-0.0158853, 0.128693, -0.583468, 1.52229, -2.05238, 0.999861):
+            v = fma(v, x2, f32(c))
+        return f32(0.0) if abs(x) >= 2.0 else v
+
+    rng = np.random.default_rng(12)
+    h, w = 7, 9
+    src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    src[2, 3] = (255, 0, 255)
+    src[3, 3] = (0, 255, 0)
+    for border in (oracle.BORDER_CLAMP, oracle.BORDER_CONSTANT):
+        for tr in ((0.03, -0.02, 0.7, -1.3), (0.0, 0.0, 1.0, -2.0)):          # (the second: every fraction exactly 0 -- tap 4's select at work)
+            t = oracle.Transform.of(*tr)
+            got = oracle.bgr_image_warp(src, t, oracle.WARP_LANCZOS2_SEPARABLE, border, f32=True)
+            A, B, TX, TY = (f32(v) for v in oracle.ul_params_warp(t, w, h))
+            A1 = f32(f32(1.0) + A)
+            for y in range(h):
+                for x in range(w):
+                    Wx = f32(f32(f32(A1 * f32(x)) - f32(B * f32(y))) + TX)      # generators.cpp:141 (the same positions as every other mode)
+                    Wy = f32(f32(f32(B * f32(x)) + f32(A1 * f32(y))) + TY)
+                    flx, fly = f32(np.floor(Wx)), f32(np.floor(Wy))
+                    frx, fry = f32(Wx - flx), f32(Wy - fly)
+                    wx = [lz(f32(f32(u - 1) - frx)) for u in range(4)]           # taps 1..4 of the 5-tap window (tap 0 weighs exactly 0)
+                    wy = [lz(f32(f32(u - 1) - fry)) for u in range(4)]
+                    den = f32(f32(f32(wx[0] + wx[1]) + f32(wx[2] + wx[3])) * f32(f32(wy[0] + wy[1]) + f32(wy[2] + wy[3])))
+                    rden = _round_f32(1 / F(float(den)))                           # the correctly rounded reciprocal
+                    for c in range(3):
+                        hrow = []
+                        for ry in range(4):
+                            v = []
+                            for rx in range(4):
+                                sx, sy = int(flx) + rx - 1, int(fly) + ry - 1
+                                if border == oracle.BORDER_CONSTANT and (sx < 0 or sy < 0 or sx >= w or sy >= h):
+                                    v.append(f32(0.0))
+                                else:
+                                    v.append(f32(src[min(max(sy, 0), h - 1), min(max(sx, 0), w - 1), c]))
+                            hrow.append(fma(wx[3], v[3], fma(wx[2], v[2], fma(wx[1], v[1], f32(wx[0] * v[0])))))
+                        num = fma(wy[3], hrow[3], fma(wy[2], hrow[2], fma(wy[1], hrow[1], f32(wy[0] * hrow[0]))))
+                        assert f32(num * rden) == got[y, x, c], (border, tr, y, x, c)
+    # ... a different function from the contracted and the un-contracted forms (else the twin would test nothing), within one LSB of both
+    big = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    t = oracle.Transform.of(0.01, 0.004, 2.3, -1.6)
+    e = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2, f32=True)
+    k = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2_CONTRACTED, f32=True)
+    sp = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2_SEPARABLE, f32=True)
+    assert not np.array_equal(sp, k) and not np.array_equal(sp, e) and np.abs(sp - e).max() < 1e-3
+    ei = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2).astype(int)
+    si = oracle.bgr_image_warp(big, t, oracle.WARP_LANCZOS2_SEPARABLE).astype(int)
+    assert np.abs(ei - si).max() <= 1
+
+
 def test_round_f32_helper():
     from fractions import Fraction as F
     rng = np.random.default_rng(5)

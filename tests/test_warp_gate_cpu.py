@@ -34,6 +34,10 @@ def test_integer_gate_contracted_vs_uncontracted(oracle, gate, bits, hi):
             ok, info = gate.integer_gate(contracted, exact)
             assert ok, (bits, tr, info)
             assert info["identical_fraction"] < 1.0 or tr[0] == 0.0      # the two forms ARE different functions
+            # ... and the separable member of the family (VS_WARP_LANCZOS2_SEP's twin), through the same gate against the UN-contracted order
+            separable = oracle.bgr_image_warp(f, t, oracle.WARP_LANCZOS2_SEPARABLE, max_value=hi)
+            ok, info = gate.integer_gate(separable, exact)
+            assert ok, ("separable", bits, tr, info)
 
 
 @pytest.mark.parametrize("bits", [8, 10])
