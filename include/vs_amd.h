@@ -37,13 +37,12 @@ enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
 /* Frame formats.  16-bit containers say how many bits the samples really use: the aligner derives its 8-bit luma with
  * gray >> (bits - 8) and the stabilizer's warp saturates at vs_format_max_value().  The reference itself is 8-bit only
  * (imgproc.cpp:207-209); BASELINE config 5 ("4K 10-bit BGR") is VS_FMT_BGR10.
- * VS_FMT_BGR16 is the format of the first release, kept with the behaviour it had there and a value of its own: a u16
- * container whose luma is taken as 10-bit (gray >> 2) while the warp saturates at 65535 -- callers that pass it with 12- or
- * 16-bit samples keep every sample value (it used to alias VS_FMT_BGR10 and clipped them to 1023). */
-enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR10 = 2, VS_FMT_BGR12 = 3, VS_FMT_BGR16_FULL = 4, VS_FMT_BGR16 = 5 };
-/* bits per sample the alignment luma assumes: 8, 10, 12 or 16 (VS_FMT_BGR16: 10); 0 for an unknown format */
+ * (ABI 5 retired VS_FMT_BGR16 = 5, the first release's "10-bit luma, 65535 saturation" format: value 5 is an unknown format now --
+ * declare the depth the samples really have.) */
+enum { VS_FMT_GRAY8 = 0, VS_FMT_BGR8 = 1, VS_FMT_BGR10 = 2, VS_FMT_BGR12 = 3, VS_FMT_BGR16_FULL = 4 };
+/* bits per sample the alignment luma assumes: 8, 10, 12 or 16; 0 for an unknown format */
 int vs_format_bits(int format);
-/* largest sample value the stabilizer's warp stores: 255, 1023, 4095, 65535 (VS_FMT_BGR16: 65535); 0 for an unknown format */
+/* largest sample value the stabilizer's warp stores: 255, 1023, 4095, 65535; 0 for an unknown format */
 int vs_format_max_value(int format);
 /* VS_WARP_LANCZOS2: the reference sampler's sequence of fp32 roundings with no contraction (bit-identical to the CPU
  * restatement's VSO_WARP_LANCZOS2).
@@ -111,11 +110,12 @@ typedef struct vs_stabilizer_params {
 
 const char* vs_last_error(void);
 const char* vs_version(void);
-/* ABI number of the structs and enums in this header.  It changes whenever a struct grows or an enum value moves (4: vs_align_info
- * carries selected_x / selected_y / level_transform, VS_FMT_BGR16 = 5).  The engine writes sizeof(vs_align_info) bytes per frame
+/* ABI number of the structs and enums in this header.  It changes whenever a struct grows, an enum value moves or a default changes its
+ * meaning (4: vs_align_info carries selected_x / selected_y / level_transform; 5: VS_FMT_BGR16 retired, VS_WARP_LANCZOS2_SEP = 3 and
+ * VS_WARP_BILINEAR_CV = 4 added, vs_stabilizer_params_default's warp_mode is VS_WARP_BILINEAR_CV).  The engine writes sizeof(vs_align_info) bytes per frame
  * into caller arrays, so a caller built against another header must not go on: check vs_abi_version() == VS_ABI_VERSION once
  * after loading the library (the facade classes do, and throw).  vs_sizeof_align_info() is the size the LIBRARY was built with. */
-#define VS_ABI_VERSION 4
+#define VS_ABI_VERSION 5
 int    vs_abi_version(void);
 size_t vs_sizeof_align_info(void);
 /* number of usable HIP devices (0 when there is none; never fails) */
@@ -377,7 +377,7 @@ typedef struct vs_stabilizer vs_stabilizer;
 vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params /* NULL = defaults */, int device);
 void vs_stabilizer_destroy(vs_stabilizer* s);
 /* VideoStabilizer::processFrame (stabilizer.hpp:39, stabilizer.cpp:9-117).  frame: interleaved BGR
- * u8 (VS_FMT_BGR8) or u16 (VS_FMT_BGR16).  out: (w-2*crop)*(h-2*crop)*3 elements, dense.
+ * u8 (VS_FMT_BGR8) or u16 (VS_FMT_BGR10 / BGR12 / BGR16_FULL).  out: (w-2*crop)*(h-2*crop)*3 elements, dense.
  * returns 1 when an output frame was written (0 for the first `lag` frames), <0 on error. */
 int  vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem,
                            void* out, int* out_w, int* out_h);

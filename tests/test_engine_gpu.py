@@ -278,8 +278,7 @@ def test_full_range_u16_through_the_batch_entry_points(gpu_vs):
     f10, _ = synth.make_clip(480, 270, 8, seed=73, channels=3, bits=10)
     frames = (f10.astype(np.uint32) << 6).astype(np.uint16)                 # full 16-bit range
     kw = dict(lag=2, crop_pixels=8, warp_mode=gpu_vs.WARP_LANCZOS2)
-    assert gpu_vs.FMT_BGR16 not in (gpu_vs.FMT_BGR10, gpu_vs.FMT_BGR12, gpu_vs.FMT_BGR16_FULL)
-    assert gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR16) == 65535 and gpu_vs.lib().vs_format_bits(gpu_vs.FMT_BGR16) == 10
+    assert gpu_vs.lib().vs_format_max_value(5) == 0 and gpu_vs.lib().vs_format_bits(5) == 0      # (ABI 5: the first release's VS_FMT_BGR16 is retired)
     assert gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR10) == 1023 and gpu_vs.lib().vs_format_max_value(gpu_vs.FMT_BGR16_FULL) == 65535
     # declared full range: batch == frame at a time, nothing clipped
     out_b, has_b = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames, fmt=gpu_vs.FMT_BGR16_FULL)
@@ -301,9 +300,9 @@ def test_full_range_u16_through_the_batch_entry_points(gpu_vs):
         assert bool(st_b[i]) == ok and t.tup() == ts_b[i].tup()
     st_c, ts_c = gpu_vs.Aligner(device=0).align_clips(frames, 1, fmt=gpu_vs.FMT_BGR16_FULL)
     assert st_c == st_b and [t.tup() for t in ts_c] == [t.tup() for t in ts_b]
-    # the first release's format: full-range output (not clipped to 1023)
-    out_l, has_l = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames, fmt=gpu_vs.FMT_BGR16)
-    assert has_l == has_b and int(out_l.max()) > 40000
+    # the first release's format value is an unknown format now
+    with pytest.raises(gpu_vs.VsError):
+        gpu_vs.Stabilizer(device=0, **kw).process_batch(frames, fmt=5)
     # undeclared u16 = 10-bit: saturates at 1023
     out_d, _ = gpu_vs.Stabilizer(device=0, **kw).process_batch(frames)
     assert int(out_d.max()) == 1023

@@ -86,11 +86,10 @@ def test_smoother_window_sizes(vs, oracle, lag, memory):
 
 def test_format_bits(vs, oracle):
     """16-bit containers carry their sample depth in the format (luma shift = bits - 8, warp saturation = vs_format_max_value)"""
-    want = {vs.FMT_GRAY8: 8, vs.FMT_BGR8: 8, vs.FMT_BGR10: 10, vs.FMT_BGR12: 12, vs.FMT_BGR16_FULL: 16, 6: 0, -1: 0}
+    want = {vs.FMT_GRAY8: 8, vs.FMT_BGR8: 8, vs.FMT_BGR10: 10, vs.FMT_BGR12: 12, vs.FMT_BGR16_FULL: 16, 5: 0, 6: 0, -1: 0}
     for f, b in want.items():
         assert vs.lib().vs_format_bits(f) == b
         assert oracle.lib().vso_format_bits(f) == b
         assert vs.lib().vs_format_max_value(f) == ((1 << b) - 1 if b else 0)
-    # the first release's VS_FMT_BGR16 is a format of its own again (it used to alias VS_FMT_BGR10 and clipped 12- / 16-bit
-    # samples to 1023): 10-bit luma, full-range warp output.  The oracle has no such format (its formats are the bit depths).
-    assert vs.FMT_BGR16 == 5 and vs.lib().vs_format_bits(vs.FMT_BGR16) == 10 and vs.lib().vs_format_max_value(vs.FMT_BGR16) == 65535
+    # (5 was the first release's VS_FMT_BGR16 -- 10-bit luma, 65535 saturation -- retired with ABI 5: an unknown format on both sides)
+    assert vs.lib().vs_abi_version() == 5

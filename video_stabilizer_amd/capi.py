@@ -17,12 +17,11 @@ LIB_PATH = os.environ.get("VS_AMD_LIB", os.path.join(_HERE, "libvs_amd.so"))
 MEM_HOST, MEM_DEVICE = 0, 1
 FMT_GRAY8, FMT_BGR8 = 0, 1
 FMT_BGR10, FMT_BGR12, FMT_BGR16_FULL = 2, 3, 4      # u16 containers: bits the samples use
-FMT_BGR16 = 5                                       # first-release format: 10-bit luma (gray >> 2), warp output saturates at 65535
 WARP_LANCZOS2, WARP_BILINEAR, WARP_LANCZOS2_FAST, WARP_LANCZOS2_SEP, WARP_BILINEAR_CV = 0, 1, 2, 3, 4
 BORDER_CLAMP, BORDER_CONSTANT = 0, 1
 SELECT_STL_HOST, SELECT_DEVICE, SELECT_STABLE = 0, 1, 2
 BATCH_EXCLUSIVE, BATCH_SHARED = 0, 1
-ABI_VERSION = 4                                     # VS_ABI_VERSION of include/vs_amd.h
+ABI_VERSION = 5                                     # VS_ABI_VERSION of include/vs_amd.h
 
 
 class Transform(C.Structure):

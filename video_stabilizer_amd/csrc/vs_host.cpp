@@ -30,14 +30,13 @@ size_t vs_sizeof_align_info(void) { return sizeof(vs_align_info); }
 int vs_format_bits(int format) {
     switch (format) {
         case VS_FMT_GRAY8: case VS_FMT_BGR8: return 8;
-        case VS_FMT_BGR10: case VS_FMT_BGR16: return 10;
+        case VS_FMT_BGR10: return 10;
         case VS_FMT_BGR12: return 12;
         case VS_FMT_BGR16_FULL: return 16;
         default: return 0;
     }
 }
 int vs_format_max_value(int format) {
-    if (format == VS_FMT_BGR16) return 65535;          // first-release behaviour: 10-bit luma, full-range warp output
     const int b = vs_format_bits(format);
     return b ? (1 << b) - 1 : 0;
 }
