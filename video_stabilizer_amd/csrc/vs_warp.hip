@@ -1150,8 +1150,10 @@ __device__ __forceinline__ void cv_pixel_global(const uint8_t* __restrict__ src,
 }
 
 // (Measured and dropped, profiles/r05_warp_cv.md: workgroups that walk several tiles with the next tile's tables computed and its source loads
-// in flight -- in registers -- while the current tile is sampled: no gain at any number of tiles per workgroup, and the registers it holds cost
-// occupancy (13.4 us per 4K frame against 11.5); fill items dealt over the tile's own column groups instead of the window's 20: no change.)
+// in flight -- in registers -- while the current tile is sampled.  Left to the scheduler the loads sink behind the sampling code and the 18
+// registers still cost occupancy (13.4 us per 4K frame against 11.5, the same at 1 / 2 / 4 / 8 tiles per workgroup); pinned early by
+// scheduling fences the kernel spills 17 registers at the 80 the occupancy allows and takes 17-22 us.  Fill items dealt over the tile's own
+// column groups instead of the window's 20, non-temporal stores: no change.)
 template <int BORDER>
 __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
                                                              const double* __restrict__ minv, uint8_t* __restrict__ dst, int dst_stride,
@@ -1251,6 +1253,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
 
     const int yw = y0 + wv * CV_RPW;                         // first row of this wave
     if (yw >= roi.h) return;                                 // wave-uniform
+    if (VS_WARP_WHATIF & 128) { if (tile_raw[threadIdx.x] == 0x12345678u) dst[threadIdx.x] = 1; return; }   // (analysis: loads + fill only)
     const int m = lane & 3;
     const bool rows_aligned = ((((uintptr_t)dst) | (uintptr_t)dst_stride) & 3) == 0;                      // uniform
     const bool lane_in = x < roi.w, quad_in = (x | 3) < roi.w;
@@ -1389,9 +1392,9 @@ hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bit
     const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
     for (int f0 = 0; f0 < n_frames; f0 += 65535) {         // gridDim.y limit
         const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
-        dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
         const uint8_t* sp = (const uint8_t*)src + (size_t)f0 * src_fs;
         uint8_t* dp = (uint8_t*)dst + (size_t)f0 * dst_fs;
+        dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
         if (border == 0)
             hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<0>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
                                tiles_x, magic, (int)tpf, chunk, roi);
