@@ -87,6 +87,39 @@ def test_cv_mode_16bit_containers(gpu_vs, oracle, bits, hi):
             assert np.array_equal(got, want), (bits, tr, border)
 
 
+def test_cv_mode_16bit_containers_ragged_sizes_mixed_depth_tiles_and_windows(gpu_vs, oracle):
+    """the tuned word-tile kernel: sizes that are not multiples of its 64 x 32 tile or of a pixel pair, unaligned rows, a frame whose samples stay
+    below 2^14 everywhere but in one corner (tiles there evaluate OpenCV's float expression as written, the others its exact integer form: both must
+    be the twin), 12-bit content, an output window"""
+    rng = np.random.default_rng(5)
+    for (h, w) in [(17, 65), (33, 130), (32, 64), (5, 7), (70, 201), (1, 1)]:
+        src = rng.integers(0, 4096, (h, w, 3), dtype=np.uint16)
+        for tr in TRANSFORMS[:2] + [(0.0, 0.0, 0.25, -0.75)]:
+            for border in (0, 1):
+                got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=border, max_value=4095)
+                want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border, max_value=4095)
+                assert np.array_equal(got, want), (h, w, tr, border)
+    src = rng.integers(0, 16384, (200, 300, 3), dtype=np.uint16)
+    src[150:, 200:] = rng.integers(0, 65536, (50, 100, 3), dtype=np.uint16)
+    src[10, 10] = (16383, 16384, 65535)                       # (the boundary itself)
+    for tr in TRANSFORMS[:3]:
+        got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=1, max_value=65535)
+        assert np.array_equal(got, oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=1, max_value=65535)), tr
+    frames = np.stack([src, src[::-1].copy()])
+    ts = [gpu_vs.Transform.of(*TRANSFORMS[0]), gpu_vs.Transform.of(*TRANSFORMS[6])]
+    full = gpu_vs.bgr_image_warp_batch(frames, ts, mode=gpu_vs.WARP_BILINEAR_CV, border=1, max_value=65535)
+    for roi in [(32, 32, 200, 100), (1, 3, 77, 40)]:
+        win = gpu_vs.bgr_image_warp_roi_batch(frames, ts, roi, mode=gpu_vs.WARP_BILINEAR_CV, border=1, max_value=65535)
+        x, y, rw, rh = roi
+        assert np.array_equal(win, full[:, y:y + rh, x:x + rw]), roi
+    # every exact half (the weights are multiples of 1/1024, so halves happen): cvRound rounds them to even in both forms
+    flat = np.zeros((40, 70, 3), np.uint16)
+    flat[:, ::2] = 1
+    got = gpu_vs.bgr_image_warp(flat, gpu_vs.Transform.of(0.0, 0.0, 0.5, 0.0), mode=gpu_vs.WARP_BILINEAR_CV, border=gpu_vs.BORDER_CONSTANT, max_value=1023)
+    assert np.array_equal(got, oracle.bgr_image_warp(flat, oracle.Transform.of(0.0, 0.0, 0.5, 0.0), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CONSTANT, max_value=1023))
+    assert got.max() == 0 and flat.max() == 1                  # 0.5 -> 0 (half to even), not 1
+
+
 def test_cv_mode_4k_frame(gpu_vs, oracle):
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(3840, 2160, 1, seed=2, channels=3)

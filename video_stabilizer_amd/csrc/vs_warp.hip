@@ -1318,6 +1318,192 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// VS_WARP_BILINEAR_CV on interleaved 16-bit containers (10 / 12 / 16-bit BGR): OpenCV's remapBilinear<Cast<float, ushort>> -- the same
+// fixed-point coordinates as the 8-bit path, FLOAT weights a b / 1024 (exact), result = cvRound(v00 w00 + v01 w01 + v10 w10 + v11 w11) with the
+// products and sums in float, left to right.  While every sample of a tile is below 2^14 each product (14 + 10 bits) and each partial sum
+// (<= the largest sample, 10 fraction bits) is EXACT in fp32, so the float expression equals the integer one: S = sum 32 a b v (< 2^29),
+// result = round-half-even(S / 2^15) -- and the tile takes the 8-bit kernel's v_perm / v_dot2_u32_u16 sampler on a word tile (8 bytes
+// {B | G << 16, R} per staged pixel: the float bilinear kernel's).  A tile that holds a sample >= 2^14 (full 16-bit content) evaluates the
+// float expression as written.  Tile 64 x 32 (28 KB of LDS); tables, footprint, stores as in the 8-bit kernel.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int CV16_TH = 32, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
+constexpr int CV16_FILL_SLOTS = (CV16_WS_H / 4 * (WS_W / 4) + 63) / 64;
+
+template <int BORDER>
+__device__ __forceinline__ void cv_pixel_global_u16(const uint16_t* __restrict__ src, int w, int h, int stride, int X, int Y, int maxv, uint32_t out[3]) {
+    const int sx = clampi(X >> 5, -32768, 32767), sy = clampi(Y >> 5, -32768, 32767);      // saturate_cast<short>
+    const int a1 = X & 31, b1 = Y & 31, a0 = 32 - a1, b0 = 32 - b1;
+    auto tap = [&](int xx, int yy, int c) -> float {
+        if (BORDER == 1) { if (xx < 0 || yy < 0 || xx >= w || yy >= h) return 0.0f; }
+        else { xx = clampi(xx, 0, w - 1); yy = clampi(yy, 0, h - 1); }
+        return (float)src[(size_t)yy * stride + (size_t)xx * 3 + c];
+    };
+    const float k = 1.0f / 1024.0f;
+    const float w00 = (float)(a0 * b0) * k, w01 = (float)(a1 * b0) * k, w10 = (float)(a0 * b1) * k, w11 = (float)(a1 * b1) * k;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float sum = tap(sx, sy, c) * w00 + tap(sx + 1, sy, c) * w01 + tap(sx, sy + 1, c) * w10 + tap(sx + 1, sy + 1, c) * w11;
+        out[c] = (uint32_t)min(max((int)rintf(sum), 0), maxv);
+    }
+}
+
+template <int BORDER>
+__global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t* __restrict__ src, int w, int h, int src_stride,
+                                                                 const double* __restrict__ minv, uint16_t* __restrict__ dst, int dst_stride,
+                                                                 size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
+                                                                 int chunk, int maxv, vsk::Roi roi) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV16_WS_H * WS_RS8 * 2];      // {B | G << 16, R} per staged source pixel
+    __shared__ __attribute__((aligned(16))) int cv_tab[128 + 2 * CV16_TH];                   // adelta[64] | bdelta[64] | X0[32] | Y0[32]
+    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
+    const int frame = blockIdx.y;
+    const double* M = minv + 6 * (size_t)frame;
+    src += (size_t)frame * src_fs;
+    dst += (size_t)frame * dst_fs;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);
+    const int txi = tl - tyi * tiles_x;
+    const int x0 = txi * WT_W, y0 = tyi * CV16_TH;
+    const int nx = min(WT_W, roi.w - x0), ny = min(CV16_TH, roi.h - y0);
+    const int x = x0 + lane;
+    const int fxq = min(x, roi.w - 1) + roi.x;
+    if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
+    else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
+    else if (wv == 2) {
+        const int r = lane & 31, fyq = min(y0 + r, roi.h - 1) + roi.y;
+        cv_tab[128 + (lane < 32 ? 0 : CV16_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+    }
+    __syncthreads();
+    const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
+    const long long adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
+    const long long bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
+    const long long XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
+    const long long YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH + ny - 1]);
+    const long long mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
+    const long long mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
+    bool fits = mnX > -(1LL << 24) && mxX < (1LL << 24) && mnY > -(1LL << 24) && mxY < (1LL << 24);
+    int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
+    if (fits) {
+        sx_lo = (int)(mnX >> 10) & ~3;
+        const int sx_hi = (int)(mxX >> 10) + 1;
+        sy_lo = (int)(mnY >> 10);
+        const int sy_hi = (int)(mxY >> 10) + 1;
+        rows = sy_hi - sy_lo + 1;
+        groups = (sx_hi - sx_lo + 4) >> 2;
+        fits = groups <= WS_W / 4 && rows <= CV16_WS_H;
+    }
+    const bool src_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * 2)) & 3) == 0;                // uniform
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t seen = 0;                                       // OR of every staged sample (as packed pairs): bits 14 / 15 of a half set = a sample >= 2^14
+    if (fits) {
+        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;
+        u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
+        FillItem it[CV16_FILL_SLOTS];
+        bool live[CV16_FILL_SLOTS], direct[CV16_FILL_SLOTS];
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            it[s] = fill_item(lane, wv + 4 * s);
+            live[s] = it[s].row < rows && it[s].g < groups;
+            const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+            direct[s] = live[s] && (interior || (src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h));
+            if (direct[s]) {
+                const uint16_t* gp = src + (size_t)sy * src_stride + (size_t)sx * 3;
+                qa[s] = *(const u32x3*)gp;
+                qb[s] = *(const u32x3*)(gp + 6);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            u32x4 lo, hi;                                       // pixels 0, 1 and 2, 3 of the group as {B | G << 16, R}
+            if (direct[s]) {
+                const u32x3 a = qa[s], b = qb[s];               // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
+                lo = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
+                hi = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
+                seen |= a.x | a.y | a.z | b.x | b.y | b.z;
+            } else {
+                const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
+                uint32_t d[4][2];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int pxi = sx + k;
+                    if (BORDER == 1 && (sy < 0 || sy >= h || pxi < 0 || pxi >= w)) d[k][0] = d[k][1] = 0u;
+                    else {
+                        const uint16_t* qq = src + (size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(pxi, 0, w - 1) * 3;
+                        d[k][0] = (uint32_t)qq[0] | ((uint32_t)qq[1] << 16);
+                        d[k][1] = (uint32_t)qq[2];
+                    }
+                    seen |= d[k][0] | d[k][1];
+                }
+                lo = u32x4{d[0][0], d[0][1], d[1][0], d[1][1]};
+                hi = u32x4{d[2][0], d[2][1], d[3][0], d[3][1]};
+            }
+            VS_BOUNDS_CHECK((it[s].row * WS_RS8 + 4 * it[s].g + 3) * 2 + 1, CV16_WS_H * WS_RS8 * 2, 215);
+            u32x4* dstp = (u32x4*)(tile_raw + 2 * VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, CV16_WS_H * WS_RS8 - 3));
+            dstp[0] = lo;
+            dstp[1] = hi;
+        }
+    }
+    // (barrier) ... and does ANY staged sample of the tile reach 2^14?  Then the float expression is not exact and is evaluated as written.
+    const bool wide = __syncthreads_or((int)((seen & 0xc000c000u) != 0u)) != 0;
+
+    const int yw = y0 + wv * CV16_RPW;
+    if (yw >= roi.h) return;                                 // wave-uniform
+    const bool rows_aligned = ((((uintptr_t)dst) | ((uintptr_t)dst_stride * 2)) & 3) == 0;               // uniform
+    const bool lane_in = x < roi.w, pair_in = (x | 1) < roi.w;
+    const int base8 = -8 * (sy_lo * WS_RS8 + sx_lo);       // LDS byte address of staged pixel (sy, sx) = 8 * ((sy - sy_lo) * WS_RS8 + (sx - sx_lo))
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 2
+    for (int k = 0; k < CV16_RPW; k++) {
+        const int y = yw + k;
+        if (y >= roi.h) break;                               // wave-uniform
+        const uint32_t Xs = (uint32_t)cv_tab[128 + wv * CV16_RPW + k] + (uint32_t)ad, Ys = (uint32_t)cv_tab[128 + CV16_TH + wv * CV16_RPW + k] + (uint32_t)bd;
+        uint32_t o[3] = {0u, 0u, 0u};
+        if (!fits) {
+            if (lane_in) cv_pixel_global_u16<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, maxv, o);
+        } else {
+            const uint32_t fx = (Xs >> 5) & 31u, fy = (Ys >> 5) & 31u;
+            const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (8 * WS_RS8) + ((((int)Xs >> 7) & ~7) + base8), 8 * (CV16_WS_H * WS_RS8 - (WS_RS8 + 2)), 216);
+            const __attribute__((address_space(3))) u32x2* t = (const __attribute__((address_space(3))) u32x2*)((const __attribute__((address_space(3))) char*)tile_raw + off);
+            const u32x2 p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+            if (!wide) {                                     // (uniform) every sample < 2^14: the integer form of the same value
+                const uint32_t apair = fx * 0xffffu + 32u;                      // (32 - fx) | fx << 16
+                const uint32_t wb = apair * (fy << 5), wt = (apair << 10) - wb; // {32 a0 b | 32 a1 b << 16}
+                const uint32_t top[3] = {__builtin_amdgcn_perm(p01.x, p00.x, 0x05040100u), __builtin_amdgcn_perm(p01.x, p00.x, 0x07060302u), __builtin_amdgcn_perm(p01.y, p00.y, 0x05040100u)};
+                const uint32_t bot[3] = {__builtin_amdgcn_perm(p11.x, p10.x, 0x05040100u), __builtin_amdgcn_perm(p11.x, p10.x, 0x07060302u), __builtin_amdgcn_perm(p11.y, p10.y, 0x05040100u)};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t S = udot2(bot[c], wb, udot2(top[c], wt, 0u));         // = 2^15 x the float sum, exactly
+                    o[c] = min((S + 16383u + ((S >> 15) & 1u)) >> 15, (uint32_t)maxv);   // cvRound: half to even
+                }
+            } else {
+                const float kk = 1.0f / 1024.0f;
+                const float w00 = (float)((32u - fx) * (32u - fy)) * kk, w01 = (float)(fx * (32u - fy)) * kk, w10 = (float)((32u - fx) * fy) * kk, w11 = (float)(fx * fy) * kk;
+                const uint32_t v00[3] = {p00.x & 0xffffu, p00.x >> 16, p00.y & 0xffffu}, v01[3] = {p01.x & 0xffffu, p01.x >> 16, p01.y & 0xffffu};
+                const uint32_t v10[3] = {p10.x & 0xffffu, p10.x >> 16, p10.y & 0xffffu}, v11[3] = {p11.x & 0xffffu, p11.x >> 16, p11.y & 0xffffu};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float sum = (float)v00[c] * w00 + (float)v01[c] * w01 + (float)v10[c] * w10 + (float)v11[c] * w11;
+                    o[c] = (uint32_t)min(max((int)rintf(sum), 0), maxv);
+                }
+            }
+        }
+        uint32_t d0, d1;
+        pair_pack_bgr16(o, x & 1, d0, d1);
+        uint16_t* orow = dst + (size_t)y * dst_stride;
+        if (rows_aligned && pair_in) {
+            uint32_t* q = (uint32_t*)(orow + (size_t)(x & ~1) * 3);   // 12 bytes per pixel pair
+            if (x & 1) VS_STORE32(q + 2, d0);
+            else { VS_STORE32(q, d0); VS_STORE32(q + 1, d1); }
+        } else if (lane_in) {
+            orow[(size_t)x * 3] = (uint16_t)o[0];
+            orow[(size_t)x * 3 + 1] = (uint16_t)o[1];
+            orow[(size_t)x * 3 + 2] = (uint16_t)o[2];
+        }
+    }
+}
+
 }  // namespace
 
 VS_BOUNDS_TU(vs_bounds_fetch_warp)
@@ -1384,6 +1570,27 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
 
 hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int border, int max_value, void* dst,
                           int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
+    if (bits == 16) {                                        // 10 / 12 / 16-bit containers: the word-tile kernel
+        if (max_value < 0 || max_value > 65535) return hipErrorNotSupported;
+        const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + CV16_TH - 1) / CV16_TH;
+        const long long tpf = (long long)tiles_x * tiles_y;
+        if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
+        const int chunk = (int)((tpf + 7) / 8);
+        const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
+        for (int f0 = 0; f0 < n_frames; f0 += 65535) {
+            const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+            dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
+            const uint16_t* sp = (const uint16_t*)src + (size_t)f0 * src_fs;
+            uint16_t* dp = (uint16_t*)dst + (size_t)f0 * dst_fs;
+            if (border == 0)
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<0>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
+            else
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<1>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
+        }
+        return hipGetLastError();
+    }
     if (bits != 8 || max_value != 255) return hipErrorNotSupported;          // (results never exceed 255: the weights sum to 1024)
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + CV_TH - 1) / CV_TH;
     const long long tpf = (long long)tiles_x * tiles_y;
