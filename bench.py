@@ -820,6 +820,12 @@ def main():
             dt_f, good_f = timed_loop(lambda: aw.step(False, m), args.steps)
             dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
             others[name] = (dt_f, good_f)
+        # ... and with the warp the reference's stabilizer actually runs per frame (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99): the
+        # fixed-point bilinear, VS_WARP_BILINEAR_CV -- the step is then bound by the alignment pass, not by the warp
+        aw.step(False, capi.WARP_BILINEAR_CV)
+        dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_BILINEAR_CV), args.steps)
+        dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
+        others["bilinear_cv"] = (dt_f, good_f)
 
     stable = None
     if aw and not args.no_warp and args.select == "device":
@@ -888,7 +894,9 @@ def main():
                          "VSO_WARP_LANCZOS2): the figure to compare across rounds (rounds 1-3 reported it as `value`)",
                 "contracted": "VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as the reference's own target allows "
                               "(CMakeLists.txt:151 fma, no strict_float): round 4's `value`",
-                "separable": "VS_WARP_LANCZOS2_SEP = the contracted weights and taps summed rows first, then columns"}
+                "separable": "VS_WARP_LANCZOS2_SEP = the contracted weights and taps summed rows first, then columns",
+                "bilinear_cv": "VS_WARP_BILINEAR_CV = cv::warpAffine's fixed-point bilinear, the warp the reference's stabilizer runs per frame "
+                               "(stabilizer.cpp:97-99) and this library's default stabilizer warp: not a Lanczos2 bgr_image_warp, so never `value`"}
         for name, (dt_f, good_f) in others.items():
             out[name + "_warp"] = {"value": round(good_f / dt_f, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_f / args.steps, 4),
                                    "note": "same step (one loop, after the pre-roll) with bgr_image_warp in " + what[name]}
@@ -1039,6 +1047,17 @@ def main():
             for key in WARP_MODES:
                 if key != args.warp_mode:
                     out["c5"][key + "_warp"] = {"value": round(nc5 * n5 * steps5 / res5[key][0], 2), "ms_per_step": round(1e3 * res5[key][0] / steps5, 4)}
+            # the same loop with the LIBRARY DEFAULTS: cv::warpAffine's fixed-point bilinear (VS_WARP_BILINEAR_CV), black border -- what
+            # stabilizer.cpp:97-99 does with every frame (on 10-bit frames: OpenCV's float-weight form, the word-tile kernel)
+            st5 = capi.Stabilizer(device=local_rank, **params_kw)
+
+            def step5d():
+                return st5.process_clips_device(frames5.data_ptr(), nc5, n5, W5, H5, capi.FMT_BGR10, out5.data_ptr())[0]
+            step5d()
+            dt5d, _ = timed_loop(step5d, steps5)
+            out["c5"]["default_warp"] = {"value": round(nc5 * n5 * steps5 / dt5d, 2), "ms_per_step": round(1e3 * dt5d / steps5, 4),
+                                         "warp": "library defaults: VS_WARP_BILINEAR_CV (cv::warpAffine INTER_LINEAR restated), constant border"}
+            del st5
             del frames5, out5
             torch.cuda.empty_cache()
         except Exception as e:

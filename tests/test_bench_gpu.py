@@ -56,6 +56,8 @@ def test_bench_line_contract(gpu_vs):
     assert j["value_warp_mode"] == "separable" and "separable" in j["config"]["warp"] and "separable" in r["kernel"]
     assert j["config"]["select_mode_in_force"] == 1
     assert j["exact_warp"]["value"] > 0 and j["contracted_warp"]["value"] > 0 and "separable_warp" not in j and j["stable_select"]["value"] > 0
+    assert j["bilinear_cv_warp"]["value"] > j["value"]              # the reference's own per-frame warp: the step is alignment-bound with it
+    assert j["roofline_4k"]["bilinear_cv"]["achieved"] > j["roofline_4k"]["bilinear"]["achieved"]
     for key in ("separable_vs_exact", "contracted_vs_exact"):
         g = p[key]
         assert g["pass"] is True and g["max_abs_diff_lsb"] <= 1 and g["least_identical_fraction"] >= 0.9999, key
@@ -73,7 +75,7 @@ def test_bench_line_contract(gpu_vs):
     # BASELINE configs[4]: 4K 10-bit, full stabilizer loop (2 of the 8 clips per GPU here)
     c5 = j["c5"]
     assert "error" not in c5 and c5["value"] > 0 and c5["dtype"] == "u16" and c5["frames_per_step"] == 2 * 60
-    assert c5["outputs_per_step"] == 2 * 50 and c5["exact_warp"]["value"] > 0 and c5["contracted_warp"]["value"] > 0 and "property-checked" in c5["note"]
+    assert c5["outputs_per_step"] == 2 * 50 and c5["exact_warp"]["value"] > 0 and c5["contracted_warp"]["value"] > 0 and "property-checked" in c5["note"] and c5["default_warp"]["value"] > 0
     # the reference's per-frame call pattern on host frames, beside the oracle making the same calls
     for res in ("1080p", "2160p"):
         d = j["drop_in"][res]

@@ -60,7 +60,9 @@ def test_selection_warp_phase_and_config_tests_pass_on_the_bounds_build_with_a_c
     (The WHOLE -m gpu suite has been run against this build once per round: profiles/r04_bounds_build.md.)"""
     # (every fresh device allocation of these runs starts filled with 0xA5: nothing compared against the oracle may depend on it)
     env = dict(os.environ, VS_AMD_LIB=bounds_lib, VS_BOUNDS_BUILD="1", VS_TEST_POISON_ALLOC="165", VS_TEST_HOOKS="1")
-    runs = [(["tests/test_select_gpu.py", "tests/test_select_stable_gpu.py", "tests/test_warp_fast_gpu.py", "tests/test_phase_gpu.py",
+    # (round 5: the separable Lanczos2 tests replace the contracted ones -- the two forms share the tile, fill and store code, the sweeps below still
+    # draw all three -- and the fixed-point bilinear kernels' tests join: byte / word tiles, coordinate tables, sites 211-216)
+    runs = [(["tests/test_select_gpu.py", "tests/test_select_stable_gpu.py", "tests/test_warp_sep_gpu.py", "tests/test_warp_cv_gpu.py", "tests/test_phase_gpu.py",
               "tests/test_warp_sweep_gpu.py", "tests/test_kernel_chain_sweep_gpu.py", "tests/test_engine_sweep_gpu.py"], None),
             (["tests/test_latency_mode_gpu.py", "tests/test_configs_gpu.py"],
              "coresident_build_at_4k or sixteen_pairs or c3_4k_bgr_lanczos2_warp or c5_one_gpus_share")]

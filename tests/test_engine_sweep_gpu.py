@@ -57,7 +57,7 @@ def test_random_stabilizer_configuration_matches_the_oracle(gpu_vs, oracle, seed
     bits = int(rng.choice([8, 8, 10]))
     crop = int(rng.integers(0, min(w, h) // 5))
     kw = dict(lag=int(rng.integers(1, 7)), smoother_memory=int(rng.integers(0, 6)), crop_pixels=crop,
-              enable_smoother=int(rng.integers(0, 2)), warp_mode=int(rng.choice([gpu_vs.WARP_LANCZOS2, gpu_vs.WARP_BILINEAR, gpu_vs.WARP_LANCZOS2_FAST])),
+              enable_smoother=int(rng.integers(0, 2)), warp_mode=int(rng.choice([gpu_vs.WARP_LANCZOS2, gpu_vs.WARP_BILINEAR, gpu_vs.WARP_LANCZOS2_FAST, gpu_vs.WARP_LANCZOS2_SEP, gpu_vs.WARP_BILINEAR_CV])),
               warp_border=int(rng.integers(0, 2)), min_disp=float(rng.choice([0.5, 2.0])), max_disp=float(rng.choice([8.0, 40.0])))
     kw["lambda"] = float(rng.choice([0.5, 2.0, 8.0]))
     n = 14
@@ -126,7 +126,7 @@ def test_random_batch_forms_equal_frame_at_a_time(gpu_vs, seed):
         assert ts[i].tup() == ref[i][1].tup(), (i, n, cut, mode)
     if ch == 3 and n <= 20:
         skw = dict(lag=int(rng.integers(1, 5)), smoother_memory=int(rng.integers(0, 4)), crop_pixels=int(rng.integers(0, 20)),
-                   warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)), **kw)
+                   warp_mode=int(rng.integers(0, 5)), warp_border=int(rng.integers(0, 2)), **kw)
         seq = gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
         outs = [seq.process(f) for f in frames]
         sb = gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
@@ -153,7 +153,7 @@ def test_random_clip_batches_equal_fresh_handles(gpu_vs, seed):
     if n_clips == 1:
         fpc = int(rng.choice([100, 131, 200]))                    # one long clip: the time-chunk path (>= 96 frames)
     skw = dict(lag=int(rng.integers(1, 6)), smoother_memory=int(rng.integers(0, 4)), crop_pixels=int(rng.integers(0, 16)),
-               warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)),
+               warp_mode=int(rng.integers(0, 5)), warp_border=int(rng.integers(0, 2)),
                pyramid_min_width=int(rng.integers(16, w // 4)), pyramid_min_height=int(rng.integers(12, h // 4)))
     base = [synth.make_clip(w, h, min(fpc, 10), seed=6000 + 10 * seed + c, channels=3, bits=bits, jitter_t=float(rng.choice([1.0, 4.0])))[0]
             for c in range(n_clips)]
@@ -329,7 +329,7 @@ def test_stabilizer_on_degenerate_sequences_and_deep_formats_matches_the_oracle(
         else: clip[i] = hi                                                  # saturated
     m = min(w, h)
     kw = dict(lag=int(rng.integers(1, 5)), smoother_memory=int(rng.integers(0, 4)), crop_pixels=int(rng.integers(0, max(1, m // 6))),
-              warp_mode=int(rng.integers(0, 3)), warp_border=int(rng.integers(0, 2)),
+              warp_mode=int(rng.integers(0, 5)), warp_border=int(rng.integers(0, 2)),
               pyramid_min_width=max(8, w // int(rng.choice([4, 8, 16]))), pyramid_min_height=max(8, h // int(rng.choice([4, 8, 16]))))
     g, c = gpu_vs.Stabilizer(device=0, **kw), oracle.Stabilizer(**kw)
     for i, f in enumerate(clip):
@@ -354,7 +354,7 @@ def test_one_long_lived_handle_through_random_call_sequences(gpu_vs, seed):
     from video_stabilizer_amd import synth
     rng = np.random.default_rng(147000 + seed)
     kw = dict(pyramid_min_width=24, pyramid_min_height=18)
-    skw = dict(lag=int(rng.integers(1, 4)), crop_pixels=int(rng.integers(0, 8)), warp_mode=int(rng.integers(0, 3)), **kw)
+    skw = dict(lag=int(rng.integers(1, 4)), crop_pixels=int(rng.integers(0, 8)), warp_mode=int(rng.integers(0, 5)), **kw)
     mode = int(rng.integers(0, 3))
     A, S = gpu_vs.Aligner(device=0, select_mode=mode, **kw), gpu_vs.Stabilizer(device=0, select_mode=mode, **skw)
     fa = fs = None                                   # the fresh shadows, rebuilt at every restart
