@@ -1,0 +1,8 @@
+O=gpurun_out/r5o; mkdir -p $O
+python -m pytest tests/test_warp_cv_gpu.py tests/test_golden.py -x -q -m gpu > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+tail -1 $O/tests.log
+for rep in 1 2 3; do
+  python tools/warp_bench.py --mode cv --frames 32 --border constant | tee -a $O/ab.txt
+  python tools/warp_bench.py --mode cv --w 1920 --h 1080 --frames 240 --border constant | tee -a $O/ab.txt
+done
+VS_AMD_LIB=$PWD/video_stabilizer_amd/variants/libvs_amd_stamps.so python tools/warp_stamps.py --mode cv --frames 4 | tee $O/stamps.json

@@ -38,7 +38,7 @@ def main():
     dst = torch.empty_like(src)
     tr = [float(v) for v in args.transform.split(",")]
     ts = [capi.Transform.of(tr[0], tr[1], tr[2] + 0.37 * i, tr[3] - 0.21 * i) for i in range(n)]
-    mode = {"lanczos2": capi.WARP_LANCZOS2, "bilinear": capi.WARP_BILINEAR, "fast": capi.WARP_LANCZOS2_FAST}[args.mode]
+    mode = {"lanczos2": capi.WARP_LANCZOS2, "bilinear": capi.WARP_BILINEAR, "fast": capi.WARP_LANCZOS2_FAST, "sep": capi.WARP_LANCZOS2_SEP, "cv": capi.WARP_BILINEAR_CV}[args.mode]
     st = torch.cuda.current_stream()
 
     def run():

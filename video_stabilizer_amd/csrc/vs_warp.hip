@@ -1122,6 +1122,12 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 // structured, not instructions (profiles/r05_warp_cv.md).
 // Tiles whose footprint does not fit the window (large rotation / zoom) take a per-pixel global path in the same kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef VS_WARP_CV_CLAMPED_FILL
+#define VS_WARP_CV_CLAMPED_FILL 0        // interior fill: 1 = items beyond the tile's rows / groups are clamped (no predicates, redundant loads), 0 = predicated
+#endif
+#ifndef VS_WARP_CV_PERM_PACK
+#define VS_WARP_CV_PERM_PACK 1           // sampler: 1 = the three samples are packed with two v_perm, 0 = with and / or
+#endif
 #ifndef VS_WARP_CV_TILE_H
 #define VS_WARP_CV_TILE_H 64             // output rows per workgroup (a multiple of 32: the row-origin table is filled 32 rows per wave pass)
 #endif
@@ -1165,9 +1171,17 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     // so each is made ONCE per workgroup -- wave 0 the column deltas a, wave 1 the column deltas b, waves 2 (and 3) the row origins -- and
     // read back by everyone after a barrier (computed per wave they were a third of the kernel's time)
     __shared__ __attribute__((aligned(16))) int cv_tab[128 + 2 * CV_TH];
+#ifdef VS_WARP_LDS_PAD
+    __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
+    if (w < 0) lds_pad[threadIdx.x] = 0;
+#endif
     // XCD-aware tile order, as in vs_k_bgr_warp_c3: every XCD walks one contiguous run of tiles in raster order
     const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
+#if VS_WARP_STAMPS
+    unsigned long long stamp[STAMP_N] = {};
+    VS_STAMP(0);
+#endif
     const int frame = blockIdx.y;
     const double* M = minv + 6 * (size_t)frame;
     src += (size_t)frame * src_fs;
@@ -1189,28 +1203,71 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     __syncthreads();
     const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
     // source footprint: X0[y] and adelta[x] are monotone (cvRound of a monotone function), so the extremes sit at the tile's corners
-    const long long adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
-    const long long bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
-    const long long XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
-    const long long YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH + ny - 1]);
-    const long long mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
-    const long long mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
-    // (|position| < 2^14 pixels in 10-bit fixed point: no wrap in X0 + adelta, no saturate_cast<short> at work, window arithmetic in range)
-    bool fits = mnX > -(1LL << 24) && mxX < (1LL << 24) && mnY > -(1LL << 24) && mxY < (1LL << 24);
+    // (each table entry is within +-2^29 or the tile does not "fit": the sums below stay inside 32 bits, and a tile that passes is far from the
+    // wrap in X0 + adelta and from saturate_cast<short>)
+    const int adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
+    const int bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
+    const int XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
+    const int YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH + ny - 1]);
+    const int lim = 1 << 23;                                 // |X0|, |adelta| < 2^23 in 10-bit fixed point = 2^13 pixels each
+    bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
+    const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
+    const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
     if (fits) {
-        sx_lo = (int)(mnX >> 10) & ~3;                         // first staged column: a multiple of 4 pixels (12 bytes)
-        const int sx_hi = (int)(mxX >> 10) + 1;
-        sy_lo = (int)(mnY >> 10);
-        const int sy_hi = (int)(mxY >> 10) + 1;
+        sx_lo = (mnX >> 10) & ~3;                              // first staged column: a multiple of 4 pixels (12 bytes)
+        const int sx_hi = (mxX >> 10) + 1;
+        sy_lo = mnY >> 10;
+        const int sy_hi = (mxY >> 10) + 1;
         rows = sy_hi - sy_lo + 1;
         groups = (sx_hi - sx_lo + 4) >> 2;
         fits = groups <= WS_W / 4 && rows <= CV_WS_H;
     }
     const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)src_stride) & 3) == 0;                      // uniform
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    if (fits && !(VS_WARP_WHATIF & 2)) {
-        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;
+    VS_STAMP(1);
+    const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
+                          (size_t)h * (size_t)src_stride < (1ull << 32);                                    // uniform
+    if (interior && !(VS_WARP_WHATIF & 2)) {
+        // Interior tiles (the whole staged window inside an aligned frame: all but the frame's rim): every address is one 24-bit multiply-add
+        // from a uniform base, no border tests.  (VS_WARP_CV_CLAMPED_FILL=1 also drops the live-item predicates by clamping the items beyond
+        // the tile's own rows / column groups onto its last row / group: the ~28 % redundant loads cost more than the branches, 12.1 us per
+        // 4K frame against 11.1.)
+        u32x3 q[CV_FILL_SLOTS];
+        uint32_t toff[CV_FILL_SLOTS];
+        bool live[CV_FILL_SLOTS];
+        const uint8_t* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {              // every load is issued before the first tile write
+            const FillItem it = fill_item(lane, wv + 4 * s);
+            live[s] = it.row < rows && it.g < groups;
+#if VS_WARP_CV_CLAMPED_FILL
+            const uint32_t r = min((uint32_t)it.row, (uint32_t)(rows - 1)), g = min((uint32_t)it.g, (uint32_t)(groups - 1));
+            q[s] = *(const u32x3*)(base + (__umul24(r, (uint32_t)src_stride) + 12u * g));
+#else
+            if (live[s]) q[s] = *(const u32x3*)(base + (__umul24((uint32_t)it.row, (uint32_t)src_stride) + 12u * (uint32_t)it.g));
+#endif
+            toff[s] = (uint32_t)it.row * (uint32_t)WS_RS8 + 4u * (uint32_t)it.g;
+        }
+        VS_STAMP(2);
+        VS_STAMP_DRAIN();
+        VS_STAMP(3);
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {
+#if VS_WARP_CV_CLAMPED_FILL
+            if (CV_WS_H / 4 * (WS_W / 4) < 64 * (s + 1) && toff[s] > (uint32_t)(CV_WS_H * WS_RS8 - 4)) continue;   // (only the last slot has items beyond the tile array)
+#else
+            if (!live[s]) continue;
+#endif
+            u32x4 px;                                           // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
+            px.x = q[s].x & 0x00ffffffu;
+            px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
+            px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
+            px.w = q[s].z >> 8;
+            VS_BOUNDS_CHECK(toff[s] + 3, CV_WS_H * WS_RS8, 217);
+            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(toff[s], CV_WS_H * WS_RS8 - 3)) = px;
+        }
+    } else if (fits && !(VS_WARP_WHATIF & 2)) {
         u32x3 q[CV_FILL_SLOTS];
         FillItem it[CV_FILL_SLOTS];
         bool live[CV_FILL_SLOTS], direct[CV_FILL_SLOTS];
@@ -1219,7 +1276,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             it[s] = fill_item(lane, wv + 4 * s);
             live[s] = it[s].row < rows && it[s].g < groups;
             const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
-            direct[s] = live[s] && (interior || (src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h));
+            direct[s] = live[s] && src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h;
             if (direct[s]) q[s] = *(const u32x3*)(src + (size_t)sy * src_stride + (size_t)sx * 3);
         }
 #pragma unroll
@@ -1249,7 +1306,9 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, CV_WS_H * WS_RS8 - 3)) = px;
         }
     }
+    VS_STAMP(4);
     __syncthreads();
+    VS_STAMP(5);
 
     const int yw = y0 + wv * CV_RPW;                         // first row of this wave
     if (yw >= roi.h) return;                                 // wave-uniform
@@ -1264,10 +1323,13 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     // v_bfe, v_add3, v_lshl_or, and v_mul_u32_u24 -- issue at 4.2-4.35 cycles per wave per SIMD, two-operand shifts / and / add at 2.3-2.6): the
     // weights are OpenCV's own 15-bit ones, 32 a b (<= 32768: a u16), so that fy enters as (Ys & 0x3e0) = 32 fy without a bit-field extract
     // and the top row's pair is (apair << 10) - bottom pair instead of a second multiply; result = (sum + 2^14) >> 15 as in the source.
+    // (the window's origin is folded into the lane's column delta once per tile: base4 is a multiple of 4, so base4 << 8 leaves the ten
+    // fraction bits of X alone and ((X + (base4 << 8)) >> 8) & ~3 = 4 sx + base4: the tile offset is one multiply-add per pixel)
     const int base4 = -4 * (sy_lo * WS_RS8 + sx_lo);
-    auto sample = [&](uint32_t Xs, uint32_t Ys) -> uint32_t {
+    const uint32_t adw = (uint32_t)ad + ((uint32_t)base4 << 8);
+    auto sample = [&](uint32_t Xs, uint32_t Ys) -> uint32_t {                   // Xs = X0 + adw (fits tiles), Ys = Y0 + bd
         const uint32_t fx = (Xs >> 5) & 31u, fy32 = Ys & 0x3e0u;
-        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * WS_RS8) + ((((int)Xs >> 8) & ~3) + base4), 4 * (CV_WS_H * WS_RS8 - (WS_RS8 + 2)), 212);
+        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * WS_RS8) + (((int)Xs >> 8) & ~3), 4 * (CV_WS_H * WS_RS8 - (WS_RS8 + 2)), 212);
         const __attribute__((address_space(3))) uint32_t* t = (const __attribute__((address_space(3))) uint32_t*)((const __attribute__((address_space(3))) char*)tile_raw + off);
         if (VS_WARP_WHATIF & 1) return t[0] + fx + fy32;                    // (analysis: one LDS read, no arithmetic)
         const uint32_t p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
@@ -1280,19 +1342,39 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             const uint32_t top = __builtin_amdgcn_perm(p01, p00, selc), bot = __builtin_amdgcn_perm(p11, p10, selc);
             o[c] = udot2(bot, wb, udot2(top, wt, 1u << 14));                // bits 15..22 = the sample
         }
+        // {B, G, R, 0}: shifts put each sample on a byte boundary (B: byte 0 of o0 >> 15, G: byte 1 of o1 >> 7, R: byte 2 of o2 << 1), two v_perm pick them
+#if VS_WARP_CV_PERM_PACK
+        const uint32_t bg = __builtin_amdgcn_perm(o[1] >> 7, o[0] >> 15, 0x0c0c0500u);
+        return __builtin_amdgcn_perm(o[2] << 1, bg, 0x0c060100u);
+#else
         return ((o[0] >> 15) & 0xffu) | ((o[1] >> 7) & 0xff00u) | ((o[2] << 1) & 0xff0000u);
+#endif
     };
-    if (fits && rows_aligned && nx == WT_W && yw + CV_RPW <= roi.h) {
+    if (fits && rows_aligned && nx == WT_W && yw + CV_RPW <= roi.h && (size_t)roi.h * (size_t)dst_stride < (1ull << 32)) {
         // the common case -- the tile fits its window, whole quads, whole rows: all rows are sampled in ONE basic block (the stores sit behind
         // a single lane mask afterwards), so that the scheduler can run the rows' LDS reads ahead of the previous rows' arithmetic
         uint32_t d[CV_RPW];
 #pragma unroll
         for (int k = 0; k < CV_RPW; k++)
-            d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k] + (uint32_t)ad, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd), sel);
+            d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k] + adw, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd), sel);
         if (m < 3 && (!(VS_WARP_WHATIF & 8) || d[0] == 0x12345678u)) {
+            // (one 32-bit byte offset per lane from the frame's uniform base, advanced by the row pitch: no 64-bit arithmetic per row)
+            uint32_t roff = (uint32_t)yw * (uint32_t)dst_stride + loff;
 #pragma unroll
-            for (int k = 0; k < CV_RPW; k++) VS_STORE32((uint32_t*)(dst + (size_t)(yw + k) * dst_stride + loff), d[k]);   // (uniform row base + lane offset)
+            for (int k = 0; k < CV_RPW; k++, roff += (uint32_t)dst_stride) VS_STORE32((uint32_t*)(dst + roff), d[k]);
         }
+#if VS_WARP_STAMPS
+        VS_STAMP(6);
+        VS_STAMP_DRAIN();
+        VS_STAMP(7);
+        {
+            const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+            stamp[8] = __builtin_amdgcn_s_getreg(4 | (31 << 11));              // HW_REG_HW_ID
+            stamp[9] = __builtin_amdgcn_s_getreg(20 | (31 << 11));             // HW_REG_XCC_ID
+            if (lane == 0 && wg < (unsigned)STAMP_WGS && interior)
+                for (int i = 0; i < STAMP_N; i++) g_warp_stamps[((size_t)wg * 4 + wv) * STAMP_N + i] = stamp[i];
+        }
+#endif
         return;
     }
 #pragma unroll 1
@@ -1305,7 +1387,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             uint32_t o[3] = {0u, 0u, 0u};
             if (lane_in) cv_pixel_global<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, o);
             p = o[0] | (o[1] << 8) | (o[2] << 16);
-        } else p = sample(Xs, Ys);
+        } else p = sample(Xs + ((uint32_t)base4 << 8), Ys);
         const uint32_t d = quad_pack_bgr(p, sel);            // every lane of the wave takes part in the shuffle
         uint8_t* orow = dst + (size_t)y * dst_stride;
         if (rows_aligned && quad_in) {
