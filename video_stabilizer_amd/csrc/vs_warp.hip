@@ -1118,8 +1118,8 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 //   * per pixel and channel: two v_perm_b32 put the channel's bytes of a window row side by side as a u16 pair {v(x), v(x + 1)}, two
 //     v_dot2_u32_u16 against the row's weight pair accumulate the four taps on top of the rounding constant; ~44 vector instructions per
 //     64 pixels in all against the float bilinear's 88.
-// 4K: 11.5 us per frame = 0.54 of the HBM peak (float bilinear 15.5 = 0.40); the what-if builds say the rest is how the memory operations are
-// structured, not instructions (profiles/r05_warp_cv.md).
+// 4K: 11.1 us per frame = 0.56 of the HBM peak (float bilinear 15.5 = 0.40).  In-kernel stamps: vector-issue-bound by the sum of ALL its
+// instructions -- three-operand integer instructions issue at half the fma's rate -- not by memory latency or occupancy (profiles/r05_warp_cv.md).
 // Tiles whose footprint does not fit the window (large rotation / zoom) take a per-pixel global path in the same kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
 #ifndef VS_WARP_CV_CLAMPED_FILL
