@@ -1458,19 +1458,20 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
     }
     __syncthreads();
     const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
-    const long long adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
-    const long long bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
-    const long long XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
-    const long long YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH + ny - 1]);
-    const long long mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
-    const long long mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
-    bool fits = mnX > -(1LL << 24) && mxX < (1LL << 24) && mnY > -(1LL << 24) && mxY < (1LL << 24);
+    const int adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
+    const int bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
+    const int XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
+    const int YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH + ny - 1]);
+    const int lim = 1 << 23;                                 // (as in the 8-bit kernel: every entry within 2^13 pixels, the sums inside 32 bits)
+    bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
+    const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
+    const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
     if (fits) {
-        sx_lo = (int)(mnX >> 10) & ~3;
-        const int sx_hi = (int)(mxX >> 10) + 1;
-        sy_lo = (int)(mnY >> 10);
-        const int sy_hi = (int)(mxY >> 10) + 1;
+        sx_lo = (mnX >> 10) & ~3;
+        const int sx_hi = (mxX >> 10) + 1;
+        sy_lo = mnY >> 10;
+        const int sy_hi = (mxY >> 10) + 1;
         rows = sy_hi - sy_lo + 1;
         groups = (sx_hi - sx_lo + 4) >> 2;
         fits = groups <= WS_W / 4 && rows <= CV16_WS_H;
@@ -1478,8 +1479,35 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
     const bool src_aligned = ((((uintptr_t)src) | ((uintptr_t)src_stride * 2)) & 3) == 0;                // uniform
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint32_t seen = 0;                                       // OR of every staged sample (as packed pairs): bits 14 / 15 of a half set = a sample >= 2^14
-    if (fits) {
-        const bool interior = src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h;
+    const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
+                          (size_t)h * (size_t)src_stride * 2 < (1ull << 32);                                 // uniform
+    if (interior) {                                          // (as in the 8-bit kernel: one 24-bit multiply-add per address from a uniform base, no border tests)
+        u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
+        uint32_t toff[CV16_FILL_SLOTS];
+        bool live[CV16_FILL_SLOTS];
+        const uint8_t* base = (const uint8_t*)(src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3));
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            const FillItem it = fill_item(lane, wv + 4 * s);
+            live[s] = it.row < rows && it.g < groups;
+            if (live[s]) {
+                const uint8_t* gp = base + (__umul24((uint32_t)it.row, 2u * (uint32_t)src_stride) + 24u * (uint32_t)it.g);
+                qa[s] = *(const u32x3*)gp;
+                qb[s] = *(const u32x3*)(gp + 12);
+            }
+            toff[s] = 2u * ((uint32_t)it.row * (uint32_t)WS_RS8 + 4u * (uint32_t)it.g);
+        }
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            const u32x3 a = qa[s], b = qb[s];                   // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
+            seen |= a.x | a.y | a.z | b.x | b.y | b.z;
+            VS_BOUNDS_CHECK(toff[s] + 7, CV16_WS_H * WS_RS8 * 2, 218);
+            u32x4* dstp = (u32x4*)(tile_raw + VS_DEBUG_CLAMP(toff[s], CV16_WS_H * WS_RS8 * 2 - 7));
+            dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
+            dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
+        }
+    } else if (fits) {
         u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
         FillItem it[CV16_FILL_SLOTS];
         bool live[CV16_FILL_SLOTS], direct[CV16_FILL_SLOTS];
@@ -1488,7 +1516,7 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
             it[s] = fill_item(lane, wv + 4 * s);
             live[s] = it[s].row < rows && it[s].g < groups;
             const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
-            direct[s] = live[s] && (interior || (src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h));
+            direct[s] = live[s] && src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h;
             if (direct[s]) {
                 const uint16_t* gp = src + (size_t)sy * src_stride + (size_t)sx * 3;
                 qa[s] = *(const u32x3*)gp;
@@ -1536,6 +1564,58 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
     const bool lane_in = x < roi.w, pair_in = (x | 1) < roi.w;
     const int base8 = -8 * (sy_lo * WS_RS8 + sx_lo);       // LDS byte address of staged pixel (sy, sx) = 8 * ((sy - sy_lo) * WS_RS8 + (sx - sx_lo))
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    // one output pixel of a tile that fits (Xs carries the window origin: base8 is a multiple of 8, base8 << 7 leaves X's fraction bits alone)
+    auto sample = [&](uint32_t Xs, uint32_t Ys, uint32_t (&o)[3]) {
+        const uint32_t fx = (Xs >> 5) & 31u, fy = (Ys >> 5) & 31u;
+        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (8 * WS_RS8) + (((int)Xs >> 7) & ~7), 8 * (CV16_WS_H * WS_RS8 - (WS_RS8 + 2)), 216);
+        const __attribute__((address_space(3))) u32x2* t = (const __attribute__((address_space(3))) u32x2*)((const __attribute__((address_space(3))) char*)tile_raw + off);
+        const u32x2 p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+        if (!wide) {                                         // (uniform) every sample < 2^14: the integer form of the same value
+            const uint32_t apair = fx * 0xffffu + 32u;                      // (32 - fx) | fx << 16
+            const uint32_t wb = apair * (fy << 5), wt = (apair << 10) - wb; // {32 a0 b | 32 a1 b << 16}
+            const uint32_t top[3] = {__builtin_amdgcn_perm(p01.x, p00.x, 0x05040100u), __builtin_amdgcn_perm(p01.x, p00.x, 0x07060302u), __builtin_amdgcn_perm(p01.y, p00.y, 0x05040100u)};
+            const uint32_t bot[3] = {__builtin_amdgcn_perm(p11.x, p10.x, 0x05040100u), __builtin_amdgcn_perm(p11.x, p10.x, 0x07060302u), __builtin_amdgcn_perm(p11.y, p10.y, 0x05040100u)};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t S = udot2(bot[c], wb, udot2(top[c], wt, 0u));         // = 2^15 x the float sum, exactly
+                o[c] = min((S + 16383u + ((S >> 15) & 1u)) >> 15, (uint32_t)maxv);   // cvRound: half to even
+            }
+        } else {
+            const float kk = 1.0f / 1024.0f;
+            const float w00 = (float)((32u - fx) * (32u - fy)) * kk, w01 = (float)(fx * (32u - fy)) * kk, w10 = (float)((32u - fx) * fy) * kk, w11 = (float)(fx * fy) * kk;
+            const uint32_t v00[3] = {p00.x & 0xffffu, p00.x >> 16, p00.y & 0xffffu}, v01[3] = {p01.x & 0xffffu, p01.x >> 16, p01.y & 0xffffu};
+            const uint32_t v10[3] = {p10.x & 0xffffu, p10.x >> 16, p10.y & 0xffffu}, v11[3] = {p11.x & 0xffffu, p11.x >> 16, p11.y & 0xffffu};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float sum = (float)v00[c] * w00 + (float)v01[c] * w01 + (float)v10[c] * w10 + (float)v11[c] * w11;
+                o[c] = (uint32_t)min(max((int)rintf(sum), 0), maxv);
+            }
+        }
+    };
+    if (fits && rows_aligned && nx == WT_W && yw + CV16_RPW <= roi.h && (size_t)roi.h * (size_t)dst_stride * 2 < (1ull << 32)) {
+        // the common case: the wave's rows in one basic block, the stores behind two lane masks afterwards (even lanes two dwords, odd lanes one),
+        // at a 32-bit byte offset from the frame's base advanced by the row pitch
+        const uint32_t adw = (uint32_t)ad + ((uint32_t)base8 << 7);
+        uint32_t d0[CV16_RPW], d1[CV16_RPW];
+#pragma unroll
+        for (int k = 0; k < CV16_RPW; k++) {
+            uint32_t o[3];
+            sample((uint32_t)cv_tab[128 + wv * CV16_RPW + k] + adw, (uint32_t)cv_tab[128 + CV16_TH + wv * CV16_RPW + k] + (uint32_t)bd, o);
+            pair_pack_bgr16(o, x & 1, d0[k], d1[k]);
+        }
+        uint32_t roff = (uint32_t)yw * (2u * (uint32_t)dst_stride) + (uint32_t)(x & ~1) * 6u;      // 12 bytes per pixel pair
+        if (x & 1) {
+#pragma unroll
+            for (int k = 0; k < CV16_RPW; k++) VS_STORE32((uint32_t*)((uint8_t*)dst + roff + (uint32_t)k * (2u * (uint32_t)dst_stride) + 8u), d0[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CV16_RPW; k++) {
+                VS_STORE32((uint32_t*)((uint8_t*)dst + roff + (uint32_t)k * (2u * (uint32_t)dst_stride)), d0[k]);
+                VS_STORE32((uint32_t*)((uint8_t*)dst + roff + (uint32_t)k * (2u * (uint32_t)dst_stride) + 4u), d1[k]);
+            }
+        }
+        return;
+    }
 #pragma unroll 2
     for (int k = 0; k < CV16_RPW; k++) {
         const int y = yw + k;
@@ -1544,33 +1624,7 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
         uint32_t o[3] = {0u, 0u, 0u};
         if (!fits) {
             if (lane_in) cv_pixel_global_u16<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, maxv, o);
-        } else {
-            const uint32_t fx = (Xs >> 5) & 31u, fy = (Ys >> 5) & 31u;
-            const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (8 * WS_RS8) + ((((int)Xs >> 7) & ~7) + base8), 8 * (CV16_WS_H * WS_RS8 - (WS_RS8 + 2)), 216);
-            const __attribute__((address_space(3))) u32x2* t = (const __attribute__((address_space(3))) u32x2*)((const __attribute__((address_space(3))) char*)tile_raw + off);
-            const u32x2 p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
-            if (!wide) {                                     // (uniform) every sample < 2^14: the integer form of the same value
-                const uint32_t apair = fx * 0xffffu + 32u;                      // (32 - fx) | fx << 16
-                const uint32_t wb = apair * (fy << 5), wt = (apair << 10) - wb; // {32 a0 b | 32 a1 b << 16}
-                const uint32_t top[3] = {__builtin_amdgcn_perm(p01.x, p00.x, 0x05040100u), __builtin_amdgcn_perm(p01.x, p00.x, 0x07060302u), __builtin_amdgcn_perm(p01.y, p00.y, 0x05040100u)};
-                const uint32_t bot[3] = {__builtin_amdgcn_perm(p11.x, p10.x, 0x05040100u), __builtin_amdgcn_perm(p11.x, p10.x, 0x07060302u), __builtin_amdgcn_perm(p11.y, p10.y, 0x05040100u)};
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const uint32_t S = udot2(bot[c], wb, udot2(top[c], wt, 0u));         // = 2^15 x the float sum, exactly
-                    o[c] = min((S + 16383u + ((S >> 15) & 1u)) >> 15, (uint32_t)maxv);   // cvRound: half to even
-                }
-            } else {
-                const float kk = 1.0f / 1024.0f;
-                const float w00 = (float)((32u - fx) * (32u - fy)) * kk, w01 = (float)(fx * (32u - fy)) * kk, w10 = (float)((32u - fx) * fy) * kk, w11 = (float)(fx * fy) * kk;
-                const uint32_t v00[3] = {p00.x & 0xffffu, p00.x >> 16, p00.y & 0xffffu}, v01[3] = {p01.x & 0xffffu, p01.x >> 16, p01.y & 0xffffu};
-                const uint32_t v10[3] = {p10.x & 0xffffu, p10.x >> 16, p10.y & 0xffffu}, v11[3] = {p11.x & 0xffffu, p11.x >> 16, p11.y & 0xffffu};
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float sum = (float)v00[c] * w00 + (float)v01[c] * w01 + (float)v10[c] * w10 + (float)v11[c] * w11;
-                    o[c] = (uint32_t)min(max((int)rintf(sum), 0), maxv);
-                }
-            }
-        }
+        } else sample(Xs + ((uint32_t)base8 << 7), Ys, o);
         uint32_t d0, d1;
         pair_pack_bgr16(o, x & 1, d0, d1);
         uint16_t* orow = dst + (size_t)y * dst_stride;
