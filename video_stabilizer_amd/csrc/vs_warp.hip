@@ -1264,8 +1264,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
             px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
             px.w = q[s].z >> 8;
-            VS_BOUNDS_CHECK(toff[s] + 3, CV_WS_H * WS_RS8, 217);
-            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(toff[s], CV_WS_H * WS_RS8 - 3)) = px;
+            VS_BOUNDS_CHECK((int)toff[s] + 3, CV_WS_H * WS_RS8, 217);
+            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV_WS_H * WS_RS8 - 3)) = px;
         }
     } else if (fits && !(VS_WARP_WHATIF & 2)) {
         u32x3 q[CV_FILL_SLOTS];
@@ -1502,8 +1502,8 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
             if (!live[s]) continue;
             const u32x3 a = qa[s], b = qb[s];                   // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
             seen |= a.x | a.y | a.z | b.x | b.y | b.z;
-            VS_BOUNDS_CHECK(toff[s] + 7, CV16_WS_H * WS_RS8 * 2, 218);
-            u32x4* dstp = (u32x4*)(tile_raw + VS_DEBUG_CLAMP(toff[s], CV16_WS_H * WS_RS8 * 2 - 7));
+            VS_BOUNDS_CHECK((int)toff[s] + 7, CV16_WS_H * WS_RS8 * 2, 218);
+            u32x4* dstp = (u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV16_WS_H * WS_RS8 * 2 - 7));
             dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
             dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
         }
