@@ -1129,10 +1129,14 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 #define VS_WARP_CV_PERM_PACK 1           // sampler: 1 = the three samples are packed with two v_perm, 0 = with and / or
 #endif
 #ifndef VS_WARP_CV_TILE_H
-#define VS_WARP_CV_TILE_H 64             // output rows per workgroup (a multiple of 32: the row-origin table is filled 32 rows per wave pass)
+#define VS_WARP_CV_TILE_H 64             // output rows per workgroup: 32, or a multiple of 64 (the row-origin table is filled 32 rows per wave pass).
+                                         // Measured (profiles/r05_warp_cv.md): 32 rows 12.3 us per 4K frame, 64 rows 11.1, 128 rows 12.9 -- the taller tile halves the
+                                         // prologue and halo shares but leaves 3 workgroups per CU (48 KB of LDS) and the fill of one is no longer covered by the others' sampling
 #endif
 constexpr int CV_TH = VS_WARP_CV_TILE_H, CV_RPW = CV_TH / 4, CV_WS_H = CV_TH + 8;
-static_assert(CV_TH % 32 == 0 && CV_TH <= 64, "row-origin table: 32 rows per pass, X0 | Y0 in one wave");
+static_assert(CV_TH % 64 == 0 || CV_TH == 32, "row-origin table: waves 2 and 3 fill it 32 rows per pass each (X0 in lanes 0..31, Y0 in lanes 32..63)");
+constexpr int CV_RBK = CV_RPW < 16 ? CV_RPW : 16;          // rows of a wave sampled in one basic block
+static_assert(CV_RPW % CV_RBK == 0, "whole row blocks");
 constexpr int CV_FILL_SLOTS = (CV_WS_H / 4 * (WS_W / 4) + 63) / 64;
 static_assert(CV_WS_H / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
 
@@ -1196,9 +1200,11 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const int fxq = min(x, roi.w - 1) + roi.x;
     if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
     else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
-    else if (wv - 2 < CV_TH / 32) {                        // wave 2 (and wave 3 of a 64-row tile): 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63
-        const int r = 32 * (wv - 2) + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
-        cv_tab[128 + (lane < 32 ? 0 : CV_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+    else {                                                 // waves 2 and 3: 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63, per pass
+        for (int r0 = 32 * (wv - 2); r0 < CV_TH; r0 += 64) {
+            const int r = r0 + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
+            cv_tab[128 + (lane < 32 ? 0 : CV_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+        }
     }
     __syncthreads();
     const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
@@ -1353,15 +1359,17 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     if (fits && rows_aligned && nx == WT_W && yw + CV_RPW <= roi.h && (size_t)roi.h * (size_t)dst_stride < (1ull << 32)) {
         // the common case -- the tile fits its window, whole quads, whole rows: all rows are sampled in ONE basic block (the stores sit behind
         // a single lane mask afterwards), so that the scheduler can run the rows' LDS reads ahead of the previous rows' arithmetic
-        uint32_t d[CV_RPW];
+        uint32_t roff = (uint32_t)yw * (uint32_t)dst_stride + loff;   // one 32-bit byte offset per lane from the frame's uniform base, advanced by the row pitch
+#pragma unroll 1
+        for (int k0 = 0; k0 < CV_RPW; k0 += CV_RBK) {
+            uint32_t d[CV_RBK];
 #pragma unroll
-        for (int k = 0; k < CV_RPW; k++)
-            d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k] + adw, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd), sel);
-        if (m < 3 && (!(VS_WARP_WHATIF & 8) || d[0] == 0x12345678u)) {
-            // (one 32-bit byte offset per lane from the frame's uniform base, advanced by the row pitch: no 64-bit arithmetic per row)
-            uint32_t roff = (uint32_t)yw * (uint32_t)dst_stride + loff;
+            for (int k = 0; k < CV_RBK; k++)
+                d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k0 + k] + adw, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k0 + k] + (uint32_t)bd), sel);
+            if (m < 3 && (!(VS_WARP_WHATIF & 8) || d[0] == 0x12345678u)) {
 #pragma unroll
-            for (int k = 0; k < CV_RPW; k++, roff += (uint32_t)dst_stride) VS_STORE32((uint32_t*)(dst + roff), d[k]);
+                for (int k = 0; k < CV_RBK; k++, roff += (uint32_t)dst_stride) VS_STORE32((uint32_t*)(dst + roff), d[k]);
+            } else roff += (uint32_t)CV_RBK * (uint32_t)dst_stride;
         }
 #if VS_WARP_STAMPS
         VS_STAMP(6);
