@@ -822,10 +822,18 @@ def main():
             others[name] = (dt_f, good_f)
         # ... and with the warp the reference's stabilizer actually runs per frame (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99): the
         # fixed-point bilinear, VS_WARP_BILINEAR_CV -- the step is then bound by the alignment pass, not by the warp
-        aw.step(False, capi.WARP_BILINEAR_CV)
-        dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_BILINEAR_CV), args.steps)
-        dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
-        others["bilinear_cv"] = (dt_f, good_f)
+        # (this warp takes a quarter of the alignment pass's time: measured with the solver kernel in both batch modes -- sharing CUs with
+        # the previous pass's warp, as `value` runs it, and exclusive -- the leg reports both and leads with the faster)
+        cv_modes = {}
+        for solver in ("shared", "exclusive"):
+            aw.shared(solver == "shared")
+            aw.step(False, capi.WARP_BILINEAR_CV)
+            dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_BILINEAR_CV), args.steps)
+            dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
+            cv_modes[solver] = (dt_f, good_f)
+        aw.shared(True)
+        cv_best = min(cv_modes, key=lambda k: cv_modes[k][0])
+        others["bilinear_cv"] = cv_modes[cv_best]
 
     stable = None
     if aw and not args.no_warp and args.select == "device":
@@ -900,6 +908,9 @@ def main():
         for name, (dt_f, good_f) in others.items():
             out[name + "_warp"] = {"value": round(good_f / dt_f, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_f / args.steps, 4),
                                    "note": "same step (one loop, after the pre-roll) with bgr_image_warp in " + what[name]}
+        if "bilinear_cv" in others:
+            out["bilinear_cv_warp"]["solver"] = cv_best
+            out["bilinear_cv_warp"]["by_solver_mode"] = {k: round(v[1] / v[0], 2) for k, v in cv_modes.items()}
         if stable:
             out["stable_select"] = {"value": round(stable[1] / stable[0], 2), "unit": "frames/s", "ms_per_step": round(1e3 * stable[0] / args.steps, 4),
                                     "note": "same step with VS_SELECT_STABLE: the keep-best-80 % step under a documented STL-independent rule (smallest "

@@ -57,6 +57,8 @@ def test_bench_line_contract(gpu_vs):
     assert j["config"]["select_mode_in_force"] == 1
     assert j["exact_warp"]["value"] > 0 and j["contracted_warp"]["value"] > 0 and "separable_warp" not in j and j["stable_select"]["value"] > 0
     assert j["bilinear_cv_warp"]["value"] > j["value"]              # the reference's own per-frame warp: the step is alignment-bound with it
+    bm = j["bilinear_cv_warp"]["by_solver_mode"]                    # ... measured with the solver kernel in both batch modes, the faster one leads
+    assert set(bm) == {"shared", "exclusive"} and j["bilinear_cv_warp"]["value"] == max(bm.values()) == bm[j["bilinear_cv_warp"]["solver"]]
     assert j["roofline_4k"]["bilinear_cv"]["achieved"] > j["roofline_4k"]["bilinear"]["achieved"]
     for key in ("separable_vs_exact", "contracted_vs_exact"):
         g = p[key]

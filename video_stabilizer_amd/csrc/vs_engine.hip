@@ -277,7 +277,11 @@ constexpr int kGnThreads = 256, kGnVirt = 512;
 #ifndef VS_NT256_MINWAVES
 #define VS_NT256_MINWAVES 4
 #endif
+#ifdef VS_NT256_NUM_VGPR
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VS_NT256_NUM_VGPR)))
+#else
 #define VS_GN_FUSED_BOUNDS __launch_bounds__(256, VS_NT256_MINWAVES)
+#endif
 #include "vs_align_kernels.inc"
 #undef VS_GN_FUSED_BOUNDS
 }  // namespace nt256v
@@ -1508,6 +1512,12 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     // the grouping cannot change results.  VS_STAB_OVERLAP=0 turns it off.
     static const bool overlap_env = []() { const char* e = getenv("VS_STAB_OVERLAP"); return e ? atoi(e) != 0 : true; }();
     static const bool prefetch_env = []() { const char* e = getenv("VS_STAB_PREFETCH"); return e ? atoi(e) != 0 : true; }();
+    // (the solver build under the overlapped warps: the small-footprint one beside a Lanczos2 warp, which fills the CUs for longer than the
+    // alignment pass takes; beside the fixed-point bilinear warp -- a quarter of the alignment pass -- the exclusive 512-thread build, whose
+    // shorter solver chain is worth more than the shared CUs: 1080p x 480 frames 101 k -> 120 k frames/s, 4K x 240 21.1 k -> 34.3 k
+    // (profiles/r05_stab_cv_solver.txt; VS_STAB_CV_SOLVER=1 selects the small build for an A/B))
+    static const int cv_solver_env = []() { const char* e = getenv("VS_STAB_CV_SOLVER"); return e && atoi(e) == VS_BATCH_SHARED ? VS_BATCH_SHARED : VS_BATCH_EXCLUSIVE; }();
+    const int overlap_mode = s && s->params.warp_mode == VS_WARP_BILINEAR_CV ? cv_solver_env : VS_BATCH_SHARED;
     const int n_clips_all = clip_len > 0 ? n / clip_len : 0;
     const bool dense_dev = s && mem == VS_MEM_DEVICE && w > 0 && stride == 3 * w && frame_stride == (size_t)h * stride;
     int group_clips = 0;
@@ -1515,7 +1525,9 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         // groups of at least kSharedMinPairs pairs (the small build's threshold), at most 4 groups (VS_STAB_GROUPS): every group boundary is a host
         // synchronisation and a latency-bound solver launch -- c5 (8 clips x 60 x 4K 10-bit) 17.3-18.1 k frames/s with 8 groups, 18.9-19.5 k with 4
         group_clips = std::max(1, (kSharedMinPairs + clip_len - 2) / (clip_len - 1));
-        static const int max_groups = []() { const char* e = getenv("VS_STAB_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
+        // (beside the fixed-point bilinear warp, with the exclusive solver build: 2 groups -- c5 27.8 k frames/s with 4 groups, 28.9 k with 2, 24.8 k with 8)
+        static const int groups_env = []() { const char* e = getenv("VS_STAB_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 0; }();
+        const int max_groups = groups_env ? groups_env : (overlap_mode == VS_BATCH_EXCLUSIVE ? 2 : 4);
         group_clips = std::max(group_clips, (n_clips_all + max_groups - 1) / max_groups);
         if (group_clips >= n_clips_all) group_clips = 0;
     }
@@ -1538,7 +1550,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         if (he == hipSuccess) he = hipStreamWaitEvent(s->warp_stream, s->warp_ev, 0);
         if (he != hipSuccess) r = set_error(VS_ERR_HIP, "stabilizer warp stream: %s", hipGetErrorString(he));
         const int saved_mode = a->batch_mode;
-        a->batch_mode = VS_BATCH_SHARED;
+        a->batch_mode = overlap_mode;
         s->overlap_warps = true;
         const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
         for (int c0 = 0; r >= 0 && c0 < n_clips_all; c0 += group_clips) {
@@ -1572,7 +1584,7 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         if (he == hipSuccess) he = hipStreamWaitEvent(s->warp_stream, s->warp_ev, 0);
         if (he != hipSuccess) r = set_error(VS_ERR_HIP, "stabilizer warp stream: %s", hipGetErrorString(he));
         const int saved_mode = a->batch_mode;
-        a->batch_mode = VS_BATCH_SHARED;
+        a->batch_mode = overlap_mode;
         s->overlap_warps = true;
         const size_t esz = vs_format_bits(format) > 8 ? 2 : 1;
         for (int f0 = 0; r >= 0 && f0 < n; f0 += time_chunk) {
