@@ -1417,7 +1417,11 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
 // {B | G << 16, R} per staged pixel: the float bilinear kernel's).  A tile that holds a sample >= 2^14 (full 16-bit content) evaluates the
 // float expression as written.  Tile 64 x 32 (28 KB of LDS); tables, footprint, stores as in the 8-bit kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int CV16_TH = 32, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
+#ifndef VS_WARP_CV16_TILE_H
+#define VS_WARP_CV16_TILE_H 32           // output rows per workgroup of the 16-bit kernel (a multiple of 4)
+#endif
+constexpr int CV16_TH = VS_WARP_CV16_TILE_H, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
+static_assert(CV16_TH % 4 == 0 && CV16_TH >= 16, "four waves share a tile's rows");
 constexpr int CV16_FILL_SLOTS = (CV16_WS_H / 4 * (WS_W / 4) + 63) / 64;
 
 template <int BORDER>
@@ -1460,9 +1464,11 @@ __global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t
     const int fxq = min(x, roi.w - 1) + roi.x;
     if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
     else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
-    else if (wv == 2) {
-        const int r = lane & 31, fyq = min(y0 + r, roi.h - 1) + roi.y;
-        cv_tab[128 + (lane < 32 ? 0 : CV16_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+    else {                                                 // waves 2 and 3: 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63, per pass
+        for (int r0 = 32 * (wv - 2); r0 < CV16_TH; r0 += 64) {
+            const int r = r0 + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
+            if (r < CV16_TH) cv_tab[128 + (lane < 32 ? 0 : CV16_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
+        }
     }
     __syncthreads();
     const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
