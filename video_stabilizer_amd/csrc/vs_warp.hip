@@ -1420,6 +1420,9 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
 #ifndef VS_WARP_CV16_TILE_H
 #define VS_WARP_CV16_TILE_H 32           // output rows per workgroup of the 16-bit kernel (a multiple of 4)
 #endif
+#ifndef VS_WARP_CV16_MINWAVES
+#define VS_WARP_CV16_MINWAVES 5
+#endif
 constexpr int CV16_TH = VS_WARP_CV16_TILE_H, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
 static_assert(CV16_TH % 4 == 0 && CV16_TH >= 16, "four waves share a tile's rows");
 constexpr int CV16_FILL_SLOTS = (CV16_WS_H / 4 * (WS_W / 4) + 63) / 64;
@@ -1443,7 +1446,7 @@ __device__ __forceinline__ void cv_pixel_global_u16(const uint16_t* __restrict__
 }
 
 template <int BORDER>
-__global__ __launch_bounds__(256, 5) void vs_k_bgr_warp_cv_c3_u16(const uint16_t* __restrict__ src, int w, int h, int src_stride,
+__global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c3_u16(const uint16_t* __restrict__ src, int w, int h, int src_stride,
                                                                  const double* __restrict__ minv, uint16_t* __restrict__ dst, int dst_stride,
                                                                  size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
                                                                  int chunk, int maxv, vsk::Roi roi) {
