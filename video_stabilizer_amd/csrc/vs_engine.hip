@@ -1535,7 +1535,10 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
     // 1080p x480 64 k frames/s with 8 chunks, 70 k with 6, 72 k with 4 or 3, 69-71 k with 2; profiles/r04_stab_long_clip.txt)
     int time_chunk = 0;
     static const int max_time_chunks = []() { const char* e = getenv("VS_STAB_TIME_CHUNKS"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 4; }();
-    if (overlap_env && dense_dev && clip_len == 0 && n >= 96) time_chunk = std::max(48, (n + max_time_chunks - 1) / max_time_chunks);
+    // (with the exclusive solver build a chunk is a latency-bound chain of its own: chunks of >= 120 frames -- 4K x240 34.2 k frames/s in 4 chunks, 35.8 k in 2)
+    if (overlap_env && dense_dev && clip_len == 0 && n >= 96)
+        time_chunk = std::max(overlap_mode == VS_BATCH_EXCLUSIVE ? 120 : 48, (n + max_time_chunks - 1) / max_time_chunks);
+    if (time_chunk >= n) time_chunk = 0;
     if (chunk > 0 && n > chunk)
         r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
                                     out_w, out_h);
