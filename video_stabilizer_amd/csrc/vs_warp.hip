@@ -1128,6 +1128,12 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 #ifndef VS_WARP_CV_PERM_PACK
 #define VS_WARP_CV_PERM_PACK 1           // sampler: 1 = the three samples are packed with two v_perm, 0 = with and / or
 #endif
+#ifndef VS_WARP_CV_ROW_FILL
+#define VS_WARP_CV_ROW_FILL 1            // interior fill: a wave slot = three staged rows x twenty column groups, the slots twelve rows apart (see the kernel)
+#endif
+#ifndef VS_WARP_CV_W16
+#define VS_WARP_CV_W16 1                 // sampler: 16-bit weights 64 a b (the top-left one saturated to 65535): the sample lands on a byte boundary
+#endif
 #ifndef VS_WARP_CV_TILE_H
 #define VS_WARP_CV_TILE_H 64             // output rows per workgroup: 32, or a multiple of 64 (the row-origin table is filled 32 rows per wave pass).
                                          // Measured (profiles/r05_warp_cv.md): 32 rows 12.3 us per 4K frame, 64 rows 11.1, 128 rows 12.9 -- the taller tile halves the
@@ -1141,6 +1147,17 @@ constexpr int CV_FILL_SLOTS = (CV_WS_H / 4 * (WS_W / 4) + 63) / 64;
 static_assert(CV_WS_H / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// packed 16-bit products of both halves of `a` with the LOW half of `b` (the second one saturating at 65535: the VOP3P clamp bit)
+__device__ __forceinline__ uint32_t pk_mul_lo_u16_lo(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mul_lo_u16_lo_sat(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
@@ -1239,10 +1256,43 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         // from a uniform base, no border tests.  (VS_WARP_CV_CLAMPED_FILL=1 also drops the live-item predicates by clamping the items beyond
         // the tile's own rows / column groups onto its last row / group: the ~28 % redundant loads cost more than the branches, 12.1 us per
         // 4K frame against 11.1.)
+        const uint8_t* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
+#if VS_WARP_CV_ROW_FILL
+        // Item map of this path: lane -> (row r3 = lane / 20 of a row triplet, column group g = lane % 20), once per tile; slot s of wave wv
+        // stages rows 3 (wv + 4 s) + r3 -- twelve rows further per slot: the source address advances by a UNIFORM 12 row pitches and the tile
+        // address by a constant (an immediate of the ds_write), so a slot costs one compare beside its load and its four formatting
+        // instructions (the 16-items-of-4-rows map of the rim path below: seven address instructions per slot).  60 of 64 lanes carry an item.
+        static_assert(WS_W / 4 == 20 && CV_WS_H % 12 == 0 && CV_FILL_SLOTS == CV_WS_H / 12, "row-triplet item map");
+        const uint32_t r3 = ((uint32_t)lane * 13u) >> 8, g = (uint32_t)lane - 20u * r3;                   // lane / 20, lane % 20 (lane < 64)
+        const uint32_t row0 = 3u * (uint32_t)wv + r3;
+        const bool col_live = r3 < 3u && (int)g < groups;
+        const uint32_t goff = __umul24(row0, (uint32_t)src_stride) + 12u * g;
+        uint32_t* const tp = tile_raw + (row0 * (uint32_t)WS_RS8 + 4u * g);
+        u32x3 q[CV_FILL_SLOTS];
+        bool live[CV_FILL_SLOTS];
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {              // every load is issued before the first tile write
+            live[s] = col_live && (int)row0 < rows - 12 * s;
+            if (live[s]) q[s] = *(const u32x3*)(base + (size_t)(12 * s) * (size_t)src_stride + goff);
+        }
+        VS_STAMP(2);
+        VS_STAMP_DRAIN();
+        VS_STAMP(3);
+#pragma unroll
+        for (int s = 0; s < CV_FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            u32x4 px;                                           // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
+            px.x = q[s].x & 0x00ffffffu;
+            px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
+            px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
+            px.w = q[s].z >> 8;
+            VS_BOUNDS_CHECK((int)((row0 + 12u * s) * WS_RS8 + 4u * g) + 3, CV_WS_H * WS_RS8, 217);
+            *(u32x4*)(tp + 12 * s * WS_RS8) = px;
+        }
+#else
         u32x3 q[CV_FILL_SLOTS];
         uint32_t toff[CV_FILL_SLOTS];
         bool live[CV_FILL_SLOTS];
-        const uint8_t* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
 #pragma unroll
         for (int s = 0; s < CV_FILL_SLOTS; s++) {              // every load is issued before the first tile write
             const FillItem it = fill_item(lane, wv + 4 * s);
@@ -1273,6 +1323,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             VS_BOUNDS_CHECK((int)toff[s] + 3, CV_WS_H * WS_RS8, 217);
             *(u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV_WS_H * WS_RS8 - 3)) = px;
         }
+#endif
     } else if (fits && !(VS_WARP_WHATIF & 2)) {
         u32x3 q[CV_FILL_SLOTS];
         FillItem it[CV_FILL_SLOTS];
@@ -1339,15 +1390,28 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         const __attribute__((address_space(3))) uint32_t* t = (const __attribute__((address_space(3))) uint32_t*)((const __attribute__((address_space(3))) char*)tile_raw + off);
         if (VS_WARP_WHATIF & 1) return t[0] + fx + fy32;                    // (analysis: one LDS read, no arithmetic)
         const uint32_t p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+#if VS_WARP_CV_W16
+        // 16-bit weights 64 a b = twice OpenCV's: (2 S + 2^15) >> 16 is (S + 2^14) >> 15, and the sample is byte 2 of the sum -- no shifts in front
+        // of the pack.  Only the top-left weight can reach 2^16 (fx = fy = 0: the other three are 0); the packed multiply saturates it to 65535, and
+        // (65535 v + 2^15) >> 16 = v for v <= 255.
+        const uint32_t apair = fx * 0x1fffeu + 64u;                         // 2 (32 - fx) | 2 fx << 16
+        const uint32_t wb = pk_mul_lo_u16_lo(apair, fy32), wt = pk_mul_lo_u16_lo_sat(apair, 1024u - fy32);
+        constexpr uint32_t kHalf = 1u << 15;
+#else
         const uint32_t apair = fx * 0xffffu + 32u;                          // (32 - fx) | fx << 16
         const uint32_t wb = apair * fy32, wt = (apair << 10) - wb;          // {32 a0 b1 | 32 a1 b1 << 16}, {32 a0 b0 | 32 a1 b0 << 16}: each <= 32768, no borrow between the halves
+        constexpr uint32_t kHalf = 1u << 14;
+#endif
         uint32_t o[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const uint32_t selc = 0x0c040c00u + 0x00010001u * (uint32_t)c;  // {byte c of the left pixel, 0, byte c of the right pixel, 0}
             const uint32_t top = __builtin_amdgcn_perm(p01, p00, selc), bot = __builtin_amdgcn_perm(p11, p10, selc);
-            o[c] = udot2(bot, wb, udot2(top, wt, 1u << 14));                // bits 15..22 = the sample
+            o[c] = udot2(bot, wb, udot2(top, wt, kHalf));                   // bits 15..22 (16..23 with the doubled weights) = the sample
         }
+#if VS_WARP_CV_W16
+        return __builtin_amdgcn_perm(o[2], __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x0c060100u);     // {B, G, R, 0}
+#endif
         // {B, G, R, 0}: shifts put each sample on a byte boundary (B: byte 0 of o0 >> 15, G: byte 1 of o1 >> 7, R: byte 2 of o2 << 1), two v_perm pick them
 #if VS_WARP_CV_PERM_PACK
         const uint32_t bg = __builtin_amdgcn_perm(o[1] >> 7, o[0] >> 15, 0x0c0c0500u);
@@ -1499,10 +1563,40 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
                           (size_t)h * (size_t)src_stride * 2 < (1ull << 32);                                 // uniform
     if (interior) {                                          // (as in the 8-bit kernel: one 24-bit multiply-add per address from a uniform base, no border tests)
+        const uint8_t* base = (const uint8_t*)(src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3));
+#if VS_WARP_CV_ROW_FILL
+        // (the 8-bit kernel's row-triplet item map: lane -> (row lane / 20 of a triplet, column group lane % 20), slots twelve rows apart)
+        static_assert(WS_W / 4 == 20 && CV16_FILL_SLOTS == (CV16_WS_H + 11) / 12, "row-triplet item map");
+        const uint32_t r3 = ((uint32_t)lane * 13u) >> 8, g = (uint32_t)lane - 20u * r3;
+        const uint32_t row0 = 3u * (uint32_t)wv + r3;
+        const bool col_live = r3 < 3u && (int)g < groups;
+        const uint32_t goff = __umul24(row0, 2u * (uint32_t)src_stride) + 24u * g;
+        uint32_t* const tp = tile_raw + 2u * (row0 * (uint32_t)WS_RS8 + 4u * g);
+        u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
+        bool live[CV16_FILL_SLOTS];
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            live[s] = col_live && (int)row0 < rows - 12 * s;
+            if (live[s]) {
+                const uint8_t* gp = base + (size_t)(12 * s) * (2 * (size_t)src_stride) + goff;
+                qa[s] = *(const u32x3*)gp;
+                qb[s] = *(const u32x3*)(gp + 12);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < CV16_FILL_SLOTS; s++) {
+            if (!live[s]) continue;
+            const u32x3 a = qa[s], b = qb[s];                   // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
+            seen |= a.x | a.y | a.z | b.x | b.y | b.z;
+            VS_BOUNDS_CHECK((int)(2u * ((row0 + 12u * s) * WS_RS8 + 4u * g)) + 7, CV16_WS_H * WS_RS8 * 2, 218);
+            u32x4* dstp = (u32x4*)(tp + 2 * 12 * s * WS_RS8);
+            dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
+            dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
+        }
+#else
         u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
         uint32_t toff[CV16_FILL_SLOTS];
         bool live[CV16_FILL_SLOTS];
-        const uint8_t* base = (const uint8_t*)(src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3));
 #pragma unroll
         for (int s = 0; s < CV16_FILL_SLOTS; s++) {
             const FillItem it = fill_item(lane, wv + 4 * s);
@@ -1524,6 +1618,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
             dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
             dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
         }
+#endif
     } else if (fits) {
         u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
         FillItem it[CV16_FILL_SLOTS];
