@@ -110,6 +110,9 @@ constexpr int WS_RS8 = WS_W + 8;
 #ifndef VS_WARP_BILINEAR_U16_TILE
 #define VS_WARP_BILINEAR_U16_TILE 1
 #endif
+#ifndef VS_WARP_CV_ROW_FILL
+#define VS_WARP_CV_ROW_FILL 1            // interior fill of every byte / word tile: a wave slot = three staged rows x twenty column groups, the slots twelve rows apart (see vs_k_bgr_warp_cv_c3)
+#endif
 #ifndef VS_WARP_TILE_H_BILINEAR_U16
 #define VS_WARP_TILE_H_BILINEAR_U16 16
 #endif
@@ -739,14 +742,27 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
     // 4 source pixels (12 bytes, one aligned load) per work item, converted once, written as 4 float4.
     // (16 + 8) rows x 20 groups = 480 items = 2 per thread; all loads are issued before the first conversion.
     u32x3 q0[FILL_SLOTS], q1[FILL_SLOTS];
+    // Interior tiles of the raw-tile (bilinear) kernels take the fixed-point bilinear kernels' row-triplet item map (VS_WARP_CV_ROW_FILL): lane ->
+    // (row lane / 20 of a row triplet, column group lane % 20), once per workgroup; slot s of wave wv stages rows 3 (wv + 4 s) + r3, twelve rows
+    // further per slot, so the source offset advances by a uniform and the tile address by a constant.  (Not the float tiles: 64 bytes per
+    // item there, and consecutive lanes 64 bytes apart put four lanes of every 16 on the same banks.)
+    constexpr bool ROWFILL = RAWTILE && VS_WARP_CV_ROW_FILL != 0;
+    static_assert(!ROWFILL || (WS_W / 4 == 20 && FILL_SLOTS == (WS_H + 11) / 12), "row-triplet item map");
+    const int rf_r3 = (int)(((uint32_t)lane * 13u) >> 8), rf_g = lane - 20 * rf_r3, rf_row0 = 3 * wv + rf_r3;      // lane / 20, lane % 20
+    auto item_of = [&](int s, bool interior) -> FillItem {
+        if (ROWFILL && interior) return FillItem{rf_r3 < 3 ? rf_row0 + 12 * s : WS_H, rf_g};                // (lanes 60..63 carry no item: a row beyond every tile)
+        return fill_item(lane, wv + 4 * s);
+    };
     // the loads of an interior tile: into q0 / q1, which the fill converts -- right away, or (VS_WARP_TILES_PER_WG > 1) after the
     // previous tile's sampler blocks, so that a tile's memory latency lies under the tile before it
     auto issue = [&](const Geom& g) {
         const T* base = (VS_WARP_WHATIF & 32) ? src : src + ((size_t)g.sy_lo * src_stride + (size_t)g.sx_lo * 3);
+        const uint32_t rf_off0 = (uint32_t)rf_row0 * (uint32_t)src_stride + 12u * (uint32_t)rf_g;
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
-            const FillItem it = fill_item(lane, wv + 4 * s);
-            uint32_t off = (uint32_t)it.row * (uint32_t)src_stride + 12u * (uint32_t)it.g;      // elements
+            const FillItem it = item_of(s, true);
+            uint32_t off = ROWFILL ? rf_off0 + (uint32_t)(12 * s) * (uint32_t)src_stride
+                                   : (uint32_t)it.row * (uint32_t)src_stride + 12u * (uint32_t)it.g;      // elements
             if (VS_WARP_WHATIF & 32) off &= 0xffcu;                  // (analysis: every load hits the same few cache lines)
             if (it.row < g.rows && it.g < g.groups) {
                 q0[s] = *(const u32x3*)(base + off);
@@ -766,7 +782,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
             VS_STAMP(3);
 #pragma unroll
             for (int s = 0; s < FILL_SLOTS; s++) {
-                it[s] = fill_item(lane, wv + 4 * s);
+                it[s] = item_of(s, true);
                 live[s] = it[s].row < rows && it[s].g < groups;
                 direct[s] = live[s];
                 rowp[s] = src;
@@ -1127,9 +1143,6 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 #endif
 #ifndef VS_WARP_CV_PERM_PACK
 #define VS_WARP_CV_PERM_PACK 1           // sampler: 1 = the three samples are packed with two v_perm, 0 = with and / or
-#endif
-#ifndef VS_WARP_CV_ROW_FILL
-#define VS_WARP_CV_ROW_FILL 1            // interior fill: a wave slot = three staged rows x twenty column groups, the slots twelve rows apart (see the kernel)
 #endif
 #ifndef VS_WARP_CV_W16
 #define VS_WARP_CV_W16 1                 // sampler: 16-bit weights 64 a b (the top-left one saturated to 65535): the sample lands on a byte boundary
