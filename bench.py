@@ -308,13 +308,14 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
     for name, mode, key in (("exact", capi.WARP_LANCZOS2, "exact"), ("contracted", capi.WARP_LANCZOS2_FAST, "contracted"),
                             ("separable", capi.WARP_LANCZOS2_SEP, "separable"),
                             ("bilinear_cv", capi.WARP_BILINEAR_CV, "bilinear_cv"),
-                            ("bilinear", capi.WARP_BILINEAR, "bilinear"), ("bilinear_10bit", capi.WARP_BILINEAR, "bilinear_10bit")):
-        bits = 16 if name == "bilinear_10bit" else 8
-        if bits == 16:                                       # 10-bit frames in 16-bit containers (configs[4]'s format): twice the bytes per pixel
+                            ("bilinear", capi.WARP_BILINEAR, "bilinear"), ("bilinear_10bit", capi.WARP_BILINEAR, "bilinear_10bit"),
+                            ("bilinear_cv_10bit", capi.WARP_BILINEAR_CV, "bilinear_cv_10bit")):
+        bits = 16 if name.endswith("_10bit") else 8
+        if bits == 16 and src8 is not None:                  # 10-bit frames in 16-bit containers (configs[4]'s format): twice the bytes per pixel
             src8 = dst8 = None
             src = torch.randint(0, 1024, (frames, H, W, 3), device=dev, dtype=torch.int32).to(torch.int16)
             dst = torch.empty_like(src)
-        else:
+        elif bits == 8:
             src, dst = src8, dst8
 
         def run():
@@ -352,13 +353,19 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR, 10-bit)"}
             continue
+        if name == "bilinear_cv_10bit":
+            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3_u16<clamp> (word tile, v_dot2_u32_u16 taps while the samples stay below 2^14)", "bound": "hbm",
+                         "binding": "hbm + valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
+                         "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR_CV on 16-bit containers: OpenCV's float-weight form)"}
+            continue
         if name == "bilinear_cv":
             # the stabilizer's DEFAULT sampler = the reference's own warp (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99 -> imgproc.cpp:472):
-            # OpenCV's fixed-point bilinear restated, integer work end to end; bound by how its memory operations are structured, not by
-            # instructions (what-if builds: profiles/r05_warp_cv.md)
+            # OpenCV's fixed-point bilinear restated, integer work end to end; vector issue and the memory side together (profiles/r05_warp_cv.md)
             pc, _ = load_profile("r05_pmc_bilinear_cv.json")
-            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3<clamp> (byte tile, v_dot2_u32_u16 taps)", "bound": "hbm", "binding": "memory structure (loads 3.7 us + "
-                         "stores 2.4 us + arithmetic 1.1 us of 11.5 per 4K frame: profiles/r05_warp_cv.md)", "valu_instr_per_px": pc.get("valu_instr_per_px"),
+            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3<clamp> (byte tile, v_dot2_u32_u16 taps)", "bound": "hbm", "binding": "valu issue + memory: ~36 integer-class "
+                         "vector instructions per pixel row of a wave, and 56 MB per 4K frame with the tile halo = 5.4 TB/s of the 6.3 TB/s copy ceiling "
+                         "(profiles/r05_warp_cv.md)", "valu_instr_per_px": pc.get("valu_instr_per_px"),
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR_CV: OpenCV 4.x's published fixed-point path, parity "
@@ -367,7 +374,7 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         if name == "bilinear":
             # the Halide sampler's float lerp (generators.cpp:148-163; the stabilizer's default until round 5): 88 vector instructions per
             # pixel (counted: profiles/r04_pmc_bilinear.json), VALU-issue-bound like the Lanczos kernels (profiles/r04_ab_warp_bilinear.md)
-            out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "valu", "valu_instr_per_px": 87.8,
+            out[name] = {"kernel": "vs_k_bgr_warp_c3<u8,bilinear,clamp> (byte tile)", "bound": "hbm", "binding": "valu", "valu_instr_per_px_r04": 87.8,
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR)"}
