@@ -35,6 +35,21 @@ def test_cv_mode_is_the_forward_map_cv_warp_affine_inverts(gpu_vs, oracle):
     assert np.array_equal(out[7:, 5:], src[:-7, :-5]) and not out[:7].any() and not out[:, :5].any()
 
 
+def test_cv_mode_every_fraction_pair_with_extreme_samples(gpu_vs, oracle):
+    """The tuned 8-bit sampler works with 16-bit weights 64 a b, its top-left weight saturated to 65535 where it would be 65536 (fx = fy = 0):
+    translations by every pair of 1/32-pixel fractions (1024 frames: each (fx, fy) is the fraction of EVERY interior sample of its frame) over an
+    image of saturated and near-saturated bytes, against the twin."""
+    rng = np.random.default_rng(77)
+    src = rng.choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), size=(40, 72, 3))
+    src[::3, ::2] = 255
+    trs = [(0.0, 0.0, 1.0 + fx / 32.0, -1.0 - fy / 32.0) for fx in range(32) for fy in range(32)]
+    frames = np.ascontiguousarray(np.broadcast_to(src, (len(trs),) + src.shape))
+    got = gpu_vs.bgr_image_warp_batch(frames, [gpu_vs.Transform.of(*t) for t in trs], mode=gpu_vs.WARP_BILINEAR_CV, border=gpu_vs.BORDER_CONSTANT)
+    for i, tr in enumerate(trs):
+        want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CONSTANT)
+        assert np.array_equal(got[i], want), tr
+
+
 def test_cv_mode_ragged_sizes_unaligned_rows_windows(gpu_vs, oracle):
     rng = np.random.default_rng(21)
     for (h, w) in [(17, 65), (33, 130), (32, 64), (5, 7), (70, 201), (1, 1), (40, 63)]:
