@@ -22,13 +22,13 @@ def _job(G, torch, k, clip, dev):
     n, h, w = clip.shape[:3]
     st, ts = G.Aligner(device=0, select_mode=k % 3, **kw).align_batch_device(dev.data_ptr(), n, w, h, G.FMT_BGR8)
     out.append((st, [t.tup() for t in ts]))
-    s = G.Stabilizer(device=0, lag=2, crop_pixels=4 + k, warp_mode=k % 3, **kw)
+    s = G.Stabilizer(device=0, lag=2, crop_pixels=4 + k, warp_mode=k % 5, **kw)                     # all five warp modes over the six threads
     o, has = s.process_batch(clip)
     out.append((has, o.tobytes()))
-    s2 = G.Stabilizer(device=0, lag=1 + k % 3, crop_pixels=2, warp_mode=(k + 1) % 3, **kw)
+    s2 = G.Stabilizer(device=0, lag=1 + k % 3, crop_pixels=2, warp_mode=(k + 1) % 5, **kw)
     out.append([None if f is None else f.tobytes() for f in (s2.process(f) for f in clip)])
     tr = [G.Transform.of(0.001 * k, -0.002, 1.5 + k, -0.5 * i) for i in range(n)]
-    out.append(G.bgr_image_warp_batch(clip, tr, k % 3, k % 2).tobytes())
+    out.append(G.bgr_image_warp_batch(clip, tr, (k + 2) % 5, k % 2).tobytes())
     return out
 
 
