@@ -135,6 +135,25 @@ def test_cv_mode_16bit_containers_ragged_sizes_mixed_depth_tiles_and_windows(gpu
     assert got.max() == 0 and flat.max() == 1                  # 0.5 -> 0 (half to even), not 1
 
 
+def test_cv_mode_16bit_every_fraction_pair_clamped_and_clampless_tiles(gpu_vs, oracle):
+    """the word-tile kernel's common path works with 16-bit weights 64 a b (top-left saturated) and takes the sample from the high half of the
+    rounded sum; tiles whose staged samples all lie within max_value skip the clamp, the others (a 10-bit frame with stray values up to 2^14 - 1
+    in one region: still the integer form) keep it.  Every pair of 1/32-pixel fractions, extreme and odd samples (halves round to even)."""
+    rng = np.random.default_rng(78)
+    src = rng.choice(np.array([0, 1, 2, 3, 511, 512, 1021, 1022, 1023], np.uint16), size=(40, 136, 3))
+    src[:, 70:] = rng.choice(np.array([0, 1, 1023, 1024, 1025, 8191, 16382, 16383], np.uint16), size=(40, 66, 3))     # above max_value, below 2^14
+    trs = [(0.0, 0.0, 1.0 + fx / 32.0, -1.0 - fy / 32.0) for fx in range(32) for fy in range(32)]
+    frames = np.ascontiguousarray(np.broadcast_to(src, (len(trs),) + src.shape))
+    got = gpu_vs.bgr_image_warp_batch(frames, [gpu_vs.Transform.of(*t) for t in trs], mode=gpu_vs.WARP_BILINEAR_CV, border=gpu_vs.BORDER_CONSTANT, max_value=1023)
+    assert got.max() == 1023
+    for i, tr in enumerate(trs):
+        want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CONSTANT, max_value=1023)
+        assert np.array_equal(got[i], want), tr
+    # a max_value that is not 2^k - 1 always clamps
+    g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(0.001, 0.002, 0.3, 0.7), mode=gpu_vs.WARP_BILINEAR_CV, border=0, max_value=1000)
+    assert np.array_equal(g, oracle.bgr_image_warp(src, oracle.Transform.of(0.001, 0.002, 0.3, 0.7), oracle.WARP_BILINEAR_CV, border=0, max_value=1000))
+
+
 def test_cv_mode_4k_frame(gpu_vs, oracle):
     from video_stabilizer_amd import synth
     frames, _ = synth.make_clip(3840, 2160, 1, seed=2, channels=3)
