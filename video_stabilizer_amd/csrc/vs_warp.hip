@@ -1138,12 +1138,6 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 // instructions -- three-operand integer instructions issue at half the fma's rate -- not by memory latency or occupancy (profiles/r05_warp_cv.md).
 // Tiles whose footprint does not fit the window (large rotation / zoom) take a per-pixel global path in the same kernel.
 // ------------------------------------------------------------------------------------------------------------------------------------
-#ifndef VS_WARP_CV_CLAMPED_FILL
-#define VS_WARP_CV_CLAMPED_FILL 0        // interior fill: 1 = items beyond the tile's rows / groups are clamped (no predicates, redundant loads), 0 = predicated
-#endif
-#ifndef VS_WARP_CV_PERM_PACK
-#define VS_WARP_CV_PERM_PACK 1           // sampler: 1 = the three samples are packed with two v_perm, 0 = with and / or
-#endif
 #ifndef VS_WARP_CV_W16
 #define VS_WARP_CV_W16 1                 // sampler: 16-bit weights 64 a b (the top-left one saturated to 65535): the sample lands on a byte boundary
 #endif
@@ -1266,9 +1260,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
                           (size_t)h * (size_t)src_stride < (1ull << 32);                                    // uniform
     if (interior && !(VS_WARP_WHATIF & 2)) {
         // Interior tiles (the whole staged window inside an aligned frame: all but the frame's rim): every address is one 24-bit multiply-add
-        // from a uniform base, no border tests.  (VS_WARP_CV_CLAMPED_FILL=1 also drops the live-item predicates by clamping the items beyond
-        // the tile's own rows / column groups onto its last row / group: the ~28 % redundant loads cost more than the branches, 12.1 us per
-        // 4K frame against 11.1.)
+        // from a uniform base, no border tests.  (Clamping the items beyond the tile's own rows / column groups onto its last row / group
+        // instead of predicating them was measured: the ~28 % redundant loads cost more than the branches, 12.1 us per 4K frame against 11.1.)
         const uint8_t* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
 #if VS_WARP_CV_ROW_FILL
         // Item map of this path: lane -> (row r3 = lane / 20 of a row triplet, column group g = lane % 20), once per tile; slot s of wave wv
@@ -1310,12 +1303,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         for (int s = 0; s < CV_FILL_SLOTS; s++) {              // every load is issued before the first tile write
             const FillItem it = fill_item(lane, wv + 4 * s);
             live[s] = it.row < rows && it.g < groups;
-#if VS_WARP_CV_CLAMPED_FILL
-            const uint32_t r = min((uint32_t)it.row, (uint32_t)(rows - 1)), g = min((uint32_t)it.g, (uint32_t)(groups - 1));
-            q[s] = *(const u32x3*)(base + (__umul24(r, (uint32_t)src_stride) + 12u * g));
-#else
             if (live[s]) q[s] = *(const u32x3*)(base + (__umul24((uint32_t)it.row, (uint32_t)src_stride) + 12u * (uint32_t)it.g));
-#endif
             toff[s] = (uint32_t)it.row * (uint32_t)WS_RS8 + 4u * (uint32_t)it.g;
         }
         VS_STAMP(2);
@@ -1323,11 +1311,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         VS_STAMP(3);
 #pragma unroll
         for (int s = 0; s < CV_FILL_SLOTS; s++) {
-#if VS_WARP_CV_CLAMPED_FILL
-            if (CV_WS_H / 4 * (WS_W / 4) < 64 * (s + 1) && toff[s] > (uint32_t)(CV_WS_H * WS_RS8 - 4)) continue;   // (only the last slot has items beyond the tile array)
-#else
             if (!live[s]) continue;
-#endif
             u32x4 px;                                           // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
             px.x = q[s].x & 0x00ffffffu;
             px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
@@ -1426,12 +1410,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         return __builtin_amdgcn_perm(o[2], __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x0c060100u);     // {B, G, R, 0}
 #endif
         // {B, G, R, 0}: shifts put each sample on a byte boundary (B: byte 0 of o0 >> 15, G: byte 1 of o1 >> 7, R: byte 2 of o2 << 1), two v_perm pick them
-#if VS_WARP_CV_PERM_PACK
         const uint32_t bg = __builtin_amdgcn_perm(o[1] >> 7, o[0] >> 15, 0x0c0c0500u);
         return __builtin_amdgcn_perm(o[2] << 1, bg, 0x0c060100u);
-#else
-        return ((o[0] >> 15) & 0xffu) | ((o[1] >> 7) & 0xff00u) | ((o[2] << 1) & 0xff0000u);
-#endif
     };
     if (fits && rows_aligned && nx == WT_W && yw + CV_RPW <= roi.h && (size_t)roi.h * (size_t)dst_stride < (1ull << 32)) {
         // the common case -- the tile fits its window, whole quads, whole rows: all rows are sampled in ONE basic block (the stores sit behind
