@@ -32,6 +32,8 @@ extern "C" {
 #define VS_ERR_HIP (-2)
 #define VS_ERR_UNSUPPORTED (-3)
 #define VS_ERR_STATE (-4)
+#define VS_ERR_NOMEM (-5)        /* a host allocation failed (std::bad_alloc), or another C++ exception was stopped at this boundary: the call is
+                                   abandoned under the error protocol of its family (engine calls: the running sequence ends, the handle stays usable) */
 
 enum { VS_MEM_HOST = 0, VS_MEM_DEVICE = 1 };
 /* Frame formats.  16-bit containers say how many bits the samples really use: the aligner derives its 8-bit luma with
@@ -243,7 +245,9 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
 
 /* Test hook, not part of the reference's surface: fault injection for the library's own device / pinned-host allocations.
  * vs_test_fail_alloc(k), k > 0: the k-th allocation the library makes from now on (any handle, any thread) fails once with
- * out-of-memory, and the call it belongs to returns VS_ERR_HIP; k = 0 disarms.  Returns the number of allocations made since the
+ * out-of-memory, and the call it belongs to returns VS_ERR_HIP; k < 0: the |k|-th allocation THROWS std::bad_alloc instead -- a host
+ * allocation failing at that point of the call, which must come back as VS_ERR_NOMEM (no exception crosses this boundary); k = 0
+ * disarms.  Returns the number of allocations made since the
  * previous call of this function.  The environment variable VS_TEST_FAIL_ALLOC=k (honoured only together with VS_TEST_HOOKS=1) arms it at load time for programs that cannot
  * call it.  tests/test_alloc_failure_gpu.py walks k over every allocation of the engine-level calls. */
 /* VS_TEST_POISON_ALLOC=<byte> in the environment (read once; honoured only together with VS_TEST_HOOKS=1): every fresh device allocation starts filled with that byte, so that a result

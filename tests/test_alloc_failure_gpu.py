@@ -27,20 +27,25 @@ def _tr(ts):
     return [t.tup() for t in ts]
 
 
-def _walk(vs, make, call, min_fired):
-    """returns the number of allocations that were failed; asserts the contract at every one of them"""
+def _walk(vs, make, call, min_fired, throwing=False, stride=1):
+    """returns the number of allocations that were failed; asserts the contract at every one of them.
+    throwing: the allocation THROWS std::bad_alloc instead (vs_test_fail_alloc(-k)) -- a host allocation failing at that point of the call: the
+    exception must stop at the C boundary (VS_ERR_NOMEM = -5) and leave the handle exactly as an error code does; stride: every stride-th k only"""
     vs.test_fail_alloc(0)
     call(make())                                   # process-wide one-time allocations (the warp's parameter ring) happen here
     ref = call(make())
     fired, k = 0, 1
     while True:
         h = make()
-        vs.test_fail_alloc(k)
+        vs.test_fail_alloc(-k if throwing else k)
         try:
             got, failed = call(h), False
         except vs.VsError as e:
             failed = True
-            assert "error -2" in str(e) and "out of memory" in str(e).lower(), str(e)
+            if throwing:
+                assert "error -5" in str(e) and "bad_alloc" in str(e), str(e)
+            else:
+                assert "error -2" in str(e) and "out of memory" in str(e).lower(), str(e)
         seen = vs.test_fail_alloc(0)
         if not failed:
             assert seen < k, "allocation %d was failed (of %d made) but the call reported success" % (k, seen)
@@ -52,7 +57,7 @@ def _walk(vs, make, call, min_fired):
         assert call(h) is not None                 # and the handle keeps working (state carried over from a good call)
         del h
         gc.collect()
-        k += 1
+        k += stride
         assert k < 400, "the walk does not terminate"
     assert fired >= min_fired, "only %d allocations were failed: the hook does not see the call's allocations" % fired
     return fired
@@ -146,6 +151,33 @@ def test_stabilizer_process_clips_device_every_allocation(gpu_vs):
         return r, list(has), out.cpu().numpy().tobytes()
     n = _walk(vs, lambda: vs.Stabilizer(device=0, lag=5, crop_pixels=crop, warp_mode=vs.WARP_LANCZOS2), call, min_fired=14)
     print("process_clips (device frames, overlapped groups): %d allocations" % n)
+
+
+def test_exceptions_stop_at_the_c_boundary(gpu_vs):
+    """include/vs_amd.h: "No exceptions cross".  The same walks with the allocation THROWING std::bad_alloc (every other k: the walks above cover
+    every k with error codes): the call returns VS_ERR_NOMEM, the next call on the handle equals a fresh handle's, nothing leaks."""
+    import torch
+    vs = gpu_vs
+    frames = _clip(6)
+    dev = torch.from_numpy(frames).cuda()
+
+    def align(h):
+        st, ts = h.align_batch_device(dev.data_ptr(), 6, W, H, vs.FMT_BGR8)
+        return list(st), _tr(ts)
+    n1 = _walk(vs, lambda: vs.Aligner(device=0), align, min_fired=7, throwing=True, stride=2)
+    host = _clip(16, seed=7)
+
+    def batch(s):
+        out, has = s.process_batch(host)
+        return list(has), out.tobytes()
+    n2 = _walk(vs, lambda: vs.Stabilizer(device=0, lag=4, smoother_memory=2, crop_pixels=8), batch, min_fired=8, throwing=True, stride=2)   # (library defaults: the fixed-point bilinear warp)
+    print("exceptions stopped at the boundary: %d (align_batch, device frames) + %d (process_batch, host frames)" % (n1, n2))
+    # a kernel-level call: the parameter ring's first allocation on a fresh thread would be the natural case; any allocation will do
+    vs.test_fail_alloc(-1)
+    with pytest.raises(vs.VsError, match="error -5"):
+        vs.phase_correlate(np.zeros((64, 64), np.uint8), np.zeros((64, 64), np.uint8))
+    vs.test_fail_alloc(0)
+    assert vs.phase_correlate(np.zeros((64, 64), np.uint8), np.zeros((64, 64), np.uint8)) is not None
 
 
 def test_failed_regrows_do_not_leak_device_memory(gpu_vs):

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,8 +42,9 @@ static const char* test_env(const char* name) {
 std::atomic<long long> g_alloc_count{0};
 std::atomic<long long> g_alloc_fail_at{[]() { const char* e = test_env("VS_TEST_FAIL_ALLOC"); return e ? atoll(e) : 0LL; }()};
 static bool alloc_injected_failure() {
-    const long long k = ++g_alloc_count;
-    return k == g_alloc_fail_at.load(std::memory_order_relaxed);
+    const long long k = ++g_alloc_count, at = g_alloc_fail_at.load(std::memory_order_relaxed);
+    if (at < 0 && k == -at) throw std::bad_alloc();        // vs_test_fail_alloc(-k): a HOST allocation failing at this point of the call
+    return k == at;
 }
 hipError_t dev_alloc(void** p, size_t bytes) {
     *p = nullptr;
@@ -260,10 +262,10 @@ static inline int finish_host(int mem, hipStream_t s) {
 
 extern "C" {
 
-int vs_stream_retire(void* stream) {
+int vs_stream_retire(void* stream) try {
     VS_HIP(vsi::retire_stream((hipStream_t)stream));      // a fault of the work that was in flight on the stream surfaces here
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 // ---- the debug build's bounds record (vs_device.hpp, -DVS_DEBUG_BOUNDS) ---------------------------------------------------
 #ifdef VS_DEBUG_BOUNDS
@@ -286,7 +288,7 @@ VS_BOUNDS_TU(vs_bounds_fetch_capi)
 extern "C" {
 #endif
 
-int vs_debug_bounds_check(void) {
+int vs_debug_bounds_check(void) try {
 #ifdef VS_DEBUG_BOUNDS
     if (!vsi::device_ready()) return VS_ERR_HIP;
     VS_HIP(hipDeviceSynchronize());
@@ -306,9 +308,9 @@ int vs_debug_bounds_check(void) {
 #else
     return set_error(VS_ERR_UNSUPPORTED, "vs_debug_bounds_check: this is not a -DVS_DEBUG_BOUNDS build of libvs_amd (tools/build_variant.sh bounds)");
 #endif
-}
+} VS_CATCH_ALL
 
-int vs_debug_bounds_selftest(void) {
+int vs_debug_bounds_selftest(void) try {
 #ifdef VS_DEBUG_BOUNDS
     if (!vsi::device_ready()) return VS_ERR_HIP;
     vsi::DevBuf out;
@@ -321,26 +323,26 @@ int vs_debug_bounds_selftest(void) {
 #else
     return set_error(VS_ERR_UNSUPPORTED, "vs_debug_bounds_selftest: this is not a -DVS_DEBUG_BOUNDS build of libvs_amd");
 #endif
-}
+} VS_CATCH_ALL
 
-int vs_test_fail_alloc(int k) {
+int vs_test_fail_alloc(int k) try {
     const long long seen = vsi::g_alloc_count.exchange(0);
-    vsi::g_alloc_fail_at.store(k > 0 ? k : 0);
+    vsi::g_alloc_fail_at.store(k);                         // k > 0: the k-th allocation reports out-of-memory; k < 0: it throws std::bad_alloc; 0: disarmed
     return (int)std::min<long long>(seen, 0x7fffffff);
-}
+} VS_CATCH_ALL
 
-int vs_device_count(void) {
+int vs_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} VS_CATCH_ALL
 
-int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stream) {
+int vs_calib_copy12(const void* src_dev, void* dst_dev, size_t bytes, void* stream) try {
     VS_ARG(src_dev && dst_dev && bytes >= 12);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     VS_HIP(vsk::calib_copy12(src_dev, dst_dev, bytes, (hipStream_t)stream));
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 // the shader clock from inside a kernel: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
 __global__ __launch_bounds__(256) void vs_k_clock_probe(unsigned long long* out, float seed, int iters) {
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void vs_k_clock_probe(unsigned long long* out,
     if (a0 + a1 + a2 + a3 == 12345.678f) out[2] = 1;                  // keeps the chains alive
 }
 
-int vs_shader_clock_probe(void* stream, double* shader_mhz) {
+int vs_shader_clock_probe(void* stream, double* shader_mhz) try {
     VS_ARG(shader_mhz);
     if (!vsi::device_ready()) return VS_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
@@ -379,10 +381,10 @@ int vs_shader_clock_probe(void* stream, double* shader_mhz) {
     VS_HIP(e);
     *shader_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, int ow, int oh, int out_stride, int mem,
-                void* stream) {
+                void* stream) try {
     VS_DIMS(w, h); VS_DIMS(ow, oh);
     VS_ARG(in && out && w > 0 && h > 0 && ow > 0 && oh > 0 && in_stride >= w && out_stride >= ow);
     VS_ARG(2 * ow <= w + 1 && 2 * oh <= h + 1);
@@ -394,12 +396,12 @@ int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, in
     VS_HIP(vsk::pyr_down(a.as<uint8_t>(), w, h, in_stride, b.as<uint8_t>(), ow, oh, out_stride, 1, 0, 0, s));
     VS_TRY(b.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_optimal_dft_size(int n) { return vsp::optimal_dft_size(n); }
 
 int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int stride, int mem, void* stream, float* surface,
-                       double* result) {
+                       double* result) try {
     VS_DIMS(w, h);
     VS_ARG(a && b && result && w > 0 && h > 0 && stride >= w);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -430,9 +432,9 @@ int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int str
     VS_HIP(hipStreamSynchronize(s));        // the result is a host value: this call always synchronises
     result[0] = r.dx; result[1] = r.dy; result[2] = r.response;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream) {
+int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy, int mem, void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(in && gx && gy && w > 0 && h > 0 && stride >= w);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -445,10 +447,10 @@ int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy
     VS_TRY(x.finish(s));
     VS_TRY(y.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy, int mem,
-                   void* stream) {
+                   void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(gx && gy && lmx && lmy && w > 0 && h > 0 && ts >= 1 && ts <= 64);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -463,10 +465,10 @@ int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint1
     VS_TRY(x.finish(s));
     VS_TRY(y.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy, int tx, int ty,
-                  float* out_x, float* out_y, int mem, void* stream) {
+                  float* out_x, float* out_y, int mem, void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(gx && gy && lmx && lmy && out_x && out_y && w > 0 && h > 0 && tx > 0 && ty > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -484,10 +486,10 @@ int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t
     VS_TRY(x.finish(s));
     VS_TRY(y.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
-                      float* jy, int mem, void* stream) {
+                      float* jy, int mem, void* stream) try {
     VS_ARG(in && lmx && lmy && jx && jy && w > 0 && h > 0 && stride >= w && ts >= 1 && ts <= 64);
     VS_ARG(w <= 65535 && h <= 65535);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -503,10 +505,10 @@ int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint1
                          q.as<float>(), 1, 0, 0, 0, s));
     VS_TRY(x.finish(s)); VS_TRY(y.finish(s)); VS_TRY(p.finish(s)); VS_TRY(q.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm, int tx,
-                       int ty, float A, float B, float TX, float TY, uint16_t* out, int mem, void* stream) {
+                       int ty, float A, float B, float TX, float TY, uint16_t* out, int mem, void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(tmpl && key && lm && out && w > 0 && h > 0 && stride >= w && tx > 0 && ty > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -521,11 +523,11 @@ int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, in
                                 o.as<uint16_t>(), s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
                   const uint16_t* sely, int ny, const float* jacx, const float* jacy, float A, float B, float TX, float TY,
-                  double* out4, int mem, void* stream) {
+                  double* out4, int mem, void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(tmpl && key && out4 && w > 0 && h > 0 && stride >= w && nx >= 0 && ny >= 0);
     VS_ARG((nx == 0 || (selx && jacx)) && (ny == 0 || (sely && jacy)));
@@ -543,10 +545,10 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
                            jx.as<float>(), jy.as<float>(), A, B, TX, TY, o.as<double>(), s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out, int ow,
-                  int oh, int mem, void* stream) {
+                  int oh, int mem, void* stream) try {
     VS_DIMS(w, h); VS_DIMS(ow, oh);
     VS_ARG(in && out && w > 0 && h > 0 && stride >= w && ow > 0 && oh > 0);
     if (!vsi::device_ready()) return VS_ERR_HIP;
@@ -557,7 +559,7 @@ int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B,
     VS_HIP(vsk::image_warp(a.as<uint8_t>(), w, h, stride, A, B, TX, TY, o.as<float>(), ow, oh, s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 // roi = NULL: the whole w x h output.  Otherwise dst holds only the window (roi->w x roi->h pixels per frame).
 static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
@@ -635,34 +637,34 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
 }
 
 int vs_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,
-                      int mode, int border, int max_value, void* dst, int dst_stride, int mem, void* stream) {
+                      int mode, int border, int max_value, void* dst, int dst_stride, int mem, void* stream) try {
     return bgr_warp_common(src, 0, 1, w, h, src_stride, channels, bits, t, mode, border, max_value, dst, 0, dst_stride,
                            false, mem, (hipStream_t)stream);
-}
+} VS_CATCH_ALL
 
 int vs_bgr_image_warp_batch(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
                             int bits, const vs_transform* t, int mode, int border, int max_value, void* dst,
-                            size_t dst_fs, int dst_stride, int mem, void* stream) {
+                            size_t dst_fs, int dst_stride, int mem, void* stream) try {
     return bgr_warp_common(src, src_fs, n_frames, w, h, src_stride, channels, bits, t, mode, border, max_value, dst,
                            dst_fs, dst_stride, false, mem, (hipStream_t)stream);
-}
+} VS_CATCH_ALL
 
 int vs_bgr_image_warp_roi_batch(const void* src, size_t src_fs, int n_frames, int w, int h, int src_stride, int channels,
                                 int bits, const vs_transform* t, int mode, int border, int max_value, int roi_x, int roi_y,
-                                int roi_w, int roi_h, void* dst, size_t dst_fs, int dst_stride, int mem, void* stream) {
+                                int roi_w, int roi_h, void* dst, size_t dst_fs, int dst_stride, int mem, void* stream) try {
     const vsk::Roi roi{roi_x, roi_y, roi_w, roi_h};
     return bgr_warp_common(src, src_fs, n_frames, w, h, src_stride, channels, bits, t, mode, border, max_value, dst,
                            dst_fs, dst_stride, false, mem, (hipStream_t)stream, &roi);
-}
+} VS_CATCH_ALL
 
 int vs_bgr_image_warp_f32(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,
-                          int mode, int border, float* dst, int dst_stride, int mem, void* stream) {
+                          int mode, int border, float* dst, int dst_stride, int mem, void* stream) try {
     return bgr_warp_common(src, 0, 1, w, h, src_stride, channels, bits, t, mode, border, 0, dst, 0, dst_stride, true, mem,
                            (hipStream_t)stream);
-}
+} VS_CATCH_ALL
 
 int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int shift_to_8, uint8_t* dst, int dst_stride,
-                   int mem, void* stream) {
+                   int mem, void* stream) try {
     VS_DIMS(w, h);
     VS_ARG(src && dst && w > 0 && h > 0 && src_stride >= 3 * w && dst_stride >= w && (bits == 8 || bits == 16));
     VS_ARG(shift_to_8 >= 0 && shift_to_8 <= 8);
@@ -674,6 +676,6 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
     VS_HIP(vsk::bgr_to_gray(a.dev, w, h, src_stride, bits, shift_to_8, o.as<uint8_t>(), dst_stride, 1, 0, 0, s));
     VS_TRY(o.finish(s));
     return finish_host(mem, s);
-}
+} VS_CATCH_ALL
 
 }  // extern "C"

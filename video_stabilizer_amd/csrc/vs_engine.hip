@@ -1051,15 +1051,15 @@ extern "C" {
 static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
                                 int32_t* status, int mem, void* stream, int rule);
 int vs_select_smallest(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
-                       int32_t* status, int mem, void* stream) {
+                       int32_t* status, int mem, void* stream) try {
     VS_ARG(status);
     return select_smallest_impl(warpdiff, n_arrays, tx, ty, fraction, out_idx, status, mem, stream, 0);
-}
+} VS_CATCH_ALL
 // ... under VS_SELECT_STABLE's rule: smallest by (abs_delta, tile index), the survivors in ascending tile order
 int vs_select_smallest_stable(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx, int mem,
-                              void* stream) {
+                              void* stream) try {
     return select_smallest_impl(warpdiff, n_arrays, tx, ty, fraction, out_idx, nullptr, mem, stream, 1);
-}
+} VS_CATCH_ALL
 static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, int ty, float fraction, int32_t* out_idx,
                                 int32_t* status, int mem, void* stream, int rule) {
     VS_ARG(warpdiff && out_idx && (status || rule) && n_arrays >= 1 && tx >= 1 && ty >= 1 && fraction > 0.0f && fraction <= 1.0f);
@@ -1086,7 +1086,7 @@ static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, 
     return nsel;
 }
 
-vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
+vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) try {
     if (!vsi::device_ready()) return nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
@@ -1132,7 +1132,7 @@ vs_aligner* vs_aligner_create(const vs_aligner_params* params, int device) {
         return nullptr;
     }
     return a;
-}
+} VS_CATCH_ALL_NULL
 
 void vs_aligner_destroy(vs_aligner* a) {
     if (!a) return;
@@ -1140,33 +1140,33 @@ void vs_aligner_destroy(vs_aligner* a) {
     delete a;
 }
 
-int vs_aligner_set_select_mode(vs_aligner* a, int mode) {
+int vs_aligner_set_select_mode(vs_aligner* a, int mode) try {
     VS_ARG(a && (mode == VS_SELECT_STL_HOST || mode == VS_SELECT_DEVICE || mode == VS_SELECT_STABLE));
     a->select_mode = mode;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_get_select_mode(const vs_aligner* a) {
+int vs_aligner_get_select_mode(const vs_aligner* a) try {
     VS_ARG(a);
     return a->select_mode;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_set_batch_mode(vs_aligner* a, int mode) {
+int vs_aligner_set_batch_mode(vs_aligner* a, int mode) try {
     VS_ARG(a && (mode == VS_BATCH_EXCLUSIVE || mode == VS_BATCH_SHARED));
     a->batch_mode = mode;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_reset(vs_aligner* a) {
+int vs_aligner_reset(vs_aligner* a) try {
     VS_ARG(a);
     a->seq = 0;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 void* vs_aligner_stream(const vs_aligner* a) { return a ? (void*)a->stream : nullptr; }
 
 // Everything enqueued on `producer_stream` so far happens before anything the handle enqueues from now on.
-int vs_aligner_wait_stream(vs_aligner* a, void* producer_stream) {
+int vs_aligner_wait_stream(vs_aligner* a, void* producer_stream) try {
     VS_ARG(a);
     VS_HIP(hipSetDevice(a->device));
     hipEvent_t ev = nullptr;
@@ -1176,7 +1176,7 @@ int vs_aligner_wait_stream(vs_aligner* a, void* producer_stream) {
     (void)hipEventDestroy(ev);        // the wait already holds what it needs; destruction is deferred by the runtime
     VS_HIP(e);
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 }  // extern "C"
 
@@ -1205,7 +1205,8 @@ static int align_start(vs_aligner* a, const void* frames, size_t frame_stride, i
     if (a->started || a->ck.open) return set_error(VS_ERR_ARG, "an alignment is already in flight on this handle");
     a->started_result = 0;
     if (clip_frames > 0) { a->seq = 0; a->clip_len = clip_frames; a->started_clips = true; }
-    const int r = align_start_impl(a, frames, frame_stride, n, w, h, stride, format, mem, params, out, status, async);
+    // (guarded: an exception -- a host allocation that fails -- ends the call like any other stage failure, under the protocol below)
+    const int r = vsi::guarded([&] { return align_start_impl(a, frames, frame_stride, n, w, h, stride, format, mem, params, out, status, async); });
     // a call REJECTED for its arguments (VS_ERR_ARG: every such test precedes the first touch of the handle's state) leaves the running
     // sequence alone -- the reference resets only when a kernel stage fails (alignment.cpp:357-367); any later error ends it
     if (r < 0) { a->started = false; align_close_clips(a); if (r != VS_ERR_ARG) align_failed(a); }
@@ -1215,7 +1216,7 @@ static int align_finish(vs_aligner* a) {
     int r = a->started_result;
     if (a->started) {
         a->started = false;
-        r = a->chunk_end();
+        r = vsi::guarded([&] { return a->chunk_end(); });
         if (r == VS_OK) for (int i = 0; i < a->started_n; i++) r += a->started_status[i];
     }
     align_close_clips(a);
@@ -1232,10 +1233,10 @@ static void align_abandon(vs_aligner* a) {
 extern "C" {
 
 int vs_aligner_align_batch(vs_aligner* a, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
-                           int format, int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status) {
+                           int format, int mem, const vs_aligner_params* params, vs_transform* out, int32_t* status) try {
     const int r = align_start(a, frames, frame_stride, n, 0, w, h, stride, format, mem, params, out, status, false);
     return r < 0 ? r : align_finish(a);
-}
+} VS_CATCH_ALL
 
 }  // extern "C"
 
@@ -1324,56 +1325,56 @@ extern "C" {
 // clips still fill the GPU).  The handle's running sequence is reset before and after.
 int vs_aligner_align_clips(vs_aligner* a, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip, int w,
                            int h, int stride, int format, int mem, const vs_aligner_params* params, vs_transform* out,
-                           int32_t* status) {
+                           int32_t* status) try {
     VS_ARG(a && n_clips >= 1 && frames_per_clip >= 1 && (long long)n_clips * frames_per_clip <= 0x7fffffff);
     const int r = align_start(a, frames, frame_stride, n_clips * frames_per_clip, frames_per_clip, w, h, stride, format, mem, params, out,
                               status, false);
     return r < 0 ? r : align_finish(a);
-}
+} VS_CATCH_ALL
 
 int vs_aligner_align_next(vs_aligner* a, const void* frame, int w, int h, int stride, int format, int mem,
-                          const vs_aligner_params* params, vs_transform* out) {
+                          const vs_aligner_params* params, vs_transform* out) try {
     int32_t st = 0;
     int r = vs_aligner_align_batch(a, frame, 0, 1, w, h, stride, format, mem, params, out, &st);
     if (r < 0) return r;
     return st;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_enable_timing(vs_aligner* a, int enable) {
+int vs_aligner_enable_timing(vs_aligner* a, int enable) try {
     VS_ARG(a);
     a->timing = enable != 0;
     memset(&a->tm, 0, sizeof(a->tm));
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_get_timings(vs_aligner* a, vs_stage_timings* out) {
+int vs_aligner_get_timings(vs_aligner* a, vs_stage_timings* out) try {
     VS_ARG(a && out);
     *out = a->tm;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info) {
+int vs_aligner_get_info(const vs_aligner* a, int i, vs_align_info* info) try {
     VS_ARG(a && info && i >= 0 && i < (int)a->info.size());
     *info = a->info[i];
     return VS_OK;
-}
+} VS_CATCH_ALL
 
-int vs_aligner_level_dims(const vs_aligner* a, int level, int* w, int* h, int* tx, int* ty, int* ts) {
+int vs_aligner_level_dims(const vs_aligner* a, int level, int* w, int* h, int* tx, int* ty, int* ts) try {
     VS_ARG(a && level >= 0 && level < a->levels);
     const LevelDims& l = a->L[level];
     if (w) *w = l.w; if (h) *h = l.h; if (tx) *tx = l.tx; if (ty) *ty = l.ty; if (ts) *ts = l.ts;
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 // frame i of the most recent chunk lives in slot i+1 (only valid for calls that fit one chunk)
-int vs_aligner_read_level_image(const vs_aligner* a, int i, int level, uint8_t* out) {
+int vs_aligner_read_level_image(const vs_aligner* a, int i, int level, uint8_t* out) try {
     VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n);
     const LevelDims& l = a->L[level];
     VS_HIP(hipSetDevice(a->device));
     VS_HIP(hipMemcpy(out, a->pyr + (size_t)(i + 1) * a->pyr_frame + l.img_off, (size_t)l.w * l.h, hipMemcpyDeviceToHost));
     return VS_OK;
-}
-int vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set, uint16_t* out) {
+} VS_CATCH_ALL
+int vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set, uint16_t* out) try {
     VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
     const LevelDims& l = a->L[level];
     VS_HIP(hipSetDevice(a->device));
@@ -1383,8 +1384,8 @@ int vs_aligner_read_level_argmax(const vs_aligner* a, int i, int level, int set,
                      hipMemcpyDeviceToHost));
     for (int t = 0; t < l.nt; t++) { out[t] = pairs[2 * (size_t)t]; out[(size_t)l.nt + t] = pairs[2 * (size_t)t + 1]; }
     return VS_OK;
-}
-int vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out) {
+} VS_CATCH_ALL
+int vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int set, float* out) try {
     VS_ARG(a && out && level >= 0 && level < a->levels && i >= 0 && i < a->last_n && (set == 0 || set == 1));
     const LevelDims& l = a->L[level];
     VS_HIP(hipSetDevice(a->device));
@@ -1395,7 +1396,7 @@ int vs_aligner_read_level_jacobian(const vs_aligner* a, int i, int level, int se
     for (int t = 0; t < l.nt; t++)
         for (int c = 0; c < 4; c++) out[(size_t)c * l.nt + t] = quads[4 * (size_t)t + c];
     return VS_OK;
-}
+} VS_CATCH_ALL
 
 }  // extern "C"
 
@@ -1447,7 +1448,7 @@ static void stab_drop_frames(vs_stabilizer* s) {
 
 extern "C" {
 
-vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int device) {
+vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int device) try {
     vs_stabilizer_params p;
     if (params) p = *params; else vs_stabilizer_params_default(&p);
     vs_aligner* a = vs_aligner_create(&p.aligner, device);
@@ -1457,7 +1458,7 @@ vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int devi
     s->aligner = a;
     s->smoother = vs_smoother_create(p.lag, p.smoother_memory, p.lambda);   // stabilizer.cpp:4
     return s;
-}
+} VS_CATCH_ALL_NULL
 
 void vs_stabilizer_destroy(vs_stabilizer* s) {
     if (!s) return;
@@ -1540,8 +1541,8 @@ static int stab_run(vs_stabilizer* s, const void* frames, size_t frame_stride, i
         time_chunk = std::max(overlap_mode == VS_BATCH_EXCLUSIVE ? 120 : 48, (n + max_time_chunks - 1) / max_time_chunks);
     if (time_chunk >= n) time_chunk = 0;
     if (chunk > 0 && n > chunk)
-        r = stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride, has_output,
-                                    out_w, out_h);
+        r = vsi::guarded([&] { return stab_run_host_pipelined(s, frames, frame_stride, n, clip_len, chunk, w, h, stride, format, out, out_frame_stride,
+                                                              has_output, out_w, out_h); });
     else if (group_clips > 0) {
         vs_aligner* a = s->aligner;
         r = 0;
@@ -1679,7 +1680,7 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
     return produced;
 }
 
-static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
+static int stab_run_impl_unguarded(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
                          int format, int mem, int out_mem, int slot_arg, void* out, size_t out_frame_stride, int32_t* has_output,
                          int* out_w, int* out_h) {
     // slot_arg >= 0: a chunk of the pipelined host batch -- its outputs leave through output area `slot_arg` and a downloader
@@ -1911,37 +1912,44 @@ static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stri
     for (int i = 0; i < n; i++) produced += has_output[i];
     return produced;
 }
+static int stab_run_impl(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int clip_len, int w, int h, int stride,
+                         int format, int mem, int out_mem, int slot_arg, void* out, size_t out_frame_stride, int32_t* has_output,
+                         int* out_w, int* out_h) {
+    // (guarded: an exception inside a chunk -- a host allocation that fails -- comes back as an error code, so that the callers' loops restore
+    // the handle's modes and stab_run's failure protocol runs)
+    return vsi::guarded([&] { return stab_run_impl_unguarded(s, frames, frame_stride, n, clip_len, w, h, stride, format, mem, out_mem, slot_arg, out, out_frame_stride, has_output, out_w, out_h); });
+}
 
 int vs_stabilizer_process_batch(vs_stabilizer* s, const void* frames, size_t frame_stride, int n, int w, int h, int stride,
                                 int format, int mem, void* out, size_t out_frame_stride, int32_t* has_output, int* out_w,
-                                int* out_h) {
+                                int* out_h) try {
     return stab_run(s, frames, frame_stride, n, 0, w, h, stride, format, mem, out, out_frame_stride, has_output, out_w, out_h);
-}
+} VS_CATCH_ALL
 
 int vs_stabilizer_process_clips(vs_stabilizer* s, const void* frames, size_t frame_stride, int n_clips, int frames_per_clip,
                                 int w, int h, int stride, int format, int mem, void* out, size_t out_frame_stride,
-                                int32_t* has_output, int* out_w, int* out_h) {
+                                int32_t* has_output, int* out_w, int* out_h) try {
     VS_ARG(n_clips >= 1 && frames_per_clip >= 1 && (long long)n_clips * frames_per_clip <= 0x7fffffff);
     return stab_run(s, frames, frame_stride, n_clips * frames_per_clip, frames_per_clip, w, h, stride, format, mem, out,
                     out_frame_stride, has_output, out_w, out_h);
-}
+} VS_CATCH_ALL
 
 // forget the clip: the next frame starts a new sequence (device buffers are kept)
 void* vs_stabilizer_stream(const vs_stabilizer* s) { return s && s->aligner ? (void*)s->aligner->stream : nullptr; }
-int vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode) {
+int vs_stabilizer_set_select_mode(vs_stabilizer* s, int mode) try {
     VS_ARG(s && s->aligner);
     return vs_aligner_set_select_mode(s->aligner, mode);
-}
-int vs_stabilizer_get_select_mode(const vs_stabilizer* s) {
+} VS_CATCH_ALL
+int vs_stabilizer_get_select_mode(const vs_stabilizer* s) try {
     VS_ARG(s && s->aligner);
     return s->aligner->select_mode;
-}
-int vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream) {
+} VS_CATCH_ALL
+int vs_stabilizer_wait_stream(vs_stabilizer* s, void* producer_stream) try {
     VS_ARG(s && s->aligner);
     return vs_aligner_wait_stream(s->aligner, producer_stream);
-}
+} VS_CATCH_ALL
 
-int vs_stabilizer_reset(vs_stabilizer* s) {
+int vs_stabilizer_reset(vs_stabilizer* s) try {
     VS_ARG(s);
     VS_HIP(hipSetDevice(s->aligner->device));
     for (auto& f : s->frames) if (f.owned) s->pool.push_back(f.ptr);
@@ -1954,14 +1962,14 @@ int vs_stabilizer_reset(vs_stabilizer* s) {
     s->last_success = 0;
     s->frame_index = 0;
     return vs_aligner_reset(s->aligner);
-}
+} VS_CATCH_ALL
 
 int vs_stabilizer_process(vs_stabilizer* s, const void* frame, int w, int h, int stride, int format, int mem, void* out,
-                          int* out_w, int* out_h) {
+                          int* out_w, int* out_h) try {
     int32_t has = 0;
     int r = vs_stabilizer_process_batch(s, frame, 0, 1, w, h, stride, format, mem, out, 0, &has, out_w, out_h);
     return r < 0 ? r : has;
-}
+} VS_CATCH_ALL
 
 void vs_stabilizer_state(const vs_stabilizer* s, vs_transform* last_meas, vs_transform* accum, int* last_success) {
     if (last_meas) *last_meas = s->last_meas;

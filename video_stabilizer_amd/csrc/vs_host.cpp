@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <vector>
 
 namespace vsi {
@@ -17,17 +19,23 @@ int set_error(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int caught() noexcept {
+    try { throw; }
+    catch (const std::bad_alloc&) { return set_error(VS_ERR_NOMEM, "host allocation failed (std::bad_alloc)"); }
+    catch (const std::exception& e) { return set_error(VS_ERR_NOMEM, "C++ exception stopped at the C boundary: %s", e.what()); }
+    catch (...) { return set_error(VS_ERR_NOMEM, "unknown C++ exception stopped at the C boundary"); }
+}
 }  // namespace vsi
 
 extern "C" {
 
 const char* vs_last_error(void) { return vsi::g_err; }
-const char* vs_version(void) { return "video_stabilizer_amd 0.4 (gfx950, ABI 4)"; }
+const char* vs_version(void) { return "video_stabilizer_amd 0.5 (gfx950, ABI 5)"; }
 int vs_abi_version(void) { return VS_ABI_VERSION; }
 size_t vs_sizeof_align_info(void) { return sizeof(vs_align_info); }
 
 // alignment.hpp:5-41
-int vs_format_bits(int format) {
+int vs_format_bits(int format) try {
     switch (format) {
         case VS_FMT_GRAY8: case VS_FMT_BGR8: return 8;
         case VS_FMT_BGR10: return 10;
@@ -35,11 +43,11 @@ int vs_format_bits(int format) {
         case VS_FMT_BGR16_FULL: return 16;
         default: return 0;
     }
-}
-int vs_format_max_value(int format) {
+} VS_CATCH_ALL
+int vs_format_max_value(int format) try {
     const int b = vs_format_bits(format);
     return b ? (1 << b) - 1 : 0;
-}
+} VS_CATCH_ALL
 
 void vs_aligner_params_default(vs_aligner_params* p) {
     p->phase_correlate = 0;
@@ -124,14 +132,14 @@ double vs_transform_max_corner_displacement(const vs_transform* t, double width,
 }
 
 // imgproc.cpp:151-162
-int vs_tile_size(int w, int h) {
+int vs_tile_size(int w, int h) try {
     int tile_size = 2;
     for (int i = 4; i <= 20; i += 2) {
         if ((w / i) * (h / i) < 1000) break;
         tile_size = i;
     }
     return tile_size;
-}
+} VS_CATCH_ALL
 
 // imgproc.cpp:69-75 / 98-103
 void vs_ul_params_sparse(const vs_transform* t, int w, int h, float out4[4]) {
@@ -202,16 +210,16 @@ struct vs_smoother {
 
 extern "C" {
 
-vs_smoother* vs_smoother_create(int lag_behind, int lag_ahead, double lambda) {
+vs_smoother* vs_smoother_create(int lag_behind, int lag_ahead, double lambda) try {
     vs_smoother* s = new vs_smoother();
     s->lag_behind = lag_behind;
     s->lag_ahead = lag_ahead;
     s->lambda = lambda;
     return s;
-}
+} VS_CATCH_ALL_NULL
 void vs_smoother_destroy(vs_smoother* s) { delete s; }
 
-int vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* out_finalized) {
+int vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* out_finalized) try {
     s->measurements.push_back(*meas);
     const int newest = (int)s->measurements.size() - 1;
     if (s->next_to_finalize + s->lag_ahead > newest) return 0;
@@ -273,6 +281,6 @@ int vs_smoother_update(vs_smoother* s, const vs_transform* meas, vs_transform* o
     }
     s->next_to_finalize++;
     return 1;
-}
+} VS_CATCH_ALL
 
 }  // extern "C"

@@ -9,7 +9,17 @@
 namespace vsi {
 // records a thread-local message for vs_last_error() and returns `code`
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// No exception crosses the C ABI (include/vs_amd.h).  caught(): inside a catch block, turns the in-flight exception into VS_ERR_NOMEM and a
+// message; guarded(f): runs f() and stops whatever it throws.  Every extern "C" entry point that can allocate on the host is a
+// function-try-block ending in VS_CATCH_ALL; the engine calls also guard their inner stages, so that their failure protocol runs.
+int caught() noexcept;
+template <typename F>
+inline int guarded(F&& f) noexcept {
+    try { return f(); } catch (...) { return caught(); }
+}
 }  // namespace vsi
+#define VS_CATCH_ALL catch (...) { return vsi::caught(); }
+#define VS_CATCH_ALL_NULL catch (...) { (void)vsi::caught(); return nullptr; }
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
