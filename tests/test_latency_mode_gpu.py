@@ -28,7 +28,24 @@ import torch                      # before the library: one HIP runtime per proc
 torch.cuda.init()
 from video_stabilizer_amd import capi, synth
 w, h, n, batch = (int(a) for a in sys.argv[2:6])
-frames, _ = synth.make_clip(w, h, n, seed=77, channels=3)
+# (the numpy generator takes ~1.5 s per 4K frame and every configuration is a process of its own: the clip is generated once per size and
+# handed from child to child through a file -- same seeded frames, a prefix of the longest clip made so far)
+import os, tempfile, numpy as np
+cache = os.path.join(tempfile.gettempdir(), "vs_latency_clip_%dx%d_seed77_uid%d.npy" % (w, h, os.getuid()))
+frames = None
+try:
+    c = np.load(cache, mmap_mode="r")
+    if c.shape[0] >= n and c.shape[1:] == (h, w, 3): frames = np.ascontiguousarray(c[:n])
+except Exception:
+    frames = None
+if frames is None:
+    frames, _ = synth.make_clip(w, h, n, seed=77, channels=3)
+    try:
+        tmp = cache + ".%d.tmp.npy" % os.getpid()
+        np.save(tmp, frames)
+        os.replace(tmp, cache)
+    except Exception:
+        pass
 al = capi.Aligner(device=0, pyramid_min_width=int(sys.argv[6]) if len(sys.argv) > 6 else 256)
 if len(sys.argv) > 7 and int(sys.argv[7]): al.set_batch_mode(capi.BATCH_SHARED)
 out = []
