@@ -154,8 +154,8 @@ def test_stabilizer_process_clips_device_every_allocation(gpu_vs):
 
 
 def test_exceptions_stop_at_the_c_boundary(gpu_vs):
-    """include/vs_amd.h: "No exceptions cross".  The same walks with the allocation THROWING std::bad_alloc (every other k: the walks above cover
-    every k with error codes): the call returns VS_ERR_NOMEM, the next call on the handle equals a fresh handle's, nothing leaks."""
+    """include/vs_amd.h: "No exceptions cross".  The same walks with the allocation THROWING std::bad_alloc: the call returns VS_ERR_NOMEM, the next
+    call on the handle equals a fresh handle's, nothing leaks."""
     import torch
     vs = gpu_vs
     frames = _clip(6)
@@ -164,14 +164,25 @@ def test_exceptions_stop_at_the_c_boundary(gpu_vs):
     def align(h):
         st, ts = h.align_batch_device(dev.data_ptr(), 6, W, H, vs.FMT_BGR8)
         return list(st), _tr(ts)
-    n1 = _walk(vs, lambda: vs.Aligner(device=0), align, min_fired=7, throwing=True, stride=2)
+    n1 = _walk(vs, lambda: vs.Aligner(device=0), align, min_fired=14, throwing=True)
     host = _clip(16, seed=7)
 
     def batch(s):
         out, has = s.process_batch(host)
         return list(has), out.tobytes()
-    n2 = _walk(vs, lambda: vs.Stabilizer(device=0, lag=4, smoother_memory=2, crop_pixels=8), batch, min_fired=8, throwing=True, stride=2)   # (library defaults: the fixed-point bilinear warp)
-    print("exceptions stopped at the boundary: %d (align_batch, device frames) + %d (process_batch, host frames)" % (n1, n2))
+    n2 = _walk(vs, lambda: vs.Stabilizer(device=0, lag=4, smoother_memory=2, crop_pixels=8), batch, min_fired=17, throwing=True)   # (library defaults: the fixed-point bilinear warp)
+    # device-resident clips: the overlapped groups (warps on their own stream, the next group's alignment prefetched; exclusive solver build beside this warp)
+    n_clips, fpc, crop = 4, 34, 8
+    cdev = torch.from_numpy(np.concatenate([_clip(fpc, seed=20 + c) for c in range(n_clips)])).cuda()
+    cout = torch.zeros((n_clips * fpc, H - 2 * crop, W - 2 * crop, 3), dtype=torch.uint8, device="cuda")
+
+    def clips(st):
+        cout.zero_()
+        r, has = st.process_clips_device(cdev.data_ptr(), n_clips, fpc, W, H, vs.FMT_BGR8, cout.data_ptr())
+        torch.cuda.synchronize()
+        return r, list(has), cout.cpu().numpy().tobytes()
+    n3 = _walk(vs, lambda: vs.Stabilizer(device=0, lag=5, crop_pixels=crop), clips, min_fired=14, throwing=True)
+    print("exceptions stopped at the boundary: %d (align_batch, device frames) + %d (process_batch, host frames) + %d (process_clips, device frames)" % (n1, n2, n3))
     # a kernel-level call: the parameter ring's first allocation on a fresh thread would be the natural case; any allocation will do
     vs.test_fail_alloc(-1)
     with pytest.raises(vs.VsError, match="error -5"):
