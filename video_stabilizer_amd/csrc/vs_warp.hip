@@ -83,8 +83,7 @@ constexpr int RPW = WT_H / 4;            // output rows per wave
 constexpr int RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW;
 static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
 constexpr int WS_W = 80;                 // staged source pixels per row (multiple of 4)
-constexpr int WS_H = WT_H + 8;           // staged source rows (multiple of 4)
-constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;   // fill items per thread: (row quads x column groups) / 16 per wave / 4 waves
+// (staged source rows: the tile height + 8, per kernel -- WS_H inside vs_k_bgr_warp_c3, CV_WS_H / CV16_WS_H for the fixed-point bilinear kernels)
 // A staged row holds WS_W pixels but is WS_RS slots long: 81 slots = 1296 bytes = 16 (mod 128), so the fill's ds_write_b128
 // (8-lane groups = 4 rows x 2 column groups, 64-byte column-group stride) touch every bank once.
 constexpr int WS_RS = WS_W + 1;
