@@ -24,6 +24,8 @@ def _torch_first():
     # torch first, where it is installed: torch ships its own copy of the HIP runtime, and the copy that is loaded first is
     # the one the whole process uses (same SONAME) -- the other way round torch finds "no HIP GPUs" in tests that also use
     # torch for device memory / streams.  bench.py imports in this order too ("one HIP runtime per process").
+    if os.environ.get("VS_AMD_LIB_PARTIAL") == "1":          # a host-only sanitizer build is under test: no HIP runtime in that process at all
+        return
     try:
         import torch
         if torch.cuda.is_available():
