@@ -1058,10 +1058,11 @@ def main():
                          "ms_per_step": round(1e3 * dt5 / steps5, 4), "steps": steps5, "frames_per_step": nc5 * n5, "outputs_per_step": outs5,
                          "dtype": "u16", "warp": "bgr_image_warp %s, crop %d, clamp border" % (WARP_MODES[args.warp_mode][2], crop5),
                          "value_counts": "input frames per second through vs_stabilizer_process_clips (every clip: 10 lag frames without an output)",
-                         "note": "BASELINE configs[4] on one GPU: %d of its 64 clips (64 / 8 GPUs); frames and outputs resident in HBM.  Parity at THIS size is "
-                                 "property-checked only (tests/test_configs_gpu.py: latency pattern, value range, clip independence; the oracle needs minutes "
-                                 "per 4K clip); the oracle comparison of the 10-bit stabilizer loop is at 640x360, the 10-bit pixel gates of the "
-                                 "contracted / separable forms are tests/test_warp_gate_gpu.py and tests/test_warp_sep_gpu.py" % nc5}
+                         "note": "BASELINE configs[4] on one GPU: %d of its 64 clips (64 / 8 GPUs); frames and outputs resident in HBM.  Parity at THIS size: one whole "
+                                 "60-frame clip against the oracle stabilizer frame for frame with the library's default warp, 14 frames with the separable Lanczos2 "
+                                 "(tests/test_configs_gpu.py::test_c5_full_size_clip_matches_the_oracle_stabilizer); the 8-clip batch itself is property-checked "
+                                 "(latency pattern, value range, clip independence), the 10-bit pixel gates of the contracted / separable forms are "
+                                 "tests/test_warp_gate_gpu.py and tests/test_warp_sep_gpu.py" % nc5}
             for key in WARP_MODES:
                 if key != args.warp_mode:
                     out["c5"][key + "_warp"] = {"value": round(nc5 * n5 * steps5 / res5[key][0], 2), "ms_per_step": round(1e3 * res5[key][0] / steps5, 4)}

@@ -5,7 +5,8 @@ to the host once, so the GPU path and the oracle see identical bytes.
   C3  4K BGR: bgr_image_warp Lanczos2 of a whole frame == oracle, bit for bit; 4K BGR alignment (4 levels) == oracle
   C4  many independent 1080p clips through vs_aligner_align_clips == one oracle aligner per clip
   C5  10-bit BGR through the full stabilizer loop (vs_stabilizer_process_clips) == one oracle stabilizer per clip;
-      one 3840x2160 10-bit clip of lag + 2 frames through size-independent properties
+      one 3840x2160 10-bit clip of lag + 2 frames through size-independent properties; one 3840x2160 10-bit clip through the loop against the
+      oracle stabilizer frame for frame (the default fixed-point bilinear warp and the separable Lanczos2)
   C4 / C5 at full size: one GPU's share of the 64-clip configs (8 clips x 120 x 1080p; 8 clips x 60 x 4K 10-bit), resident
       in HBM, in one call -- clip independence (a clip re-run alone is bit-identical), latency pattern, value range
 """
@@ -101,6 +102,39 @@ def test_c5_10bit_stabilizer_clips_match_one_oracle_stabilizer_per_clip(gpu_vs, 
             # rounding boundary, never further
             assert d.max() <= 1 and (d != 0).mean() < 1e-2, (c, k, int(d.max()), float((d != 0).mean()))
     assert produced == n_clips * (fpc - 10)
+
+
+@pytest.mark.parametrize("sampler,fpc,lag", [("default", 60, 10), ("separable", 14, 10)])
+def test_c5_full_size_clip_matches_the_oracle_stabilizer(gpu_vs, oracle, sampler, fpc, lag):
+    """configs[4] at its REAL frame size against the oracle ("C5 at full size is property-checked only"): one 3840 x 2160 10-bit
+    clip through the full stabilizer loop -- the library defaults (lag 10, L1 smoother, crop 32, cv::warpAffine's fixed-point bilinear on 16-bit
+    containers: a WHOLE 60-frame clip of the config, 50 outputs) and the separable Lanczos2 (14 frames, 4 outputs: the oracle's Lanczos2 takes seconds per 4K frame) --
+    frame for frame against one oracle stabilizer: same latency pattern, pixels within the 1-LSB band two warps leave whose transforms agree to 1e-4 px."""
+    w, h = 3840, 2160
+    clip = _device_clip(w, h, fpc, seed=2005, bits=10)[0]
+    kw = dict(pyramid_min_width=256)
+    if lag != 10:
+        kw.update(lag=lag, smoother_memory=2)
+    if sampler != "default":
+        kw.update(warp_mode=gpu_vs.WARP_LANCZOS2_SEP, warp_border=gpu_vs.BORDER_CLAMP)
+    g = gpu_vs.Stabilizer(device=0, **kw)
+    out, has = g.process_batch(clip)
+    okw = dict(kw)
+    if sampler != "default":
+        okw.update(warp_mode=oracle.WARP_LANCZOS2_SEPARABLE, warp_border=oracle.BORDER_CLAMP)
+    cpu = oracle.Stabilizer(**okw)
+    produced = 0
+    for k in range(fpc):
+        oc = cpu.process(clip[k])
+        assert bool(has[k]) == (oc is not None) == (k >= lag), k
+        if oc is None:
+            continue
+        produced += 1
+        og = out[k]
+        assert og.shape == oc.shape == (h - 64, w - 64, 3) and og.dtype == np.uint16 and int(og.max()) <= 1023
+        d = np.abs(og.astype(np.int32) - oc.astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-2, (sampler, k, int(d.max()), float((d != 0).mean()))
+    assert produced == fpc - lag
 
 
 def test_c5_4k_10bit_clip_properties(gpu_vs):
