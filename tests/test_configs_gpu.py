@@ -2,6 +2,7 @@
 test_engine_gpu.py).  Clips are made on the device by synth.TorchClipFactory (the generator bench.py uses) and copied
 to the host once, so the GPU path and the oracle see identical bytes.
 
+  C2 / C3  the WHOLE headline clips (240 x 1080p, 120 x 4K: bench.py's generator and seeds) through the aligner == oracle, frame for frame
   C3  4K BGR: bgr_image_warp Lanczos2 of a whole frame == oracle, bit for bit; 4K BGR alignment (4 levels) == oracle
   C4  many independent 1080p clips through vs_aligner_align_clips == one oracle aligner per clip
   C5  10-bit BGR through the full stabilizer loop (vs_stabilizer_process_clips) == one oracle stabilizer per clip;
@@ -55,6 +56,30 @@ def test_c3_4k_bgr_alignment_matches_the_oracle(gpu_vs, oracle):
         _same_alignment(gpu.info(i), dbg, st[i], ok_c, ts[i], t_c, i)
         good += bool(ok_c)
     assert good == 3
+
+
+@pytest.mark.parametrize("w,h,n,seed,levels", [(1920, 1080, 240, 1, 3), (3840, 2160, 120, 2, 4)])
+def test_whole_headline_clips_match_the_oracle_aligner(gpu_vs, oracle, w, h, n, seed, levels):
+    """BASELINE configs[1] and configs[2] at their real size AND length: the clip bench.py times (same generator, same seed) -- 240 frames of 1080p,
+    120 frames of 4K -- through vs_aligner_align_batch on device memory in one call, against the oracle aligner frame for frame: status, failure
+    reason, iterations per level, transform within 1e-4."""
+    import torch
+    from video_stabilizer_amd import synth
+    dev = torch.device("cuda", 0)
+    clip = synth.TorchClipFactory(w, h, seed, dev, channels=3, bits=8).make(n, seed)[0]
+    torch.cuda.synchronize()
+    kw = dict(pyramid_min_width=256)
+    gpu, cpu = gpu_vs.Aligner(device=0, **kw), oracle.Aligner(**kw)
+    st, ts = gpu.align_batch_device(clip.data_ptr(), n, w, h, gpu_vs.FMT_BGR8)
+    host = clip.cpu().numpy()
+    good = 0
+    for i in range(n):
+        ok_c, t_c = cpu.align_next(host[i])
+        dbg = cpu.debug()
+        assert i == 0 or dbg.levels == levels
+        _same_alignment(gpu.info(i), dbg, st[i], ok_c, ts[i], t_c, i)
+        good += bool(ok_c)
+    assert good == n - 1                                   # what bench.py counts as `aligned_per_step`
 
 
 def test_c4_many_1080p_clips_match_one_oracle_aligner_per_clip(gpu_vs, oracle):
@@ -173,11 +198,11 @@ def _device_clips(w, h, n_clips, fpc, seed, bits=8):
     return allf
 
 
-def test_c4_one_gpus_share_at_full_size(gpu_vs):
+def test_c4_one_gpus_share_at_full_size(gpu_vs, oracle):
     """configs[3] as one of 8 GPUs sees it: 8 clips x 120 frames of 1080p, resident in HBM, through ONE
-    vs_aligner_align_clips call.  Size-independent properties: every clip starts with a first frame, every other frame
-    aligns, and a clip's results do not depend on its neighbours -- clips 0, 3 and 7 re-run alone through a fresh aligner
-    give the same transforms bit for bit."""
+    vs_aligner_align_clips call.  Every clip starts with a first frame, every other frame aligns, a clip's results do not depend on its
+    neighbours -- clips 0, 3 and 7 re-run alone through a fresh aligner give the same transforms bit for bit -- and ALL 960 frames equal
+    one oracle aligner per clip (status, failure reason, iterations per level, transform within 1e-4)."""
     n_clips, fpc, w, h = 8, 120, 1920, 1080
     allf = _device_clips(w, h, n_clips, fpc, seed=1000)
     kw = dict(pyramid_min_width=256)
@@ -190,6 +215,12 @@ def test_c4_one_gpus_share_at_full_size(gpu_vs):
         s1, t1 = alone.align_batch_device(allf[c * fpc].data_ptr(), fpc, w, h, gpu_vs.FMT_BGR8)
         assert list(s1) == list(st[c * fpc:(c + 1) * fpc])
         assert [t.tup() for t in t1] == [t.tup() for t in ts[c * fpc:(c + 1) * fpc]], c
+    for c in range(n_clips):
+        cpu = oracle.Aligner(**kw)                          # a fresh VideoAligner per clip, as grid_search_align.cpp:174 does
+        host = allf[c * fpc:(c + 1) * fpc].cpu().numpy()
+        for k in range(fpc):
+            ok_c, t_c = cpu.align_next(host[k])
+            _same_alignment(al.info(c * fpc + k), cpu.debug(), st[c * fpc + k], ok_c, ts[c * fpc + k], t_c, (c, k))
 
 
 def test_c5_one_gpus_share_at_full_size(gpu_vs):
