@@ -23,7 +23,10 @@ LIB = os.path.join(ROOT, "video_stabilizer_amd", "variants", "libvs_amd_bounds.s
 
 @pytest.fixture(scope="module")
 def bounds_lib(gpu_vs):
-    if not os.path.exists(LIB):
+    # (built on demand, and again whenever a source of the library is newer than it: a stale variant would test yesterday's kernels)
+    csrc = os.path.join(ROOT, "video_stabilizer_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".inc", ".cpp"))] + [os.path.join(ROOT, "include", "vs_amd.h")]
+    if not os.path.exists(LIB) or max(os.path.getmtime(f) for f in srcs) > os.path.getmtime(LIB):
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "bounds"])
     assert os.path.exists(LIB)
     return LIB
