@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         // stages rows 3 (wv + 4 s) + r3 -- twelve rows further per slot: the source address advances by a UNIFORM 12 row pitches and the tile
         // address by a constant (an immediate of the ds_write), so a slot costs one compare beside its load and its four formatting
         // instructions (the 16-items-of-4-rows map of the rim path below: seven address instructions per slot).  60 of 64 lanes carry an item.
-        static_assert(WS_W / 4 == 20 && CV_WS_H % 12 == 0 && CV_FILL_SLOTS == CV_WS_H / 12, "row-triplet item map");
+        static_assert(WS_W / 4 == 20 && CV_FILL_SLOTS == (CV_WS_H + 11) / 12, "row-triplet item map");      // (a last, partial slot is cut by the row test)
         const uint32_t r3 = ((uint32_t)lane * 13u) >> 8, g = (uint32_t)lane - 20u * r3;                   // lane / 20, lane % 20 (lane < 64)
         const uint32_t row0 = 3u * (uint32_t)wv + r3;
         const bool col_live = r3 < 3u && (int)g < groups;
