@@ -1149,7 +1149,8 @@ constexpr int CV_TH = VS_WARP_CV_TILE_H, CV_RPW = CV_TH / 4, CV_WS_H = CV_TH + 8
 static_assert(CV_TH % 64 == 0 || CV_TH == 32, "row-origin table: waves 2 and 3 fill it 32 rows per pass each (X0 in lanes 0..31, Y0 in lanes 32..63)");
 constexpr int CV_RBK = CV_RPW < 16 ? CV_RPW : 16;          // rows of a wave sampled in one basic block
 static_assert(CV_RPW % CV_RBK == 0, "whole row blocks");
-constexpr int CV_FILL_SLOTS = (CV_WS_H / 4 * (WS_W / 4) + 63) / 64;
+constexpr int CV_FILL_SLOTS_RIM = (CV_WS_H / 4 * (WS_W / 4) + 63) / 64, CV_FILL_SLOTS_ROW = (CV_WS_H + 11) / 12;      // the rim path's item map / the row-triplet map
+constexpr int CV_FILL_SLOTS = CV_FILL_SLOTS_RIM > CV_FILL_SLOTS_ROW ? CV_FILL_SLOTS_RIM : CV_FILL_SLOTS_ROW;
 static_assert(CV_WS_H / 4 * (WS_W / 4) < 1024, "fill_item's p / 20 is exact below 1024");
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -1267,7 +1268,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         // stages rows 3 (wv + 4 s) + r3 -- twelve rows further per slot: the source address advances by a UNIFORM 12 row pitches and the tile
         // address by a constant (an immediate of the ds_write), so a slot costs one compare beside its load and its four formatting
         // instructions (the 16-items-of-4-rows map of the rim path below: seven address instructions per slot).  60 of 64 lanes carry an item.
-        static_assert(WS_W / 4 == 20 && CV_FILL_SLOTS == (CV_WS_H + 11) / 12, "row-triplet item map");      // (a last, partial slot is cut by the row test)
+        static_assert(WS_W / 4 == 20 && CV_FILL_SLOTS >= (CV_WS_H + 11) / 12, "row-triplet item map");      // (a last, partial slot is cut by the row test)
         const uint32_t r3 = ((uint32_t)lane * 13u) >> 8, g = (uint32_t)lane - 20u * r3;                   // lane / 20, lane % 20 (lane < 64)
         const uint32_t row0 = 3u * (uint32_t)wv + r3;
         const bool col_live = r3 < 3u && (int)g < groups;
