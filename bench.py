@@ -69,7 +69,7 @@ WARP_MODES = {
     "contracted": ("WARP_LANCZOS2_FAST", "WARP_LANCZOS2_CONTRACTED", "lanczos2 contracted (VS_WARP_LANCZOS2_FAST)"),
     "exact": ("WARP_LANCZOS2", "WARP_LANCZOS2", "lanczos2"),
 }
-WARP_BENCH_NAME = {"separable": "sep", "contracted": "fast", "exact": "lanczos2"}          # tools/warp_bench.py --mode
+WARP_BENCH_NAME = {"separable": "sep", "contracted": "fast", "exact": "lanczos2", "bilinear_cv": "cv"}          # tools/warp_bench.py --mode
 PREROLL_SECONDS = 0.15
 REPEATS = 3
 
@@ -282,7 +282,7 @@ def measure_traffic_live(W, H, n_frames, bits, timeout_s=150, mode="separable"):
             vals, ids = 0.0, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "warp_c3" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    if "bgr_warp_c" in row["Kernel_Name"] and row["Counter_Name"] == ctr:       # (vs_k_bgr_warp_c3 and vs_k_bgr_warp_cv_c3[_u16])
                         vals += float(row["Counter_Value"])
                         ids.add(row["Dispatch_Id"])
             if not ids:
@@ -513,25 +513,66 @@ class AlignWarp:
     def align(self):
         return self.aligner.align_clips(self.N, self.n_clips, mem_ptr=self.frames.data_ptr(), w=self.W, h=self.H, fmt=self.fmt, raw=True)
 
-    def warp(self, ts, mode, timed=False):
+    def warp(self, ts, mode, timed=False, border=None):
         torch = self.torch
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(self.stream)
         self.capi.bgr_image_warp_batch_device(self.frames.data_ptr(), self.N, self.W, self.H, 3, 8 if self.bits == 8 else 16, ts,
-                                              self.warped.data_ptr(), mode, self.capi.BORDER_CLAMP, max_value=self.max_value,
+                                              self.warped.data_ptr(), mode, self.capi.BORDER_CLAMP if border is None else border, max_value=self.max_value,
                                               stream=self.stream.cuda_stream)
         if timed:
             b.record(self.stream)
             self.ev.append((a, b))
 
-    def step(self, timed=False, mode=None):
+    def step(self, timed=False, mode=None, border=None):
         status, ts = self.align()
         if not self.args.no_warp:
             if mode is None:
                 mode = getattr(self.capi, WARP_MODES[self.args.warp_mode][0])
-            self.warp(ts, mode, timed)
+            self.warp(ts, mode, timed, border)
         return sum(status)
+
+    def default_warp_leg(self, timed_loop, steps, aggregate=None):
+        """The reference's own pipeline on this workload: AlignNextFrame + warpBySimilarityTransform = cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT) with the
+        measured transform as the FORWARD map (stabilizer.cpp:97-99 -> imgproc.cpp:472-481) -- VS_WARP_BILINEAR_CV, the library's default stabilizer warp.
+        That warp takes a quarter of the alignment pass's time, so the step is alignment-bound: measured with the solver kernel in both batch modes
+        (sharing CUs with the previous pass's warp, as `value` runs it, and exclusive); the faster one leads.  Its own in-step roofline (HIP events on the
+        launch stream around every warp launch of the timed loop) and the aligner's stage table ride along."""
+        capi, torch = self.capi, self.torch
+        saved_ev = self.ev
+        modes = {}
+        for solver in ("shared", "exclusive"):
+            self.shared(solver == "shared")
+            self.step(False, capi.WARP_BILINEAR_CV, capi.BORDER_CONSTANT)
+            torch.cuda.synchronize()
+            self.ev = []
+            self.aligner.enable_timing(True)
+            dt, good = timed_loop(lambda: self.step(True, capi.WARP_BILINEAR_CV, capi.BORDER_CONSTANT), steps)
+            tm = self.aligner.timings()
+            if aggregate is not None:
+                dt, _, good_total = aggregate(dt, self.N * steps, int(good) * steps)
+            else:
+                good_total = int(good) * steps
+            launch_ms = sum(a.elapsed_time(b) for a, b in self.ev) / max(1, len(self.ev))
+            modes[solver] = dict(dt=dt, good=good_total, tm=tm, launch_ms=launch_ms)
+        self.ev = saved_ev
+        self.shared(True)
+        best = min(modes, key=lambda k: modes[k]["dt"])
+        m = modes[best]
+        nbytes = self.W * self.H * 3 * 2 * (1 if self.bits == 8 else 2) * self.N
+        ach = nbytes / (m["launch_ms"] * 1e-3) / 1e9
+        return {"value": round(m["good"] / m["dt"], 2), "unit": "frames/s", "ms_per_step": round(1e3 * m["dt"] / steps, 4), "solver": best,
+                "by_solver_mode": {k: round(v["good"] / v["dt"], 2) for k, v in modes.items()},
+                "warp": "VS_WARP_BILINEAR_CV (cv::warpAffine INTER_LINEAR restated: OpenCV's fixed-point bilinear), VS_BORDER_CONSTANT, the measured transform as the "
+                        "forward map: what stabilizer.cpp:97-99 -> imgproc.cpp:472-481 does with every frame",
+                "roofline": {"kernel": "vs_k_bgr_warp_cv_c3<constant> (byte tile, v_dot2_u32_u16 taps)" if self.bits == 8 else "vs_k_bgr_warp_cv_c3_u16<constant>",
+                             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                             "launch_ms": round(m["launch_ms"], 4), "bytes_per_launch": nbytes,
+                             "note": "in-step: the launch runs beside the next pass's aligner kernels (HIP events on the launch stream, mean over the timed loop)"},
+                "stages": stage_table(m["tm"], steps),
+                "gn_iterations_per_frame": round(m["tm"]["gn_iterations"] / max(1, m["tm"]["frames"]), 2),
+                "note": "never `value` (not a Lanczos2 bgr_image_warp): the figure a drop-in user of the reference's pipeline gets on this workload, frames resident in HBM"}
 
     def free(self):
         self.frames = self.warped = self.clips = None
@@ -694,6 +735,24 @@ def main():
             os._exit(7)
         assert world == args.gpus or args.force_dist, "--gpus %d but WORLD_SIZE %d" % (args.gpus, world)
     red_dev = dev if (dist is not None and backend_used == "nccl") else None     # where the three report scalars are reduced
+    if dist is not None:
+        # roll call BEFORE anything is timed: one line per rank (stderr: stdout carries the one JSON line) with its device, the backend the report
+        # collectives run over and the strong-scaling leg's clip split; two ranks on ONE physical device while the node shows a device for each
+        # is a launch error (LOCAL_RANK ignored, a bad visible-devices mask) and ends the job with exit code 5 on every rank
+        props = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "device": local_rank, "device_name": props.name,
+              "device_key": "%s/%s" % (socket.gethostname(), getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or local_rank),
+              "backend": backend_used, "rccl_ranks": dist.get_world_size() if backend_used == "nccl" else 0,
+              "c4_clips": vsdist.shard_clips(args.c4_clips, rank, world)}
+        everyone = vsdist.roll_call(me)
+        sys.stderr.write("bench.py rank %d/%d: device %d (%s, %s), report collectives over %s (%d RCCL ranks), strong-leg clips %s; no 1 -> 8 GPU curve has "
+                         "been measured in rounds 1-6\n" % (rank, world, local_rank, props.name, me["device_key"], backend_used, me["rccl_ranks"],
+                                                            me["c4_clips"] if len(me["c4_clips"]) <= 8 else "%d clips" % len(me["c4_clips"])))
+        sys.stderr.flush()
+        clash = vsdist.shared_devices(everyone, torch.cuda.device_count()) if args.device < 0 else []
+        if clash:
+            sys.stderr.write("bench.py rank %d: ranks share a physical device although %d devices are visible: %r\n" % (rank, torch.cuda.device_count(), clash))
+            sys.exit(5)
 
     wl = WORKLOADS[args.workload]
     W, H, bits = wl["w"], wl["h"], wl["bits"]
@@ -816,6 +875,7 @@ def main():
         aw.shared(True)
 
     others = {}
+    default_leg = None
     if aw and not args.no_warp:
         # beside `value`: the same step with the OTHER members of the sampler family -- `exact_warp` (VS_WARP_LANCZOS2: the reference's
         # written, un-contracted rounding order; rounds 1-3's `value`), `contracted_warp` (round 4's `value`), `separable_warp`
@@ -827,20 +887,9 @@ def main():
             dt_f, good_f = timed_loop(lambda: aw.step(False, m), args.steps)
             dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
             others[name] = (dt_f, good_f)
-        # ... and with the warp the reference's stabilizer actually runs per frame (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99): the
-        # fixed-point bilinear, VS_WARP_BILINEAR_CV -- the step is then bound by the alignment pass, not by the warp
-        # (this warp takes a quarter of the alignment pass's time: measured with the solver kernel in both batch modes -- sharing CUs with
-        # the previous pass's warp, as `value` runs it, and exclusive -- the leg reports both and leads with the faster)
-        cv_modes = {}
-        for solver in ("shared", "exclusive"):
-            aw.shared(solver == "shared")
-            aw.step(False, capi.WARP_BILINEAR_CV)
-            dt_f, good_f = timed_loop(lambda: aw.step(False, capi.WARP_BILINEAR_CV), args.steps)
-            dt_f, _, good_f = vsdist.aggregate(dt_f, n * n_clips * args.steps, int(good_f) * args.steps, device=red_dev)
-            cv_modes[solver] = (dt_f, good_f)
-        aw.shared(True)
-        cv_best = min(cv_modes, key=lambda k: cv_modes[k][0])
-        others["bilinear_cv"] = cv_modes[cv_best]
+        # ... and the reference's OWN pipeline on this workload (align + cv::warpAffine's fixed-point bilinear, constant border): `default_warp`
+        default_leg = aw.default_warp_leg(timed_loop, args.steps,
+                                          aggregate=lambda dt_, fr_, gd_: vsdist.aggregate(dt_, fr_, gd_, device=red_dev))
 
     stable = None
     if aw and not args.no_warp and args.select == "device":
@@ -859,6 +908,8 @@ def main():
         out = {
             "metric": "aligned frames/sec", "value": round((total_good if not wl["stabilizer"] else total_frames) / dt, 2), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "ranks": ([{k: e[k] for k in ("rank", "device", "device_key", "backend")} for e in everyone] if dist is not None else None),
+            "scaling_curve_measured": False,
             "dist_backend": (backend_used if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "value_warp_mode": None if (args.no_warp and not wl["stabilizer"]) else args.warp_mode,
@@ -909,15 +960,12 @@ def main():
                          "VSO_WARP_LANCZOS2): the figure to compare across rounds (rounds 1-3 reported it as `value`)",
                 "contracted": "VS_WARP_LANCZOS2_FAST = the sampler with the multiply-adds fused as the reference's own target allows "
                               "(CMakeLists.txt:151 fma, no strict_float): round 4's `value`",
-                "separable": "VS_WARP_LANCZOS2_SEP = the contracted weights and taps summed rows first, then columns",
-                "bilinear_cv": "VS_WARP_BILINEAR_CV = cv::warpAffine's fixed-point bilinear, the warp the reference's stabilizer runs per frame "
-                               "(stabilizer.cpp:97-99) and this library's default stabilizer warp: not a Lanczos2 bgr_image_warp, so never `value`"}
+                "separable": "VS_WARP_LANCZOS2_SEP = the contracted weights and taps summed rows first, then columns"}
         for name, (dt_f, good_f) in others.items():
             out[name + "_warp"] = {"value": round(good_f / dt_f, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_f / args.steps, 4),
                                    "note": "same step (one loop, after the pre-roll) with bgr_image_warp in " + what[name]}
-        if "bilinear_cv" in others:
-            out["bilinear_cv_warp"]["solver"] = cv_best
-            out["bilinear_cv_warp"]["by_solver_mode"] = {k: round(v[1] / v[0], 2) for k, v in cv_modes.items()}
+        if default_leg:
+            out["default_warp"] = default_leg
         if stable:
             out["stable_select"] = {"value": round(stable[1] / stable[0], 2), "unit": "frames/s", "ms_per_step": round(1e3 * stable[0] / args.steps, 4),
                                     "note": "same step with VS_SELECT_STABLE: the keep-best-80 % step under a documented STL-independent rule (smallest "
@@ -992,6 +1040,7 @@ def main():
                          "roofline": roofline_of(a3, n3),
                          "note": "solver in VS_BATCH_SHARED mode; the 4K level 0 (20736 tiles per set) selects on the pair's global scratch"}
             out["c3"].update(others3)
+            out["c3"]["default_warp"] = a3.default_warp_leg(timed_loop, steps3)
             if not args.no_cpu_baseline and args.warp_mode != "exact":
                 # the 4K frame of the pixel gate: the GPU's warp of frame 1 in the form `value` runs (its measured transform) against the
                 # un-contracted oracle
@@ -1121,6 +1170,17 @@ def main():
         a4.free()
 
     if rank == 0:
+        r4 = out.get("roofline_4k")
+        if isinstance(r4, dict) and args.warp_mode in r4 and "roofline" in out:
+            # the `value` warp mode where the north star quotes it (4K, isolated), inside the headline's own roofline object
+            q = r4[args.warp_mode]
+            out["roofline"]["at_4k"] = {"mode": args.warp_mode, "us_per_frame": q["us_per_frame"], "achieved": q["achieved"], "frac": q["frac"],
+                                        "frames_per_launch": q["frames_per_launch"]}
+        if isinstance(r4, dict):
+            # LAST key of the line (a record that keeps only the tail of the line still shows it): {mode: [us per 4K frame, fraction of 8 TB/s]}
+            out["roofline_4k_summary"] = dict({k: [v["us_per_frame"], v["frac"]] for k, v in r4.items()},
+                                              shader_clock_mhz=shader_mhz, frames_per_launch=32,
+                                              note="isolated 32 x 4K launches, HIP events; algorithmic bytes W*H*3*(in+out) per frame; no 1 -> 8 GPU curve has been measured")
         print(json.dumps(out), flush=True)
     if dist is not None:
         vsdist.barrier()

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from _diff import same
+
 from test_engine_gpu import TOL, _check_seq, _cmp_transform, _diverged, _run_both
 
 pytestmark = pytest.mark.gpu
@@ -136,7 +138,7 @@ def test_random_batch_forms_equal_frame_at_a_time(gpu_vs, seed):
         for i in range(n):
             assert bool(hb[i]) == (outs[i] is not None), i
             if outs[i] is not None:
-                assert np.array_equal(ob[i], outs[i]), (i, skw)
+                assert same(ob[i], outs[i]), (i, skw)
 
 
 @pytest.mark.parametrize("seed", range(24 * _SCALE))
@@ -184,7 +186,7 @@ def test_random_clip_batches_equal_fresh_handles(gpu_vs, seed):
     assert has == want_has and r == sum(want_has), (n_clips, fpc, skw)
     for i in range(len(allf)):
         if want_has[i]:
-            assert np.array_equal(got[i], want[i]), (i, n_clips, fpc, skw)
+            assert same(got[i], want[i]), (i, n_clips, fpc, skw)
     al = gpu_vs.Aligner(device=0, **{k: skw[k] for k in ("pyramid_min_width", "pyramid_min_height")})
     st, ts = al.align_clips(len(allf), n_clips, mem_ptr=dev.data_ptr(), w=w, h=h, fmt=fmt)
     for i in range(len(allf)):
@@ -267,7 +269,7 @@ def test_random_pitched_and_unaligned_frames_align_like_dense_ones(gpu_vs, seed)
         assert bool(st[i]) == bool(st_ref[i]), (i, w, h, ch, bits, sp, sfs, so, on_device)
         if not st[i] and not all(abs(v) <= 2.0 ** 31 for v in out[i].tup() + ts_ref[i].tup()):
             continue                                            # (refused after diverging beyond the integer range: see test_random_batch_forms_equal_frame_at_a_time)
-        assert np.array_equal(out[i].tup(), ts_ref[i].tup(), equal_nan=True), (i, w, h, ch, bits, sp, sfs, so, on_device)
+        assert same(out[i].tup(), ts_ref[i].tup(), equal_nan=True), (i, w, h, ch, bits, sp, sfs, so, on_device)
         assert not st[i] or all(np.isfinite(out[i].tup())), i          # (a refused frame's estimate may be NaN; an aligned frame's never)
 
 
@@ -378,14 +380,14 @@ def test_one_long_lived_handle_through_random_call_sequences(gpu_vs, seed):
         pos += k
         if k == 1 and rng.random() < 0.6:
             got, want = A.align_next(fr[0]), fa.align_next(fr[0])
-            assert got[0] == want[0] and np.array_equal(got[1].tup(), want[1].tup(), equal_nan=True), (op, size)
+            assert got[0] == want[0] and same(got[1].tup(), want[1].tup(), equal_nan=True), (op, size)
             og, ow = S.process(fr[0]), fs.process(fr[0])
-            assert (og is None) == (ow is None) and (og is None or np.array_equal(og, ow)), (op, size)
+            assert (og is None) == (ow is None) and (og is None or same(og, ow)), (op, size)
         else:
             (st, ts), (st2, ts2) = A.align_batch(fr), fa.align_batch(fr)
-            assert st == st2 and all(np.array_equal(a.tup(), b.tup(), equal_nan=True) for a, b in zip(ts, ts2)), (op, size, k)
+            assert st == st2 and all(same(a.tup(), b.tup(), equal_nan=True) for a, b in zip(ts, ts2)), (op, size, k)
             (o, hs), (o2, hs2) = S.process_batch(fr), fs.process_batch(fr)
-            assert hs == hs2 and np.array_equal(o[np.array(hs, bool)], o2[np.array(hs2, bool)]), (op, size, k)
+            assert hs == hs2 and same(o[np.array(hs, bool)], o2[np.array(hs2, bool)]), (op, size, k)
 
 
 @pytest.mark.parametrize("seed", range(24 * _SCALE))

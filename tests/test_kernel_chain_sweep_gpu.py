@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from _diff import same
+
 pytestmark = pytest.mark.gpu
 _SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
 
@@ -32,17 +34,17 @@ def test_random_chain_is_bit_exact(gpu_vs, oracle, seed):
     rng = np.random.default_rng(52000 + seed)
     w, h = int(rng.integers(8, 900)), int(rng.integers(8, 420))
     key = _content(rng, w, h)
-    assert np.array_equal(gpu_vs.pyr_down(key), oracle.pyr_down(key))
+    assert same(gpu_vs.pyr_down(key), oracle.pyr_down(key))
     gx, gy = gpu_vs.grad_xy(key)
     ogx, ogy = oracle.grad_xy(key)
-    assert np.array_equal(gx, ogx) and np.array_equal(gy, ogy)
+    assert same(gx, ogx) and same(gy, ogy)
     ts = None if rng.random() < 0.5 else int(rng.integers(2, min(w, h, 40) + 1))
     gts, lmx, lmy, jx, jy = gpu_vs.keyframe_fused(key, ts=ts)
     ots, olx, oly = oracle.grad_argmax(ogx, ogy, ts=ts)
     ojx, ojy = oracle.sparse_jac(ogx, ogy, olx, oly)
     assert gts == ots
-    assert np.array_equal(lmx, olx) and np.array_equal(lmy, oly)
-    assert np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+    assert same(lmx, olx) and same(lmy, oly)
+    assert same(jx, ojx) and same(jy, ojy)
     # a template = the keyframe shifted a little, plus noise; a transform near the truth or far from it
     tmpl = np.roll(key, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (0, 1))
     tmpl = np.clip(tmpl.astype(np.int16) + rng.integers(-3, 4, tmpl.shape), 0, 255).astype(np.uint8)
@@ -51,7 +53,7 @@ def test_random_chain_is_bit_exact(gpu_vs, oracle, seed):
     for lm in (olx, oly):
         g = gpu_vs.sparse_warpdiff(tmpl, key, lm, gpu_vs.Transform.of(*tr))
         o = oracle.sparse_warpdiff(tmpl, key, lm, oracle.Transform.of(*tr))
-        assert np.array_equal(g, o), (w, h, tr)
+        assert same(g, o), (w, h, tr)
     nt = olx.shape[1] * olx.shape[2]
     n = max(1, int(nt * 0.8))
     kx, ky = rng.permutation(nt)[:n], rng.permutation(nt)[:n]

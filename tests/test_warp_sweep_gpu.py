@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from _diff import same
+
 pytestmark = pytest.mark.gpu
 _SCALE = max(1, int(os.environ.get("VS_SWEEP_SCALE", "1")))     # a soak run draws this many times the cases (seeds continue upward)
 
@@ -41,12 +43,12 @@ def test_random_warp_is_bit_exact(gpu_vs, oracle, seed):
     exp = np.stack([oracle.bgr_image_warp(src[i], oracle.Transform.of(*trs[i]), mode, border, max_value=max_value) for i in range(n)])
     ts = [gpu_vs.Transform.of(*t) for t in trs]
     got = gpu_vs.bgr_image_warp_batch(src, ts, mode, border, max_value=max_value)
-    assert np.array_equal(got, exp), (w, h, bits, mode, border, trs)
+    assert same(got, exp), (w, h, bits, mode, border, trs)
     # a window of the same warp
     rw, rh = int(rng.integers(1, w + 1)), int(rng.integers(1, h + 1))
     rx, ry = int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1))
     win = gpu_vs.bgr_image_warp_roi_batch(src, ts, (rx, ry, rw, rh), mode, border, max_value=max_value)
-    assert np.array_equal(win, exp[:, ry:ry + rh, rx:rx + rw]), (w, h, bits, mode, border, trs, (rx, ry, rw, rh))
+    assert same(win, exp[:, ry:ry + rh, rx:rx + rw]), (w, h, bits, mode, border, trs, (rx, ry, rw, rh))
 
 
 @pytest.mark.parametrize("seed", range(80 * _SCALE))
@@ -67,11 +69,11 @@ def test_random_generic_warp_forms_are_bit_exact(gpu_vs, oracle, seed):
         f32 = False                                              # (cv::warpAffine's integer path has no float output)
     g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode, border, f32=f32)
     o = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), mode, border, f32=f32)
-    assert np.array_equal(g, o, equal_nan=True), (w, h, c, bits, mode, border, f32, tr)
+    assert same(g, o, equal_nan=True), (w, h, c, bits, mode, border, f32, tr)
     gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
-    assert np.array_equal(gpu_vs.image_warp(gray, gpu_vs.Transform.of(*tr)), oracle.image_warp(gray, oracle.Transform.of(*tr)), equal_nan=True), (w, h, tr)
+    assert same(gpu_vs.image_warp(gray, gpu_vs.Transform.of(*tr)), oracle.image_warp(gray, oracle.Transform.of(*tr)), equal_nan=True), (w, h, tr)
     bgr = rng.integers(0, 256 if bits == 8 else 1024, (h, w, 3)).astype(src.dtype)
-    assert np.array_equal(gpu_vs.bgr_to_gray(bgr), oracle.bgr_to_gray(bgr)), (w, h, bits)
+    assert same(gpu_vs.bgr_to_gray(bgr), oracle.bgr_to_gray(bgr)), (w, h, bits)
 
 
 @pytest.mark.parametrize("seed", range(100 * _SCALE))
@@ -120,9 +122,10 @@ def test_random_pitches_and_unaligned_device_pointers(gpu_vs, oracle, seed):
     keep = np.ones(got.shape, bool)
     for i in range(n):
         rows = np.lib.stride_tricks.as_strided(got[do + i * dfs:], (h, 3 * w), (dp * esz, esz))
-        assert np.array_equal(rows, exp[i].reshape(h, 3 * w)), (i, w, h, bits, mode, border, sp, dp, so, do, trs[i])
+        assert same(rows, exp[i].reshape(h, 3 * w)), ("frame %d" % i, w, h, bits, mode, border, sp, dp, so, do, trs[i], "dst_fill %d" % dst_fill, "host" if got is dst else "device")
         np.lib.stride_tricks.as_strided(keep[do + i * dfs:], (h, 3 * w), (dp, 1))[...] = False
-    assert np.all(got[keep] == dst_fill), "bytes outside the output rows were written"
+    outside = np.flatnonzero(keep & (got != dst_fill))
+    assert outside.size == 0, "%d elements outside the output rows were written; first: element %d = %d (fill %d)" % (outside.size, outside[0], got[outside[0]], dst_fill)
 
 
 @pytest.mark.parametrize("seed", range(30 * _SCALE))

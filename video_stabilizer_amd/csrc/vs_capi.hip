@@ -79,22 +79,125 @@ hipError_t pinned_alloc(void** p, size_t bytes) {
     return e;
 }
 
+// ---- the staging pool ------------------------------------------------------------------------------------------------------------
+// Free blocks are kept per process (any thread, any device: a block remembers its device); a lease takes the smallest free block that
+// is large enough, or allocates one (capacities are rounded up so that a sweep of slightly different sizes reuses blocks).  At most
+// kStageKeepBlocks / kStageKeepBytes stay cached; what does not fit is freed on release.  Nothing is freed at process exit (the HIP
+// runtime may already be gone).
+namespace {
+constexpr size_t kStageKeepBlocks = 24, kStageKeepBytes = (size_t)3 << 30;
+struct StagePool {
+    std::mutex mu;
+    std::vector<StageBlock*> free_;
+    size_t kept_bytes = 0;
+};
+StagePool& stage_pool() { static StagePool* p = new StagePool(); return *p; }
+size_t stage_capacity(size_t n) {
+    if (n <= 4096) return 4096;
+    if (n <= ((size_t)64 << 20)) { size_t c = 4096; while (c < n) c <<= 1; return c; }
+    const size_t g = (size_t)64 << 20;
+    return (n + g - 1) / g * g;
+}
+void stage_destroy(StageBlock* b) {
+    if (b->dev) (void)hipFree(b->dev);
+    if (b->pin) (void)hipHostFree(b->pin);
+    delete b;
+}
+thread_local unsigned long long t_sync_epoch = 1;
+}  // namespace
+unsigned long long host_sync_epoch() { return t_sync_epoch; }
+void host_synced() { ++t_sync_epoch; }
+
+StageBlock* stage_acquire(size_t bytes) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); set_error(VS_ERR_HIP, "hipGetDevice failed (staging)"); return nullptr; }
+    const size_t cap = stage_capacity(bytes ? bytes : 1);
+    StageBlock* b = nullptr;
+    {
+        StagePool& p = stage_pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < p.free_.size(); i++)
+            if (p.free_[i]->device == device && p.free_[i]->cap >= cap && (best == (size_t)-1 || p.free_[i]->cap < p.free_[best]->cap)) best = i;
+        if (best != (size_t)-1) {
+            b = p.free_[best];
+            p.free_.erase(p.free_.begin() + (long)best);
+            p.kept_bytes -= b->cap;
+        }
+    }
+    static const int poison = []() { const char* v = test_env("VS_TEST_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) & 255 : -1; }();
+    if (b) {
+        // test hook: a reused block starts from the poison byte like a fresh allocation (tests/test_uninitialised_memory_gpu.py)
+        if (poison >= 0 && (hipMemset(b->dev, poison, b->cap) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+            (void)hipGetLastError(); stage_destroy(b); set_error(VS_ERR_HIP, "poisoning a staging block failed"); return nullptr;
+        }
+        if (poison >= 0) memset(b->pin, poison, b->cap);
+        return b;
+    }
+    b = new StageBlock();
+    b->cap = cap; b->device = device;
+    hipError_t e = dev_alloc(&b->dev, cap);
+    if (e == hipSuccess) e = pinned_alloc(&b->pin, cap);
+    if (e != hipSuccess) {
+        stage_destroy(b);
+        set_error(VS_ERR_HIP, "staging block of %zu bytes: %s", cap, hipGetErrorString(e));
+        return nullptr;
+    }
+    if (poison >= 0) memset(b->pin, poison, cap);
+    return b;
+}
+void stage_release(StageBlock* b) {
+    if (!b) return;
+    {
+        StagePool& p = stage_pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        if (p.free_.size() < kStageKeepBlocks && p.kept_bytes + b->cap <= kStageKeepBytes) {
+            p.free_.push_back(b);
+            p.kept_bytes += b->cap;
+            return;
+        }
+        // the cache is full: drop the smallest cached block if this one is larger (large blocks are the expensive ones to make)
+        size_t small = (size_t)-1;
+        for (size_t i = 0; i < p.free_.size(); i++)
+            if (small == (size_t)-1 || p.free_[i]->cap < p.free_[small]->cap) small = i;
+        if (small != (size_t)-1 && p.free_[small]->cap < b->cap && p.kept_bytes - p.free_[small]->cap + b->cap <= kStageKeepBytes) {
+            std::swap(b, p.free_[small]);
+            p.kept_bytes += p.free_[small]->cap - b->cap;
+        }
+    }
+    stage_destroy(b);
+}
+
+Staged::~Staged() {
+    if (!blk) return;
+    // an error return between the first enqueue and the call's synchronisation: work that reads or writes the block may still be in flight
+    if (epoch == host_sync_epoch()) { (void)hipDeviceSynchronize(); (void)hipGetLastError(); }
+    stage_release(blk);
+}
+int Staged::lease(size_t n) {
+    if (blk) { stage_release(blk); blk = nullptr; }
+    blk = stage_acquire(n);
+    if (!blk) return VS_ERR_HIP;
+    dev = blk->dev;
+    epoch = host_sync_epoch();
+    return VS_OK;
+}
 int Staged::in(const void* ptr, size_t n, int mem, hipStream_t s) {
     bytes = n; is_out = false;
     if (mem == VS_MEM_DEVICE) { dev = const_cast<void*>(ptr); staged = false; return VS_OK; }
     staged = true; host = const_cast<void*>(ptr);
-    VS_HIP(buf.alloc(n));
-    dev = buf.p;
-    if (n) VS_HIP(hipMemcpyAsync(dev, ptr, n, hipMemcpyHostToDevice, s));
+    if (int r = lease(n)) return r;
+    if (n) {
+        memcpy(blk->pin, ptr, n);
+        VS_HIP(hipMemcpyAsync(dev, blk->pin, n, hipMemcpyHostToDevice, s));
+    }
     return VS_OK;
 }
 int Staged::out(void* ptr, size_t n, int mem) {
     bytes = n; is_out = true;
     if (mem == VS_MEM_DEVICE) { dev = ptr; staged = false; return VS_OK; }
     staged = true; host = ptr;
-    VS_HIP(buf.alloc(n));
-    dev = buf.p;
-    return VS_OK;
+    return lease(n);
 }
 int Staged::out_image(void* ptr, size_t row_bytes_, size_t rows_, size_t pitch_, size_t frames_, size_t frame_pitch_, int mem) {
     const size_t n = frames_ == 0 || rows_ == 0 ? 0 : (frames_ - 1) * frame_pitch_ + (rows_ - 1) * pitch_ + row_bytes_;
@@ -105,10 +208,25 @@ int Staged::out_image(void* ptr, size_t row_bytes_, size_t rows_, size_t pitch_,
 }
 int Staged::finish(hipStream_t s) {
     if (!(staged && is_out && bytes)) return VS_OK;
-    if (rows == 0) { VS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s)); return VS_OK; }
-    for (size_t f = 0; f < frames; f++)           // pitched: the bytes between the rows stay as the caller had them
-        VS_HIP(hipMemcpy2DAsync((char*)host + f * frame_pitch, pitch, (const char*)dev + f * frame_pitch, pitch, row_bytes, rows,
-                                hipMemcpyDeviceToHost, s));
+    VS_HIP(hipMemcpyAsync(blk->pin, dev, bytes, hipMemcpyDeviceToHost, s));     // dense: the gaps between rows travel too and are dropped by complete()
+    copied_back = true;
+    return VS_OK;
+}
+void Staged::complete() {
+    if (!copied_back) return;
+    copied_back = false;
+    const char* m = (const char*)blk->pin;
+    if (rows == 0) { memcpy(host, m, bytes); return; }
+    for (size_t f = 0; f < frames; f++)               // pitched: the bytes between the rows stay as the caller had them
+        for (size_t r = 0; r < rows; r++)
+            memcpy((char*)host + f * frame_pitch + r * pitch, m + f * frame_pitch + r * pitch, row_bytes);
+}
+int finish_outputs(int mem, hipStream_t s, std::initializer_list<Staged*> outs) {
+    for (Staged* o : outs) if (int r = o->finish(s)) return r;
+    if (mem != VS_MEM_HOST) return VS_OK;
+    VS_HIP(hipStreamSynchronize(s));
+    host_synced();
+    for (Staged* o : outs) o->complete();
     return VS_OK;
 }
 
@@ -133,14 +251,14 @@ using vsi::set_error;
 // One ring per (running thread, device): calls from different threads or for different devices never wait on each other and
 // need no lock on the call path (the header promises that distinct handles are independent).  Events are pooled.
 namespace {
-struct ParamRing {
-    static constexpr size_t kSlots = 1 << 15;    // 32768 float4 = 512 KiB
-    float4* host = nullptr;
-    float4* dev = nullptr;
+// span bookkeeping of a ring of `slots` units: reserve() hands out the next free span (waiting for every in-flight span it overlaps),
+// commit() marks it busy behind an event on the stream, fence() moves that event behind the consuming kernel
+struct SpanRing {
+    size_t slots = 0;
     size_t head = 0;
     struct Busy { size_t begin, end; hipEvent_t ev; hipStream_t stream; };
     std::deque<Busy> busy;
-    std::mutex mu;                               // the owning thread (upload / fence) against vsi::retire_stream from any thread
+    std::mutex mu;                               // the owning thread (reserve / commit / fence) against vsi::retire_stream from any thread
     std::vector<hipEvent_t> pool;
     int take_event(hipEvent_t* ev) {
         if (!pool.empty()) { *ev = pool.back(); pool.pop_back(); return VS_OK; }
@@ -153,35 +271,33 @@ struct ParamRing {
         busy.erase(it);
         return VS_OK;
     }
-    int upload(const float* src, size_t n, hipStream_t s, float4** out) {
-        std::lock_guard<std::mutex> g(mu);
-        if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
-        if (!host) VS_HIP(vsi::pinned_alloc((void**)&host, kSlots * sizeof(float4)));
-        if (!dev) VS_HIP(vsi::dev_alloc((void**)&dev, kSlots * sizeof(float4)));
-        if (head + n > kSlots) head = 0;
-        const size_t b = head, e = head + n;
-        // wait for (and retire) every in-flight span that overlaps [b, e)
+    // (mu held) the next span of n units: [*b, *b + n), every in-flight span that overlaps it waited for and retired
+    int reserve(size_t n, size_t* b) {
+        if (head + n > slots) head = 0;
+        const size_t lo = head, hi = head + n;
         for (bool again = true; again;) {
             again = false;
             for (auto it = busy.begin(); it != busy.end(); ++it)
-                if (it->begin < e && b < it->end) { VS_TRY_RING(retire(it)); again = true; break; }
+                if (it->begin < hi && lo < it->end) { VS_TRY_RING(retire(it)); again = true; break; }
         }
         while (busy.size() > 64) VS_TRY_RING(retire(busy.begin()));   // keep the list short: retire the oldest
-        memcpy(host + b, src, n * sizeof(float4));
-        Busy bz{b, e, nullptr, s};
+        *b = lo;
+        return VS_OK;
+    }
+    // (mu held) the span is busy from now on: an event recorded on `s` right behind what the caller has just enqueued
+    int commit(size_t b, size_t n, hipStream_t s, hipError_t enqueue_result) {
+        Busy bz{b, b + n, nullptr, s};
         VS_TRY_RING(take_event(&bz.ev));
-        hipError_t err = hipMemcpyAsync(dev + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s);
+        hipError_t err = enqueue_result;
         if (err == hipSuccess) err = hipEventRecord(bz.ev, s);
         if (err != hipSuccess) { pool.push_back(bz.ev); VS_HIP(err); }
         busy.push_back(bz);
-        *out = dev + b;
-        head = e;
+        head = b + n;
         return VS_OK;
     }
-    // called after the consuming kernel has been enqueued on `s`: the span stays busy until that kernel is done
-    int fence(float4* p, hipStream_t s) {
+    // called after the consuming kernel has been enqueued on `s`: the span that begins at b stays busy until that kernel is done
+    int fence_span(size_t b, hipStream_t s) {
         std::lock_guard<std::mutex> g(mu);
-        const size_t b = (size_t)(p - dev);
         for (auto& z : busy)
             if (z.begin == b) { VS_HIP(hipEventRecord(z.ev, s)); z.stream = s; return VS_OK; }
         return VS_OK;
@@ -202,26 +318,64 @@ struct ParamRing {
         return first;
     }
 };
-// A thread takes a ring per device on first use and hands it back to a process-wide pool when it exits; the next thread that
+struct ParamRing : SpanRing {
+    static constexpr size_t kSlots = 1 << 15;    // 32768 float4 = 512 KiB
+    float4* host = nullptr;
+    float4* dev = nullptr;
+    ParamRing() { slots = kSlots; }
+    int upload(const float* src, size_t n, hipStream_t s, float4** out) {
+        std::lock_guard<std::mutex> g(mu);
+        if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
+        if (!host) VS_HIP(vsi::pinned_alloc((void**)&host, kSlots * sizeof(float4)));
+        if (!dev) VS_HIP(vsi::dev_alloc((void**)&dev, kSlots * sizeof(float4)));
+        size_t b = 0;
+        VS_TRY_RING(reserve(n, &b));
+        memcpy(host + b, src, n * sizeof(float4));
+        VS_TRY_RING(commit(b, n, s, hipMemcpyAsync(dev + b, host + b, n * sizeof(float4), hipMemcpyHostToDevice, s)));
+        *out = dev + b;
+        return VS_OK;
+    }
+    int fence(float4* p, hipStream_t s) { return fence_span((size_t)(p - dev), s); }
+};
+// Device-only scratch for VS_WARP_BILINEAR_CV's per-frame coordinate tables (vs_k_cv_tables writes them, the warp kernel of the same
+// call reads them): 48 KiB per 4K frame.  take() hands out n ints; the caller enqueues the table kernel and the warp kernel, then fence()s.
+struct TableRing : SpanRing {
+    static constexpr size_t kInts = (size_t)8 << 20;     // 32 MiB: ~680 4K frames; a call takes at most half per launch group
+    int* dev = nullptr;
+    TableRing() { slots = kInts; }
+    int take(size_t n, hipStream_t s, int** out) {
+        std::lock_guard<std::mutex> g(mu);
+        if (n == 0 || n > kInts / 2) return vsi::set_error(VS_ERR_ARG, "coordinate tables of %zu ints are too large", n);
+        if (!dev) VS_HIP(vsi::dev_alloc((void**)&dev, kInts * sizeof(int)));
+        size_t b = 0;
+        VS_TRY_RING(reserve(n, &b));
+        VS_TRY_RING(commit(b, n, s, hipSuccess));
+        *out = dev + b;
+        return VS_OK;
+    }
+    int fence(int* p, hipStream_t s) { return fence_span((size_t)(p - dev), s); }
+};
+// A thread takes a ring pair per device on first use and hands it back to a process-wide pool when it exits; the next thread that
 // needs one for that device reuses it (its in-flight spans are retired by event as always).  So the pinned / device memory
 // held is bounded by the largest number of threads that were inside bgr_image_warp entry points at the same time, not by the
 // number of threads that ever called one (a thread-per-frame caller used to leave 1 MiB behind per thread).  Nothing is freed
 // at thread or process exit: the HIP runtime may already be gone by then.
+struct Rings { ParamRing params; TableRing tables; };
 struct RingPool {
     std::mutex mu;
-    std::vector<ParamRing*> free_[16];
-    std::vector<ParamRing*> all;                 // every ring ever made (rings are never destroyed)
+    std::vector<Rings*> free_[16];
+    std::vector<Rings*> all;                     // every ring pair ever made (rings are never destroyed)
 };
 RingPool& ring_pool() { static RingPool* p = new RingPool(); return *p; }      // never destroyed: outlives every thread's holder
 struct RingHolder {
-    ParamRing* r[16] = {};
+    Rings* r[16] = {};
     ~RingHolder() {
         RingPool& p = ring_pool();
         std::lock_guard<std::mutex> g(p.mu);
         for (int d = 0; d < 16; d++) if (r[d]) p.free_[d].push_back(r[d]);
     }
 };
-ParamRing* param_ring() {
+Rings* thread_rings() {
     thread_local RingHolder holder;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return nullptr;
@@ -229,35 +383,34 @@ ParamRing* param_ring() {
         RingPool& p = ring_pool();
         std::lock_guard<std::mutex> g(p.mu);
         if (!p.free_[device].empty()) { holder.r[device] = p.free_[device].back(); p.free_[device].pop_back(); }
-        else { holder.r[device] = new ParamRing(); p.all.push_back(holder.r[device]); }
+        else { holder.r[device] = new Rings(); p.all.push_back(holder.r[device]); }
     }
     return holder.r[device];
 }
+ParamRing* param_ring() { Rings* r = thread_rings(); return r ? &r->params : nullptr; }
+TableRing* table_ring() { Rings* r = thread_rings(); return r ? &r->tables : nullptr; }
 }  // namespace
 
 // A stream is about to be destroyed (a handle's own stream: ~vs_aligner; a caller's stream: vs_stream_retire): nothing in the
 // library may refer to it afterwards.
 hipError_t vsi::retire_stream(hipStream_t s) {
-    std::vector<ParamRing*> rings;
+    std::vector<Rings*> rings;
     {
         RingPool& p = ring_pool();
         std::lock_guard<std::mutex> g(p.mu);
         rings = p.all;
     }
     hipError_t first = hipSuccess;
-    for (ParamRing* r : rings) {
-        const hipError_t e = r->forget_stream(s);
-        if (e != hipSuccess && first == hipSuccess) first = e;
+    for (Rings* r : rings) {
+        const hipError_t e1 = r->params.forget_stream(s), e2 = r->tables.forget_stream(s);
+        if (e1 != hipSuccess && first == hipSuccess) first = e1;
+        if (e2 != hipSuccess && first == hipSuccess) first = e2;
     }
     return first;
 }
 
 static inline size_t img_span(int w, int h, int stride, int channels) {
     return (size_t)(h - 1) * stride + (size_t)w * channels;
-}
-static inline int finish_host(int mem, hipStream_t s) {
-    if (mem == VS_MEM_HOST) VS_HIP(hipStreamSynchronize(s));
-    return VS_OK;
 }
 
 extern "C" {
@@ -394,8 +547,7 @@ int vs_pyr_down(const uint8_t* in, int w, int h, int in_stride, uint8_t* out, in
     VS_TRY(a.in(in, img_span(w, h, in_stride, 1), mem, s));
     VS_TRY(b.out_image(out, (size_t)ow, (size_t)oh, (size_t)out_stride, 1, 0, mem));
     VS_HIP(vsk::pyr_down(a.as<uint8_t>(), w, h, in_stride, b.as<uint8_t>(), ow, oh, out_stride, 1, 0, 0, s));
-    VS_TRY(b.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&b});
 } VS_CATCH_ALL
 
 int vs_optimal_dft_size(int n) { return vsp::optimal_dft_size(n); }
@@ -430,6 +582,8 @@ int vs_phase_correlate(const uint8_t* a, const uint8_t* b, int w, int h, int str
     vsp::Result r;
     VS_HIP(hipMemcpyAsync(&r, res.p, sizeof r, hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));        // the result is a host value: this call always synchronises
+    vsi::host_synced();
+    surf.complete();
     result[0] = r.dx; result[1] = r.dy; result[2] = r.response;
     return VS_OK;
 } VS_CATCH_ALL
@@ -444,9 +598,7 @@ int vs_grad_xy(const uint8_t* in, int w, int h, int stride, float* gx, float* gy
     VS_TRY(x.out(gx, (size_t)w * h * 4, mem));
     VS_TRY(y.out(gy, (size_t)w * h * 4, mem));
     VS_HIP(vsk::grad_xy(a.as<uint8_t>(), w, h, stride, x.as<float>(), y.as<float>(), s));
-    VS_TRY(x.finish(s));
-    VS_TRY(y.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&x, &y});
 } VS_CATCH_ALL
 
 int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint16_t* lmx, uint16_t* lmy, int mem,
@@ -462,9 +614,7 @@ int vs_grad_argmax(const float* gx, const float* gy, int w, int h, int ts, uint1
     VS_TRY(x.out(lmx, nt * 2 * 2, mem));
     VS_TRY(y.out(lmy, nt * 2 * 2, mem));
     VS_HIP(vsk::grad_argmax(a.as<float>(), b.as<float>(), w, h, ts, x.as<uint16_t>(), y.as<uint16_t>(), s));
-    VS_TRY(x.finish(s));
-    VS_TRY(y.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&x, &y});
 } VS_CATCH_ALL
 
 int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t* lmx, const uint16_t* lmy, int tx, int ty,
@@ -483,9 +633,7 @@ int vs_sparse_jac(const float* gx, const float* gy, int w, int h, const uint16_t
     VS_TRY(y.out(out_y, nt * 16, mem));
     VS_HIP(vsk::sparse_jac(a.as<float>(), b.as<float>(), w, h, c.as<uint16_t>(), d.as<uint16_t>(), (int)nt, x.as<float>(),
                            y.as<float>(), s));
-    VS_TRY(x.finish(s));
-    VS_TRY(y.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&x, &y});
 } VS_CATCH_ALL
 
 int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint16_t* lmx, uint16_t* lmy, float* jx,
@@ -503,8 +651,7 @@ int vs_keyframe_fused(const uint8_t* in, int w, int h, int stride, int ts, uint1
     VS_TRY(q.out(jy, nt * 16, mem));
     VS_HIP(vsk::keyframe(a.as<uint8_t>(), w, h, stride, ts, x.as<uint16_t>(), y.as<uint16_t>(), p.as<float>(),
                          q.as<float>(), 1, 0, 0, 0, s));
-    VS_TRY(x.finish(s)); VS_TRY(y.finish(s)); VS_TRY(p.finish(s)); VS_TRY(q.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&x, &y, &p, &q});
 } VS_CATCH_ALL
 
 int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* lm, int tx,
@@ -521,8 +668,7 @@ int vs_sparse_warpdiff(const uint8_t* tmpl, const uint8_t* key, int w, int h, in
     VS_TRY(o.out(out, nt * 2, mem));
     VS_HIP(vsk::sparse_warpdiff(a.as<uint8_t>(), b.as<uint8_t>(), w, h, stride, c.as<uint16_t>(), (int)nt, A, B, TX, TY,
                                 o.as<uint16_t>(), s));
-    VS_TRY(o.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&o});
 } VS_CATCH_ALL
 
 int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int stride, const uint16_t* selx, int nx,
@@ -543,8 +689,7 @@ int vs_sparse_ica(const uint8_t* tmpl, const uint8_t* key, int w, int h, int str
     VS_TRY(o.out(out4, 32, mem));
     VS_HIP(vsk::sparse_ica(a.as<uint8_t>(), b.as<uint8_t>(), w, h, stride, sx.as<uint16_t>(), nx, sy.as<uint16_t>(), ny,
                            jx.as<float>(), jy.as<float>(), A, B, TX, TY, o.as<double>(), s));
-    VS_TRY(o.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&o});
 } VS_CATCH_ALL
 
 int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B, float TX, float TY, float* out, int ow,
@@ -557,8 +702,7 @@ int vs_image_warp(const uint8_t* in, int w, int h, int stride, float A, float B,
     VS_TRY(a.in(in, img_span(w, h, stride, 1), mem, s));
     VS_TRY(o.out(out, (size_t)ow * oh * 4, mem));
     VS_HIP(vsk::image_warp(a.as<uint8_t>(), w, h, stride, A, B, TX, TY, o.as<float>(), ow, oh, s));
-    VS_TRY(o.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&o});
 } VS_CATCH_ALL
 
 // roi = NULL: the whole w x h output.  Otherwise dst holds only the window (roi->w x roi->h pixels per frame).
@@ -587,7 +731,12 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
         const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
         VS_TRY(a.in(src, in_bytes, mem, s));
         VS_TRY(o.out_image(dst, (size_t)roi.w * channels * esz, (size_t)roi.h, (size_t)dst_stride * esz, (size_t)n_frames, dst_fs * esz, mem));
-        const int per_call = (int)(ParamRing::kSlots / 2 / 3);             // frames whose matrices fit one upload of the ring (half its slots per call)
+        // frames per launch group: their matrices fit one upload of the parameter ring (half its slots per call) and -- tuned kernel -- their
+        // coordinate tables half of the table ring
+        TableRing* tring = channels == 3 ? table_ring() : nullptr;
+        const size_t tab_per = channels == 3 ? vsk::bgr_warp_cv_table_ints(bits, roi) : 0;
+        int per_call = (int)(ParamRing::kSlots / 2 / 3);
+        if (tab_per) per_call = (int)std::min<size_t>((size_t)per_call, std::max<size_t>(1, TableRing::kInts / 2 / tab_per));
         std::vector<double> Mv((size_t)std::min(n_frames, per_call) * 6 + 2);   // (+2: an upload is counted in 16-byte slots)
         for (int f0 = 0; f0 < n_frames; f0 += per_call) {
             const int nf = std::min(per_call, n_frames - f0);
@@ -597,14 +746,18 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
             const char* sp = (const char*)a.dev + (size_t)f0 * src_fs * esz;
             char* dp = (char*)o.dev + (size_t)f0 * dst_fs * esz;
             hipError_t e = hipErrorNotSupported;
-            if (channels == 3) e = vsk::bgr_warp_cv_c3(sp, w, h, src_stride, bits, (const double*)mdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+            int* tdev = nullptr;
+            if (channels == 3 && tring && tab_per * (size_t)nf <= TableRing::kInts / 2) {
+                VS_TRY(tring->take(tab_per * (size_t)nf, s, &tdev));
+                e = vsk::bgr_warp_cv_c3(sp, w, h, src_stride, bits, (const double*)mdev, tdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+            }
             if (e == hipErrorNotSupported)
                 e = vsk::bgr_warp_cv_generic(sp, w, h, src_stride, channels, bits, (const double*)mdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
             VS_HIP(e);
             VS_TRY(ring->fence(mdev, s));
+            if (tdev) VS_TRY(tring->fence(tdev, s));
         }
-        VS_TRY(o.finish(s));
-        return finish_host(mem, s);
+        return vsi::finish_outputs(mem, s, {&o});
     }
     // kernel parameters of every frame, then (tuned 3-channel kernel) the extents its tile prologue uses: one upload of 2n float4
     static const bool host_extents = []() { const char* e = getenv("VS_WARP_HOST_EXTENTS"); return e ? atoi(e) != 0 : true; }();
@@ -632,8 +785,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);
     VS_HIP(e);
     VS_TRY(ring->fence(pdev, s));
-    VS_TRY(o.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&o});
 }
 
 int vs_bgr_image_warp(const void* src, int w, int h, int src_stride, int channels, int bits, const vs_transform* t,
@@ -674,8 +826,7 @@ int vs_bgr_to_gray(const void* src, int w, int h, int src_stride, int bits, int 
     VS_TRY(a.in(src, img_span(w, h, src_stride, 3) * (bits / 8), mem, s));
     VS_TRY(o.out_image(dst, (size_t)w, (size_t)h, (size_t)dst_stride, 1, 0, mem));
     VS_HIP(vsk::bgr_to_gray(a.dev, w, h, src_stride, bits, shift_to_8, o.as<uint8_t>(), dst_stride, 1, 0, 0, s));
-    VS_TRY(o.finish(s));
-    return finish_host(mem, s);
+    return vsi::finish_outputs(mem, s, {&o});
 } VS_CATCH_ALL
 
 }  // extern "C"

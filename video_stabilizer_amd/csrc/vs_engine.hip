@@ -1080,9 +1080,8 @@ static int select_smallest_impl(const uint16_t* warpdiff, int n_arrays, int tx, 
     hipLaunchKernelGGL(kernel, dim3(n_arrays), dim3(small_wg ? nt512::kGnThreads : nt1024::kGnThreads), dyn, s, a.as<uint16_t>(), nt,
                        nsel, o.as<int32_t>(), status ? st.as<int32_t>() : (int32_t*)nullptr, rule);
     VS_HIP(hipGetLastError());
-    VS_TRY(o.finish(s));
-    if (status) VS_TRY(st.finish(s));
-    if (mem == VS_MEM_HOST) VS_HIP(hipStreamSynchronize(s));
+    if (status) VS_TRY(vsi::finish_outputs(mem, s, {&o, &st}));
+    else VS_TRY(vsi::finish_outputs(mem, s, {&o}));
     return nsel;
 }
 
@@ -1453,10 +1452,14 @@ vs_stabilizer* vs_stabilizer_create(const vs_stabilizer_params* params, int devi
     if (params) p = *params; else vs_stabilizer_params_default(&p);
     vs_aligner* a = vs_aligner_create(&p.aligner, device);
     if (!a) return nullptr;
+    // the aligner owns streams and device slabs: whatever fails from here on releases it (a host allocation that throws included)
+    struct Guard { vs_aligner* a; ~Guard() { if (a) vs_aligner_destroy(a); } } guard{a};
     vs_stabilizer* s = new vs_stabilizer();
     s->params = p;
     s->aligner = a;
+    guard.a = nullptr;                                     // (from here vs_stabilizer_destroy releases it)
     s->smoother = vs_smoother_create(p.lag, p.smoother_memory, p.lambda);   // stabilizer.cpp:4
+    if (!s->smoother) { vs_stabilizer_destroy(s); return nullptr; }         // (last error: the smoother's)
     return s;
 } VS_CATCH_ALL_NULL
 
@@ -1955,8 +1958,11 @@ int vs_stabilizer_reset(vs_stabilizer* s) try {
     for (auto& f : s->frames) if (f.owned) s->pool.push_back(f.ptr);
     s->frames.clear();
     s->measurements.clear();
+    // (make the new smoother first: if that fails the handle keeps a valid, if stale, one -- never a null pointer for the next call to walk into)
+    vs_smoother* fresh = vs_smoother_create(s->params.lag, s->params.smoother_memory, s->params.lambda);
+    if (!fresh) return VS_ERR_NOMEM;
     vs_smoother_destroy(s->smoother);
-    s->smoother = vs_smoother_create(s->params.lag, s->params.smoother_memory, s->params.lambda);
+    s->smoother = fresh;
     s->accum = vs_transform{0, 0, 0, 0};
     s->last_meas = vs_transform{0, 0, 0, 0};
     s->last_success = 0;

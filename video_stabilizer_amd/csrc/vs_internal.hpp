@@ -5,6 +5,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <initializer_list>
 
 namespace vsi {
 // records a thread-local message for vs_last_error() and returns `code`
@@ -54,23 +55,51 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
+// Staging for the host-memory (VS_MEM_HOST) form of the kernel-level calls.  A block = device memory + a PINNED host mirror of the same size,
+// leased from a process-wide pool (vs_capi.hip): no hipMalloc / hipFree per call, and the HIP runtime never sees the caller's pageable memory --
+// inputs are copied into the mirror by the CPU and travel as one dense pinned H2D copy; outputs come back as one dense D2H copy into the mirror
+// and the CPU scatters the rows into the caller's buffer after the stream has been synchronised.  (Until round 5 outputs went back with one
+// hipMemcpy2DAsync per frame straight into pageable, possibly 2-byte-aligned caller memory: profiles/r06_flake.md.)
+struct StageBlock {
+    void* dev = nullptr;
+    void* pin = nullptr;
+    size_t cap = 0;
+    int device = 0;
+};
+StageBlock* stage_acquire(size_t bytes);                   // nullptr on failure (last error set)
+void stage_release(StageBlock* b);
+// "the calling thread has synchronised with every copy and kernel it enqueued on a staged block": bumped by finish_outputs() and by entry
+// points that synchronise themselves; a Staged that dies without having seen it (an error return) quiesces the device before its block is reused
+unsigned long long host_sync_epoch();
+void host_synced();
+
 // An argument that lives wherever the caller said (`mem`): for device memory it is the caller's
 // pointer; for host memory it is a staged device copy (uploaded for inputs, downloaded for outputs).
 struct Staged {
-    DevBuf buf;
+    StageBlock* blk = nullptr;
     void* dev = nullptr;
     void* host = nullptr;
     size_t bytes = 0;
-    bool is_out = false, staged = false;
+    bool is_out = false, staged = false, copied_back = false;
+    unsigned long long epoch = 0;
+    Staged() = default;
+    Staged(const Staged&) = delete;
+    Staged& operator=(const Staged&) = delete;
+    ~Staged();
     int in(const void* ptr, size_t n, int mem, hipStream_t s);
     int out(void* ptr, size_t n, int mem);
     // an image output: `frames` images of `rows` rows of `row_bytes` bytes, `pitch` bytes from row to row and `frame_pitch` from
-    // image to image.  Only the rows' own bytes travel back: the padding between them may be the caller's neighbouring pixels.
+    // image to image.  Only the rows' own bytes reach the caller: the padding between them may be the caller's neighbouring pixels.
     int out_image(void* ptr, size_t row_bytes, size_t rows, size_t pitch, size_t frames, size_t frame_pitch, int mem);
-    int finish(hipStream_t s);   // D2H for staged outputs (async; caller syncs)
+    int finish(hipStream_t s);   // staged outputs: ONE dense D2H into the pinned mirror (async; complete() after the stream has been synchronised)
+    void complete();             // mirror -> the caller's memory (CPU; rows only for pitched images)
     size_t row_bytes = 0, rows = 0, pitch = 0, frames = 0, frame_pitch = 0;   // set by out_image (pitch != row_bytes or gaps between frames)
     template <typename T> T* as() const { return (T*)dev; }
+private:
+    int lease(size_t n);
 };
+// the tail of every kernel-level call: D2H of the staged outputs, (host memory) synchronise, rows into the caller's buffers
+int finish_outputs(int mem, hipStream_t s, std::initializer_list<Staged*> outs);
 
 bool device_ready();   // true when a HIP device is usable (sets last error otherwise)
 // `s` is about to be destroyed: wait for and drop everything the library still tracks on it (bgr_image_warp's parameter ring

@@ -56,7 +56,10 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
 // hipErrorNotSupported for anything else
 hipError_t bgr_warp_cv_generic(const void* src, int w, int h, int src_stride, int channels, int bits, const double* minv_dev, int border,
                                int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s);
-hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int border, int max_value, void* dst,
+// (tuned) tab_dev: device scratch of n_frames * bgr_warp_cv_table_ints(bits, roi) ints -- the per-frame coordinate tables, written by a small
+// kernel in front of the warp launch on the same stream (cv::warpAffine's adelta / bdelta / row origins, made once per frame as OpenCV makes them)
+size_t bgr_warp_cv_table_ints(int bits, Roi roi);
+hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int* tab_dev, int border, int max_value, void* dst,
                           int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s);
 // host side of the tuned kernel's tile prologue: per frame {lo_x, hi_x, lo_y, hi_y} from the kernel parameters {A, B, TX, TY}, for the
 // tile of the kernel that bgr_warp_c3 launches for (bits, mode)

@@ -1169,6 +1169,26 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
 }
 
+// The coordinate tables of a launch: per frame adelta[tab_w] | bdelta[tab_w] | X0[tab_h] | Y0[tab_h] (ints), tab_w / tab_h = the output window
+// rounded up to whole tiles; entries beyond the window repeat its last column / row.  One thread per entry: each is ONE double-precision
+// evaluation exactly as OpenCV's warpAffine makes it once per call (cvRound(m x 1024), cvRound((m y + t) 1024) + round_delta).
+__global__ __launch_bounds__(256) void vs_k_cv_tables(const double* __restrict__ minv, int* __restrict__ tab, int tab_w, int tab_h, vsk::Roi roi) {
+    const int per = 2 * (tab_w + tab_h);
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= per) return;
+    const double* M = minv + 6 * (size_t)blockIdx.y;
+    int v;
+    if (i < 2 * tab_w) {
+        const int xx = i < tab_w ? i : i - tab_w;
+        v = cv_delta(i < tab_w ? M[0] : M[3], min(xx, roi.w - 1) + roi.x);
+    } else {
+        const int j = i - 2 * tab_w, yy = j < tab_h ? j : j - tab_h;
+        const int fy = min(yy, roi.h - 1) + roi.y;
+        v = j < tab_h ? cv_row_origin(M[1], M[2], fy) : cv_row_origin(M[4], M[5], fy);
+    }
+    tab[(size_t)blockIdx.y * (size_t)per + i] = v;
+}
+
 template <int BORDER>
 __device__ __forceinline__ void cv_pixel_global(const uint8_t* __restrict__ src, int w, int h, int stride, int X, int Y, uint32_t out[3]) {
     const int sx = clampi(X >> 5, -32768, 32767), sy = clampi(Y >> 5, -32768, 32767);      // saturate_cast<short>
@@ -1190,15 +1210,15 @@ __device__ __forceinline__ void cv_pixel_global(const uint8_t* __restrict__ src,
 // column groups instead of the window's 20, non-temporal stores: no change.)
 template <int BORDER>
 __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
-                                                             const double* __restrict__ minv, uint8_t* __restrict__ dst, int dst_stride,
+                                                             const int* __restrict__ tab, int tab_w, int tab_h, uint8_t* __restrict__ dst, int dst_stride,
                                                              size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
                                                              int chunk, vsk::Roi roi) {
     __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV_WS_H * WS_RS8];     // B | G << 8 | R << 16 per staged source pixel
-    // the tile's fixed-point coordinate tables: adelta[64] | bdelta[64] | X0[CV_TH] | Y0[CV_TH].  The double-precision evaluations behind them
-    // (cvRound of a double product: ~10 fp64 instructions each, at a fraction of the fp32 rate) are the expensive part of a tile's prologue,
-    // so each is made ONCE per workgroup -- wave 0 the column deltas a, wave 1 the column deltas b, waves 2 (and 3) the row origins -- and
-    // read back by everyone after a barrier (computed per wave they were a third of the kernel's time)
-    __shared__ __attribute__((aligned(16))) int cv_tab[128 + 2 * CV_TH];
+    // The fixed-point coordinate tables -- adelta[tab_w] | bdelta[tab_w] | X0[tab_h] | Y0[tab_h] per frame -- are made ONCE PER FRAME by
+    // vs_k_cv_tables in front of this launch, as cv::warpAffine makes them once per call (until round 5 every workgroup rebuilt its 64 + 64 +
+    // 2 x 64 entries in fp64 and shared them through LDS behind a barrier: 29 % of a wave's life, profiles/r05_cv_stamps_final.json).  A tile
+    // reads its footprint corners and its rows' origins with SCALAR loads (uniform addresses) and its lane's two column deltas with one
+    // vector load each: no fp64, no table barrier, no LDS reads of the tables in the sampler.
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
     if (w < 0) lds_pad[threadIdx.x] = 0;
@@ -1211,7 +1231,6 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     VS_STAMP(0);
 #endif
     const int frame = blockIdx.y;
-    const double* M = minv + 6 * (size_t)frame;
     src += (size_t)frame * src_fs;
     dst += (size_t)frame * dst_fs;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1220,25 +1239,20 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const int x0 = txi * WT_W, y0 = tyi * CV_TH;
     const int nx = min(WT_W, roi.w - x0), ny = min(CV_TH, roi.h - y0);             // live columns / rows of this tile (>= 1)
     const int x = x0 + lane;
-    // columns / rows beyond the window repeat its last column / row (masked at the store)
-    const int fxq = min(x, roi.w - 1) + roi.x;
-    if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
-    else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
-    else {                                                 // waves 2 and 3: 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63, per pass
-        for (int r0 = 32 * (wv - 2); r0 < CV_TH; r0 += 64) {
-            const int r = r0 + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
-            cv_tab[128 + (lane < 32 ? 0 : CV_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
-        }
-    }
-    __syncthreads();
-    const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
+    // this frame's tables at this tile (tab_w / tab_h are whole tiles: columns / rows beyond the window repeat its last column / row there,
+    // masked at the store)
+    const int* __restrict__ const adp = tab + (size_t)frame * (size_t)(2 * (tab_w + tab_h)) + x0;
+    const int* __restrict__ const bdp = adp + tab_w;
+    const int* __restrict__ const X0p = adp + (2 * tab_w - x0) + y0;
+    const int* __restrict__ const Y0p = X0p + tab_h;
+    const int ad = adp[lane], bd = bdp[lane];
     // source footprint: X0[y] and adelta[x] are monotone (cvRound of a monotone function), so the extremes sit at the tile's corners
     // (each table entry is within +-2^29 or the tile does not "fit": the sums below stay inside 32 bits, and a tile that passes is far from the
     // wrap in X0 + adelta and from saturate_cast<short>)
-    const int adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
-    const int bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
-    const int XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
-    const int YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV_TH + ny - 1]);
+    const int adA = adp[0], adB = adp[nx - 1];
+    const int bdA = bdp[0], bdB = bdp[nx - 1];
+    const int XA = X0p[0], XB = X0p[ny - 1];
+    const int YA = Y0p[0], YB = Y0p[ny - 1];
     const int lim = 1 << 23;                                 // |X0|, |adelta| < 2^23 in 10-bit fixed point = 2^13 pixels each
     bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
@@ -1256,8 +1270,9 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)src_stride) & 3) == 0;                      // uniform
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     VS_STAMP(1);
+    // (row offsets are 24-bit multiplies: a pitch of 2^24 bytes or more takes the rim path, whatever the frame's height)
     const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
-                          (size_t)h * (size_t)src_stride < (1ull << 32);                                    // uniform
+                          (size_t)h * (size_t)src_stride < (1ull << 32) && src_stride < (1 << 24);            // uniform
     if (interior && !(VS_WARP_WHATIF & 2)) {
         // Interior tiles (the whole staged window inside an aligned frame: all but the frame's rim): every address is one 24-bit multiply-add
         // from a uniform base, no border tests.  (Clamping the items beyond the tile's own rows / column groups onto its last row / group
@@ -1422,7 +1437,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             uint32_t d[CV_RBK];
 #pragma unroll
             for (int k = 0; k < CV_RBK; k++)
-                d[k] = quad_pack_bgr(sample((uint32_t)cv_tab[128 + wv * CV_RPW + k0 + k] + adw, (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k0 + k] + (uint32_t)bd), sel);
+                d[k] = quad_pack_bgr(sample((uint32_t)X0p[wv * CV_RPW + k0 + k] + adw, (uint32_t)Y0p[wv * CV_RPW + k0 + k] + (uint32_t)bd), sel);
             if (m < 3 && (!(VS_WARP_WHATIF & 8) || d[0] == 0x12345678u)) {
 #pragma unroll
                 for (int k = 0; k < CV_RBK; k++, roff += (uint32_t)dst_stride) VS_STORE32((uint32_t*)(dst + roff), d[k]);
@@ -1446,7 +1461,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     for (int k = 0; k < CV_RPW; k++) {
         const int y = yw + k;
         if (y >= roi.h) break;                               // wave-uniform
-        const uint32_t Xs = (uint32_t)cv_tab[128 + wv * CV_RPW + k] + (uint32_t)ad, Ys = (uint32_t)cv_tab[128 + CV_TH + wv * CV_RPW + k] + (uint32_t)bd;
+        const uint32_t Xs = (uint32_t)X0p[wv * CV_RPW + k] + (uint32_t)ad, Ys = (uint32_t)Y0p[wv * CV_RPW + k] + (uint32_t)bd;
         uint32_t p = 0u;
         if (!fits) {
             uint32_t o[3] = {0u, 0u, 0u};
@@ -1504,15 +1519,13 @@ __device__ __forceinline__ void cv_pixel_global_u16(const uint16_t* __restrict__
 
 template <int BORDER>
 __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c3_u16(const uint16_t* __restrict__ src, int w, int h, int src_stride,
-                                                                 const double* __restrict__ minv, uint16_t* __restrict__ dst, int dst_stride,
+                                                                 const int* __restrict__ tab, int tab_w, int tab_h, uint16_t* __restrict__ dst, int dst_stride,
                                                                  size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
                                                                  int chunk, int maxv, vsk::Roi roi) {
     __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV16_WS_H * WS_RS8 * 2];      // {B | G << 16, R} per staged source pixel
-    __shared__ __attribute__((aligned(16))) int cv_tab[128 + 2 * CV16_TH];                   // adelta[64] | bdelta[64] | X0[32] | Y0[32]
     const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
     const int frame = blockIdx.y;
-    const double* M = minv + 6 * (size_t)frame;
     src += (size_t)frame * src_fs;
     dst += (size_t)frame * dst_fs;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1521,21 +1534,16 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     const int x0 = txi * WT_W, y0 = tyi * CV16_TH;
     const int nx = min(WT_W, roi.w - x0), ny = min(CV16_TH, roi.h - y0);
     const int x = x0 + lane;
-    const int fxq = min(x, roi.w - 1) + roi.x;
-    if (wv == 0) cv_tab[lane] = cv_delta(M[0], fxq);
-    else if (wv == 1) cv_tab[64 + lane] = cv_delta(M[3], fxq);
-    else {                                                 // waves 2 and 3: 32 rows' X0 in lanes 0..31, their Y0 in lanes 32..63, per pass
-        for (int r0 = 32 * (wv - 2); r0 < CV16_TH; r0 += 64) {
-            const int r = r0 + (lane & 31), fyq = min(y0 + r, roi.h - 1) + roi.y;
-            if (r < CV16_TH) cv_tab[128 + (lane < 32 ? 0 : CV16_TH) + r] = lane < 32 ? cv_row_origin(M[1], M[2], fyq) : cv_row_origin(M[4], M[5], fyq);
-        }
-    }
-    __syncthreads();
-    const int ad = cv_tab[lane], bd = cv_tab[64 + lane];
-    const int adA = __builtin_amdgcn_readfirstlane(cv_tab[0]), adB = __builtin_amdgcn_readfirstlane(cv_tab[nx - 1]);
-    const int bdA = __builtin_amdgcn_readfirstlane(cv_tab[64]), bdB = __builtin_amdgcn_readfirstlane(cv_tab[64 + nx - 1]);
-    const int XA = __builtin_amdgcn_readfirstlane(cv_tab[128]), XB = __builtin_amdgcn_readfirstlane(cv_tab[128 + ny - 1]);
-    const int YA = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH]), YB = __builtin_amdgcn_readfirstlane(cv_tab[128 + CV16_TH + ny - 1]);
+    // (the per-frame tables of vs_k_cv_tables, read as in the 8-bit kernel: corners and row origins by scalar loads, the lane's deltas by vector loads)
+    const int* __restrict__ const adp = tab + (size_t)frame * (size_t)(2 * (tab_w + tab_h)) + x0;
+    const int* __restrict__ const bdp = adp + tab_w;
+    const int* __restrict__ const X0p = adp + (2 * tab_w - x0) + y0;
+    const int* __restrict__ const Y0p = X0p + tab_h;
+    const int ad = adp[lane], bd = bdp[lane];
+    const int adA = adp[0], adB = adp[nx - 1];
+    const int bdA = bdp[0], bdB = bdp[nx - 1];
+    const int XA = X0p[0], XB = X0p[ny - 1];
+    const int YA = Y0p[0], YB = Y0p[ny - 1];
     const int lim = 1 << 23;                                 // (as in the 8-bit kernel: every entry within 2^13 pixels, the sums inside 32 bits)
     bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
@@ -1554,7 +1562,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     uint32_t seen = 0;                                       // OR of every staged sample (as packed pairs): bits 14 / 15 of a half set = a sample >= 2^14
     const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
-                          (size_t)h * (size_t)src_stride * 2 < (1ull << 32);                                 // uniform
+                          (size_t)h * (size_t)src_stride * 2 < (1ull << 32) && src_stride < (1 << 23);       // uniform (24-bit row-offset multiplies)
     if (interior) {                                          // (as in the 8-bit kernel: one 24-bit multiply-add per address from a uniform base, no border tests)
         const uint8_t* base = (const uint8_t*)(src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3));
 #if VS_WARP_CV_ROW_FILL
@@ -1705,7 +1713,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
 #pragma unroll
         for (int k = 0; k < CV16_RPW; k++) {
             uint32_t o[3];
-            sample((uint32_t)cv_tab[128 + wv * CV16_RPW + k] + adw, (uint32_t)cv_tab[128 + CV16_TH + wv * CV16_RPW + k] + (uint32_t)bd, o);
+            sample((uint32_t)X0p[wv * CV16_RPW + k] + adw, (uint32_t)Y0p[wv * CV16_RPW + k] + (uint32_t)bd, o);
             pair_pack_bgr16(o, x & 1, d0[k], d1[k]);
         }
         uint32_t roff = (uint32_t)yw * (2u * (uint32_t)dst_stride) + (uint32_t)(x & ~1) * 6u;      // 12 bytes per pixel pair
@@ -1725,7 +1733,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     for (int k = 0; k < CV16_RPW; k++) {
         const int y = yw + k;
         if (y >= roi.h) break;                               // wave-uniform
-        const uint32_t Xs = (uint32_t)cv_tab[128 + wv * CV16_RPW + k] + (uint32_t)ad, Ys = (uint32_t)cv_tab[128 + CV16_TH + wv * CV16_RPW + k] + (uint32_t)bd;
+        const uint32_t Xs = (uint32_t)X0p[wv * CV16_RPW + k] + (uint32_t)ad, Ys = (uint32_t)Y0p[wv * CV16_RPW + k] + (uint32_t)bd;
         uint32_t o[3] = {0u, 0u, 0u};
         if (!fits) {
             if (lane_in) cv_pixel_global_u16<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, maxv, o);
@@ -1809,46 +1817,47 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
                                n_frames, src_fs, dst_fs, (float)max_value, roi, s);
 }
 
-hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int border, int max_value, void* dst,
+// ints of table per frame for (bits, window): what bgr_warp_cv_c3's caller reserves (n_frames times) for `tab_dev`
+size_t bgr_warp_cv_table_ints(int bits, Roi roi) {
+    const int th = bits == 16 ? CV16_TH : CV_TH;
+    const size_t tw = (size_t)((roi.w + WT_W - 1) / WT_W) * WT_W, tt = (size_t)((roi.h + th - 1) / th) * th;
+    return 2 * (tw + tt);
+}
+
+hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int* tab_dev, int border, int max_value, void* dst,
                           int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
-    if (bits == 16) {                                        // 10 / 12 / 16-bit containers: the word-tile kernel
-        if (max_value < 0 || max_value > 65535) return hipErrorNotSupported;
-        const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + CV16_TH - 1) / CV16_TH;
-        const long long tpf = (long long)tiles_x * tiles_y;
-        if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
-        const int chunk = (int)((tpf + 7) / 8);
-        const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
-        for (int f0 = 0; f0 < n_frames; f0 += 65535) {
-            const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
-            dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
-            const uint16_t* sp = (const uint16_t*)src + (size_t)f0 * src_fs;
-            uint16_t* dp = (uint16_t*)dst + (size_t)f0 * dst_fs;
-            if (border == 0)
-                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<0>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
-                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
-            else
-                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<1>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
-                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
-        }
-        return hipGetLastError();
-    }
-    if (bits != 8 || max_value != 255) return hipErrorNotSupported;          // (results never exceed 255: the weights sum to 1024)
-    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + CV_TH - 1) / CV_TH;
+    if (bits == 16 ? (max_value < 0 || max_value > 65535) : (bits != 8 || max_value != 255)) return hipErrorNotSupported;   // (8-bit results never exceed 255: the weights sum to 1024)
+    const int th = bits == 16 ? CV16_TH : CV_TH;
+    const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + th - 1) / th;
     const long long tpf = (long long)tiles_x * tiles_y;
     if (tpf > 0x3fffffLL || tpf * tiles_x >= (1LL << 32)) return hipErrorNotSupported;
     const int chunk = (int)((tpf + 7) / 8);
     const uint32_t magic = (uint32_t)(0x100000000ULL / (uint32_t)tiles_x) + 1u;
+    const int tab_w = tiles_x * WT_W, tab_h = tiles_y * th;
+    const size_t per = 2 * ((size_t)tab_w + (size_t)tab_h), esz = (size_t)bits / 8;
     for (int f0 = 0; f0 < n_frames; f0 += 65535) {         // gridDim.y limit
         const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
-        const uint8_t* sp = (const uint8_t*)src + (size_t)f0 * src_fs;
-        uint8_t* dp = (uint8_t*)dst + (size_t)f0 * dst_fs;
+        const int* tp = tab_dev + (size_t)f0 * per;
+        hipLaunchKernelGGL(vs_k_cv_tables, dim3((unsigned)((per + 255) / 256), (unsigned)nf), dim3(256), 0, s, minv_dev + 6 * (size_t)f0, tab_dev + (size_t)f0 * per,
+                           tab_w, tab_h, roi);
         dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
-        if (border == 0)
-            hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<0>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
-                               tiles_x, magic, (int)tpf, chunk, roi);
-        else
-            hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<1>), grid, block, 0, s, sp, w, h, src_stride, minv_dev + 6 * (size_t)f0, dp, dst_stride, src_fs, dst_fs,
-                               tiles_x, magic, (int)tpf, chunk, roi);
+        const char* sp = (const char*)src + (size_t)f0 * src_fs * esz;
+        char* dp = (char*)dst + (size_t)f0 * dst_fs * esz;
+        if (bits == 16) {                                    // 10 / 12 / 16-bit containers: the word-tile kernel
+            if (border == 0)
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<0>), grid, block, 0, s, (const uint16_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint16_t*)dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
+            else
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<1>), grid, block, 0, s, (const uint16_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint16_t*)dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, max_value, roi);
+        } else {
+            if (border == 0)
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<0>), grid, block, 0, s, (const uint8_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint8_t*)dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, roi);
+            else
+                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<1>), grid, block, 0, s, (const uint8_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint8_t*)dp, dst_stride, src_fs, dst_fs,
+                                   tiles_x, magic, (int)tpf, chunk, roi);
+        }
     }
     return hipGetLastError();
 }

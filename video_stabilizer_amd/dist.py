@@ -138,3 +138,24 @@ def gather_seconds(seconds, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t, group=_REPORT_GROUP if device is not None else None)
     return [float(x.item()) for x in out]
+
+
+def roll_call(info):
+    """every rank's `info` (a small dict), in rank order -- over the host-side channel (gloo), before anything is timed.  One rank: [info]."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [info]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, info)
+    return out
+
+
+def shared_devices(infos, visible_devices):
+    """ranks that sit on the SAME physical device although the node shows enough devices for one each: [(device key, [ranks])].
+    A job with more ranks than visible devices (a rehearsal on a one-GPU box) is allowed to share."""
+    if len(infos) > visible_devices:
+        return []
+    seen = {}
+    for i in infos:
+        seen.setdefault(i["device_key"], []).append(i["rank"])
+    return [(k, r) for k, r in sorted(seen.items()) if len(r) > 1]
