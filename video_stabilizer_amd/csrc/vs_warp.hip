@@ -1140,11 +1140,10 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 #ifndef VS_WARP_CV_W16
 #define VS_WARP_CV_W16 1                 // sampler: 16-bit weights 64 a b (the top-left one saturated to 65535): the sample lands on a byte boundary
 #endif
-#ifndef VS_WARP_CV_DMA_FILL
-#define VS_WARP_CV_DMA_FILL 1            // interior tiles of the 8-bit kernel are filled by LDS-DMA (global_load_lds_dword at a 3-byte lane stride); 0: through registers
-#endif
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+// (Measured and dropped, round 6 -- commit 2 of the round, profiles/r06_warp_cv.md: interior tiles filled by LDS-DMA, one `global_load_lds_dword` per 64
+// staged pixels with each lane reading the four bytes at its pixel's byte-aligned address, which lands the sampler's own tile format with no registers and no
+// formatting instructions.  Bit-identical (tools/ubench_glds3.hip: right for every byte offset and pitch), 13.5 us per 4K frame against 10.8: 144 four-byte
+// gathers per tile cost the texture path more than 21 twelve-byte loads and their formatting cost the vector unit.)
 #ifndef VS_WARP_CV_TILE_H
 #define VS_WARP_CV_TILE_H 64             // output rows per workgroup: 32, or a multiple of 64 (the row-origin table is filled 32 rows per wave pass).
                                          // Measured (profiles/r05_warp_cv.md): 32 rows 12.3 us per 4K frame, 64 rows 11.1, 128 rows 12.9 -- the taller tile halves the
@@ -1259,7 +1258,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const int XA = X0p[0], XB = X0p[ny - 1];
     const int YA = Y0p[0], YB = Y0p[ny - 1];
     const int lim = 1 << 23;                                 // |X0|, |adelta| < 2^23 in 10-bit fixed point = 2^13 pixels each
-    bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
+    // (one test over all eight corners, no short circuit: the eight scalar loads then issue together and are waited for once)
+    bool fits = max(max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))), max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB)))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
     const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
@@ -1278,25 +1278,6 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     // (row offsets are 24-bit multiplies: a pitch of 2^24 bytes or more takes the rim path, whatever the frame's height)
     const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
                           (size_t)h * (size_t)src_stride < (1ull << 32) && src_stride < (1 << 24);            // uniform
-#if VS_WARP_CV_DMA_FILL
-    // LDS-DMA fill: one `global_load_lds_dword` per 64 staged pixels of a row, each lane reading the FOUR bytes at its pixel's (byte-aligned) address
-    // -- {B, G, R, next pixel's B} -- which land lane-linear in the tile: the sampler's own format (its byte selectors never pick byte 3), no
-    // registers, no formatting instructions, no source alignment requirement (tools/ubench_glds3.hip: right for every byte offset and pitch).
-    // The read of a row's last staged pixel reaches one byte past it: not allowed where that could be the byte behind the frame's last pixel.
-    const bool dma = fits && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h && (sy_lo + rows < h || sx_lo + 4 * groups < w);
-    if (dma && !(VS_WARP_WHATIF & 2)) {
-        const uint8_t* lanep = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3) + 3 * lane;
-        const int tail = 4 * groups - 64;                       // staged columns beyond the first 64 (<= 16)
-        for (int r = wv; r < rows; r += 4) {
-            const uint8_t* rp = lanep + (size_t)r * (size_t)src_stride;
-            __builtin_amdgcn_global_load_lds((gptr_t)rp, (lptr_t)(tile_raw + r * WS_RS8), 4, 0, 0);
-            if (lane < tail) __builtin_amdgcn_global_load_lds((gptr_t)(rp + 192), (lptr_t)(tile_raw + r * WS_RS8 + 64), 4, 0, 0);
-        }
-        VS_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        VS_STAMP(3);
-    } else
-#endif
     if (interior && !(VS_WARP_WHATIF & 2)) {
         // Interior tiles (the whole staged window inside an aligned frame: all but the frame's rim): every address is one 24-bit multiply-add
         // from a uniform base, no border tests.  (Clamping the items beyond the tile's own rows / column groups onto its last row / group
@@ -1569,7 +1550,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     const int XA = X0p[0], XB = X0p[ny - 1];
     const int YA = Y0p[0], YB = Y0p[ny - 1];
     const int lim = 1 << 23;                                 // (as in the 8-bit kernel: every entry within 2^13 pixels, the sums inside 32 bits)
-    bool fits = max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))) < lim && max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB))) < lim;
+    bool fits = max(max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))), max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB)))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
     const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
     int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
