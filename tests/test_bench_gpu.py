@@ -56,9 +56,19 @@ def test_bench_line_contract(gpu_vs):
     assert j["value_warp_mode"] == "separable" and "separable" in j["config"]["warp"] and "separable" in r["kernel"]
     assert j["config"]["select_mode_in_force"] == 1
     assert j["exact_warp"]["value"] > 0 and j["contracted_warp"]["value"] > 0 and "separable_warp" not in j and j["stable_select"]["value"] > 0
-    assert j["bilinear_cv_warp"]["value"] > j["value"]              # the reference's own per-frame warp: the step is alignment-bound with it
-    bm = j["bilinear_cv_warp"]["by_solver_mode"]                    # ... measured with the solver kernel in both batch modes, the faster one leads
-    assert set(bm) == {"shared", "exclusive"} and j["bilinear_cv_warp"]["value"] == max(bm.values()) == bm[j["bilinear_cv_warp"]["solver"]]
+    # the reference's OWN pipeline on the headline workload (align + cv::warpAffine's fixed-point bilinear, constant border, forward map): alignment-bound,
+    # measured with the solver kernel in both batch modes (the faster one leads), with its own in-step roofline and stage table
+    dw = j["default_warp"]
+    assert dw["value"] > j["value"] and "VS_BORDER_CONSTANT" in dw["warp"] and "gn" in dw["stages"]
+    bm = dw["by_solver_mode"]
+    assert set(bm) == {"shared", "exclusive"} and dw["value"] == max(bm.values()) == bm[dw["solver"]]
+    assert dw["roofline"]["bytes_per_launch"] == 1920 * 1080 * 3 * 2 * 8 and abs(dw["roofline"]["frac"] - dw["roofline"]["achieved"] / 8000.0) < 1e-3
+    # the record's tail: {mode: [us per 4K frame, fraction of the HBM peak]} as the LAST key of the line, and the `value` mode at 4K inside `roofline`
+    assert list(j)[-1] == "roofline_4k_summary" and j["scaling_curve_measured"] is False
+    sm = j["roofline_4k_summary"]
+    for name in ("separable", "exact", "bilinear_cv", "bilinear_cv_10bit"):
+        assert sm[name] == [j["roofline_4k"][name]["us_per_frame"], j["roofline_4k"][name]["frac"]]
+    assert r["at_4k"]["mode"] == "separable" and r["at_4k"]["frac"] == sm["separable"][1]
     assert j["roofline_4k"]["bilinear_cv"]["achieved"] > j["roofline_4k"]["bilinear"]["achieved"]
     for key in ("separable_vs_exact", "contracted_vs_exact"):
         g = p[key]
@@ -74,6 +84,7 @@ def test_bench_line_contract(gpu_vs):
     assert "error" not in c3 and c3["value"] > 0 and c3["frames_per_step"] == 120 and c3["aligned_per_step"] == 119
     assert c3["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120 and "gn" in c3["stages"]
     assert c3["exact_warp"]["value"] > 0 and c3["contracted_warp"]["value"] > 0 and c3["separable_vs_exact"]["pass"] is True
+    assert c3["default_warp"]["value"] > c3["value"] and c3["default_warp"]["roofline"]["bytes_per_launch"] == 3840 * 2160 * 3 * 2 * 120
     # BASELINE configs[4]: 4K 10-bit, full stabilizer loop (2 of the 8 clips per GPU here)
     c5 = j["c5"]
     assert "error" not in c5 and c5["value"] > 0 and c5["dtype"] == "u16" and c5["frames_per_step"] == 2 * 60
@@ -116,6 +127,12 @@ def test_bench_spawns_its_own_ranks(gpu_vs):
     assert out.stdout.strip() == lines[0]                           # ... and nothing else on stdout (library banners go to stderr)
     j = json.loads(lines[0])
     assert j["n_gpus"] == RANKS and j["rccl_ranks"] == RANKS and j["dist_backend"] == "gloo"
+    # the roll call before anything is timed: one stderr line per rank (device, backend, clip split), the same facts in the line, and the plain
+    # statement that no scaling curve has been measured
+    for rk in range(RANKS):
+        assert "bench.py rank %d/%d: device 0" % (rk, RANKS) in out.stderr, out.stderr[-1500:]
+    assert [e["rank"] for e in j["ranks"]] == list(range(RANKS)) and all(e["device"] == 0 and e["backend"] == "gloo" for e in j["ranks"])
+    assert j["scaling_curve_measured"] is False and "no 1 -> 8 GPU curve" in out.stderr
     assert j["aligned_per_step"] == RANKS * 5                       # every rank's clip is counted
     assert len(j["value_spread"]["values"]) == 3
     # N > 1, default workload: BASELINE configs[3] as a strong-scaling leg beside the weak `value`: 64 clips, clip i -> rank i mod N,

@@ -24,7 +24,9 @@ d.barrier()
 dt = time.perf_counter() - t0
 secs, tot_f, tot_a = D.aggregate(dt, frames, aligned)
 per_rank = D.gather_seconds(dt)
-print(json.dumps({"rank": rank, "clips": clips, "secs": secs, "frames": tot_f, "aligned": tot_a, "own": dt, "per_rank": per_rank}))
+roll = D.roll_call({"rank": rank, "device_key": "box/gpu%%d" %% (0 if os.environ.get("SAME_DEVICE") else rank)})
+print(json.dumps({"rank": rank, "clips": clips, "secs": secs, "frames": tot_f, "aligned": tot_a, "own": dt, "per_rank": per_rank,
+                  "roll": roll, "clash_8_visible": D.shared_devices(roll, 8), "clash_1_visible": D.shared_devices(roll, 1)}))
 d.destroy_process_group()
 '''
 
@@ -53,6 +55,31 @@ def test_two_rank_gloo_shard_and_aggregate(tmp_path):
     # the per-rank view (bench.py's c4_strong.per_rank_seconds): every rank sees every rank's own seconds, in rank order
     for o in outs:
         assert o["per_rank"] == [outs[0]["own"], outs[1]["own"]] and max(o["per_rank"]) == o["secs"]
+        # the roll call bench.py makes before anything is timed: every rank has every rank's record, in rank order; distinct devices: no clash
+        assert [e["rank"] for e in o["roll"]] == [0, 1] and o["clash_8_visible"] == [] and o["clash_1_visible"] == []
+
+
+def test_roll_call_finds_two_ranks_on_one_device(tmp_path):
+    """both ranks report the same physical device: a launch error when the node shows a device for each (bench.py ends the job with exit code 5),
+    an allowed rehearsal when there are more ranks than visible devices"""
+    import json
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    port = str(29900 + os.getpid() % 90)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SAME_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e
+        j = json.loads(o.strip().splitlines()[-1])
+        assert j["clash_8_visible"] == [["box/gpu0", [0, 1]]] and j["clash_1_visible"] == []
+
+
+def test_roll_call_without_a_process_group():
+    from video_stabilizer_amd import dist as D
+    assert D.roll_call({"rank": 0, "device_key": "x"}) == [{"rank": 0, "device_key": "x"}]
 
 
 FALLBACK_WORKER = r'''

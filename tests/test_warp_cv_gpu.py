@@ -6,6 +6,8 @@ In this mode the transform argument is the FORWARD map handed to warpBySimilarit
 import numpy as np
 import pytest
 
+from _diff import same
+
 pytestmark = pytest.mark.gpu
 
 TRANSFORMS = [(0.004, -0.003, 2.25, -1.5), (-0.01, 0.02, -7.75, 3.125), (0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 3.0, -2.0), (0.0007, 0.0019, 0.5, 0.5),
@@ -136,9 +138,12 @@ def test_cv_mode_16bit_containers_ragged_sizes_mixed_depth_tiles_and_windows(gpu
 
 
 def test_cv_mode_16bit_every_fraction_pair_clamped_and_clampless_tiles(gpu_vs, oracle):
-    """the word-tile kernel's common path works with 16-bit weights 64 a b (top-left saturated) and takes the sample from the high half of the
-    rounded sum; tiles whose staged samples all lie within max_value skip the clamp, the others (a 10-bit frame with stray values up to 2^14 - 1
-    in one region: still the integer form) keep it.  Every pair of 1/32-pixel fractions, extreme and odd samples (halves round to even)."""
+    """the word-tile kernel has two sampler forms, chosen per tile by `seen & 0xc000c000` (does ANY staged sample reach 2^14?): below it the INTEGER form --
+    OpenCV's 15-bit weights 32 a b, S = sum w v by v_dot2_u32_u16, result (S + 16383 + ((S >> 15) & 1)) >> 15 = cvRound's half-to-even, then
+    min(., max_value), always -- and from 2^14 up the FLOAT expression as OpenCV writes it.  This frame keeps every tile on the integer side of the
+    boundary, with stray samples up to 2^14 - 1 = 16383 in one region (above max_value: the clamp must bite) and 10-bit content in the other; every
+    pair of 1/32-pixel fractions, extreme and odd samples (exact halves round to even).  The float side of the boundary: test_cv_mode_16bit_*
+    above (full 16-bit content) and the mixed-tile frame below."""
     rng = np.random.default_rng(78)
     src = rng.choice(np.array([0, 1, 2, 3, 511, 512, 1021, 1022, 1023], np.uint16), size=(40, 136, 3))
     src[:, 70:] = rng.choice(np.array([0, 1, 1023, 1024, 1025, 8191, 16382, 16383], np.uint16), size=(40, 66, 3))     # above max_value, below 2^14
@@ -152,6 +157,41 @@ def test_cv_mode_16bit_every_fraction_pair_clamped_and_clampless_tiles(gpu_vs, o
     # a max_value that is not 2^k - 1 always clamps
     g = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(0.001, 0.002, 0.3, 0.7), mode=gpu_vs.WARP_BILINEAR_CV, border=0, max_value=1000)
     assert np.array_equal(g, oracle.bgr_image_warp(src, oracle.Transform.of(0.001, 0.002, 0.3, 0.7), oracle.WARP_BILINEAR_CV, border=0, max_value=1000))
+    # the boundary itself: ONE sample of 16384 = 2^14 in a tile flips that tile (and only it) to the float form; both forms must agree with the twin on
+    # the tiles either side of it (64 x 32 output tiles: the sample sits in the second tile column)
+    edge = src.copy()
+    edge[:, 70:] = np.minimum(edge[:, 70:], 16383)
+    edge[5, 100, 1] = 16384
+    for tr in [(0.0, 0.0, 1.0 + 7 / 32.0, -1.0 - 13 / 32.0), (0.003, -0.002, 0.4, 0.9)]:
+        g = gpu_vs.bgr_image_warp(edge, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=gpu_vs.BORDER_CONSTANT, max_value=65535)
+        assert same(g, oracle.bgr_image_warp(edge, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CONSTANT, max_value=65535)), tr
+
+
+def test_cv_mode_row_pitch_of_2_to_the_24_bytes_and_more(gpu_vs, oracle):
+    """the interior fills address rows with 24-bit multiplies (row x pitch): a caller's pitch of 2^24 bytes or more (allowed: the API bounds the extents,
+    not the pitch) must take the rim path instead of wrapping.  Three rows 2^24 + 4 bytes apart (8-bit) and 2^23 + 2 elements apart (16-bit
+    containers), device memory, an interior-sized frame."""
+    import ctypes as C
+    import torch
+    w, h = 200, 3
+    rng = np.random.default_rng(5)
+    for bits, pitch in ((8, (1 << 24) + 4), (16, (1 << 23) + 2)):                 # pitch in elements
+        dt, tdt, mv = (np.uint8, torch.uint8, 255) if bits == 8 else (np.uint16, torch.int16, 1023)
+        img = rng.integers(0, mv + 1, (h, w, 3)).astype(dt)
+        src = torch.zeros((h - 1) * pitch + 3 * w, dtype=tdt, device="cuda:0")
+        for y in range(h):
+            row = torch.from_numpy(img[y].reshape(-1).view(np.int16) if bits == 16 else img[y].reshape(-1)).to("cuda:0")
+            src[y * pitch:y * pitch + 3 * w] = row
+        dst = torch.zeros((h, 3 * w), dtype=tdt, device="cuda:0")
+        tr = (0.001, -0.002, 0.3, 0.2)
+        t = gpu_vs.Transform.of(*tr)
+        r = gpu_vs.lib().vs_bgr_image_warp(C.c_void_p(src.data_ptr()), w, h, pitch, 3, bits, C.byref(t), gpu_vs.WARP_BILINEAR_CV, gpu_vs.BORDER_CLAMP, mv,
+                                           C.c_void_p(dst.data_ptr()), 3 * w, gpu_vs.MEM_DEVICE, None)
+        assert r >= 0, gpu_vs.lib().vs_last_error()
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        got = (got.view(np.uint16) if bits == 16 else got).reshape(h, w, 3)
+        assert same(got, oracle.bgr_image_warp(img, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CLAMP, max_value=mv)), bits
 
 
 def test_cv_mode_4k_frame(gpu_vs, oracle):

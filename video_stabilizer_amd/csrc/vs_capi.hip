@@ -741,20 +741,25 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
         for (int f0 = 0; f0 < n_frames; f0 += per_call) {
             const int nf = std::min(per_call, n_frames - f0);
             for (int i = 0; i < nf; i++) vs_cv_inverse_matrix(&t[f0 + i], w, h, &Mv[(size_t)i * 6]);
-            float4* mdev = nullptr;
-            VS_TRY(ring->upload((const float*)Mv.data(), ((size_t)nf * 6 * sizeof(double) + 15) / 16, s, &mdev));
             const char* sp = (const char*)a.dev + (size_t)f0 * src_fs * esz;
             char* dp = (char*)o.dev + (size_t)f0 * dst_fs * esz;
             hipError_t e = hipErrorNotSupported;
             int* tdev = nullptr;
+            float4* mdev = nullptr;
+            // small calls (one frame of the drop-in pattern, the parity tests' batches): the matrices go to the table kernel as kernel arguments, no upload
+            const bool by_value = n_frames <= vsk::kCvInlineFrames;
             if (channels == 3 && tring && tab_per * (size_t)nf <= TableRing::kInts / 2) {
+                if (!by_value) VS_TRY(ring->upload((const float*)Mv.data(), ((size_t)nf * 6 * sizeof(double) + 15) / 16, s, &mdev));
                 VS_TRY(tring->take(tab_per * (size_t)nf, s, &tdev));
-                e = vsk::bgr_warp_cv_c3(sp, w, h, src_stride, bits, (const double*)mdev, tdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+                e = vsk::bgr_warp_cv_c3(sp, w, h, src_stride, bits, (const double*)mdev, by_value ? Mv.data() : nullptr, tdev, border, max_value, dp, dst_stride, nf, src_fs,
+                                        dst_fs, roi, s);
             }
-            if (e == hipErrorNotSupported)
+            if (e == hipErrorNotSupported) {
+                if (!mdev) VS_TRY(ring->upload((const float*)Mv.data(), ((size_t)nf * 6 * sizeof(double) + 15) / 16, s, &mdev));
                 e = vsk::bgr_warp_cv_generic(sp, w, h, src_stride, channels, bits, (const double*)mdev, border, max_value, dp, dst_stride, nf, src_fs, dst_fs, roi, s);
+            }
             VS_HIP(e);
-            VS_TRY(ring->fence(mdev, s));
+            if (mdev) VS_TRY(ring->fence(mdev, s));
             if (tdev) VS_TRY(tring->fence(tdev, s));
         }
         return vsi::finish_outputs(mem, s, {&o});

@@ -1176,11 +1176,26 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 // The coordinate tables of a launch: per frame adelta[tab_w] | bdelta[tab_w] | X0[tab_h] | Y0[tab_h] (ints), tab_w / tab_h = the output window
 // rounded up to whole tiles; entries beyond the window repeat its last column / row.  One thread per entry: each is ONE double-precision
 // evaluation exactly as OpenCV's warpAffine makes it once per call (cvRound(m x 1024), cvRound((m y + t) 1024) + round_delta).
-__global__ __launch_bounds__(256) void vs_k_cv_tables(const double* __restrict__ minv, int* __restrict__ tab, int tab_w, int tab_h, vsk::Roi roi) {
+// (calls of up to vsk::kCvInlineFrames frames hand their matrices to this kernel BY VALUE, as kernel arguments: no upload stands between the host's
+// numbers and the tables -- the per-frame drop-in call and the small batches of the parity tests; larger batches read them from the parameter ring)
+struct CvMatrices { double m[6 * vsk::kCvInlineFrames]; };
+template <bool INLINE>
+__global__ __launch_bounds__(256) void vs_k_cv_tables(const double* __restrict__ minv, CvMatrices inl, int* __restrict__ tab, int tab_w, int tab_h, vsk::Roi roi) {
     const int per = 2 * (tab_w + tab_h);
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= per) return;
-    const double* M = minv + 6 * (size_t)blockIdx.y;
+    double Mv[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Mv[k] = INLINE ? 0.0 : minv[6 * (size_t)blockIdx.y + k];
+    if (INLINE) {
+#pragma unroll
+        for (int f = 0; f < vsk::kCvInlineFrames; f++)           // (uniform select: kernel arguments cannot be indexed dynamically without scratch)
+            if ((int)blockIdx.y == f) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) Mv[k] = inl.m[6 * f + k];
+            }
+    }
+    const double* M = Mv;
     int v;
     if (i < 2 * tab_w) {
         const int xx = i < tab_w ? i : i - tab_w;
@@ -1829,8 +1844,8 @@ size_t bgr_warp_cv_table_ints(int bits, Roi roi) {
     return 2 * (tw + tt);
 }
 
-hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, int* tab_dev, int border, int max_value, void* dst,
-                          int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
+hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, const double* minv_host, int* tab_dev, int border, int max_value,
+                          void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s) {
     if (bits == 16 ? (max_value < 0 || max_value > 65535) : (bits != 8 || max_value != 255)) return hipErrorNotSupported;   // (8-bit results never exceed 255: the weights sum to 1024)
     const int th = bits == 16 ? CV16_TH : CV_TH;
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + th - 1) / th;
@@ -1843,8 +1858,15 @@ hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bit
     for (int f0 = 0; f0 < n_frames; f0 += 65535) {         // gridDim.y limit
         const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
         const int* tp = tab_dev + (size_t)f0 * per;
-        hipLaunchKernelGGL(vs_k_cv_tables, dim3((unsigned)((per + 255) / 256), (unsigned)nf), dim3(256), 0, s, minv_dev + 6 * (size_t)f0, tab_dev + (size_t)f0 * per,
-                           tab_w, tab_h, roi);
+        if (minv_host && n_frames <= kCvInlineFrames) {
+            CvMatrices inl{};
+            for (int k = 0; k < 6 * n_frames; k++) inl.m[k] = minv_host[k];
+            hipLaunchKernelGGL(vs_k_cv_tables<true>, dim3((unsigned)((per + 255) / 256), (unsigned)nf), dim3(256), 0, s, (const double*)nullptr, inl, tab_dev, tab_w, tab_h, roi);
+        } else {
+            if (!minv_dev) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(vs_k_cv_tables<false>, dim3((unsigned)((per + 255) / 256), (unsigned)nf), dim3(256), 0, s, minv_dev + 6 * (size_t)f0, CvMatrices{},
+                               tab_dev + (size_t)f0 * per, tab_w, tab_h, roi);
+        }
         dim3 grid((unsigned)(chunk * 8), (unsigned)nf), block(256);
         const char* sp = (const char*)src + (size_t)f0 * src_fs * esz;
         char* dp = (char*)dst + (size_t)f0 * dst_fs * esz;
