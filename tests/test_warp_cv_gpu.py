@@ -167,6 +167,26 @@ def test_cv_mode_16bit_every_fraction_pair_clamped_and_clampless_tiles(gpu_vs, o
         assert same(g, oracle.bgr_image_warp(edge, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=oracle.BORDER_CONSTANT, max_value=65535)), tr
 
 
+@pytest.mark.parametrize("shape", [(9000, 70), (70, 9000), (16500, 66), (66, 16500)])
+def test_cv_mode_frames_beyond_8192_and_16384_pixels(gpu_vs, oracle, shape):
+    """the tuned path's "fits" test bounds the fixed-point table entries: 2^24 = 16384 pixels since round 6 (2^23 before: frames beyond 8192 pixels fell
+    to the per-pixel path -- still right, 2-4x slower); beyond 16384 the per-pixel path takes over inside one frame.  Both depths, both borders,
+    a rotation that moves the far end of the frame by tens of pixels."""
+    w, h = shape
+    rng = np.random.default_rng(w + h)
+    for bits in (8, 10):
+        mv = 255 if bits == 8 else 1023
+        src = rng.integers(0, mv + 1, (h, w, 3)).astype(np.uint8 if bits == 8 else np.uint16)
+        for border, tr in ((0, (0.001, -0.002, 3.25, -1.5)), (1, (-0.0005, 0.0011, -2.75, 4.5))):
+            oracle.set_threads(8)
+            try:
+                want = oracle.bgr_image_warp(src, oracle.Transform.of(*tr), oracle.WARP_BILINEAR_CV, border=border, max_value=mv)
+            finally:
+                oracle.set_threads(1)
+            got = gpu_vs.bgr_image_warp(src, gpu_vs.Transform.of(*tr), mode=gpu_vs.WARP_BILINEAR_CV, border=border, max_value=mv)
+            assert same(got, want), (shape, bits, border)
+
+
 def test_cv_mode_row_pitch_of_2_to_the_24_bytes_and_more(gpu_vs, oracle):
     """the interior fills address rows with 24-bit multiplies (row x pitch): a caller's pitch of 2^24 bytes or more (allowed: the API bounds the extents,
     not the pitch) must take the rim path instead of wrapping.  Three rows 2^24 + 4 bytes apart (8-bit) and 2^23 + 2 elements apart (16-bit

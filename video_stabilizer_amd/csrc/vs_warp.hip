@@ -1272,7 +1272,10 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const int bdA = bdp[0], bdB = bdp[nx - 1];
     const int XA = X0p[0], XB = X0p[ny - 1];
     const int YA = Y0p[0], YB = Y0p[ny - 1];
-    const int lim = 1 << 23;                                 // |X0|, |adelta| < 2^23 in 10-bit fixed point = 2^13 pixels each
+    // |X0|, |adelta| < 2^24 in 10-bit fixed point = 2^14 pixels each: the sums stay below 2^25 (a source coordinate below 2^15: saturate_cast<short> is
+    // never reached inside a tile that fits), and the window origin folded into the lane's delta (base4 << 8, |base4| < 4 * 89 * 2^14) stays inside 32 bits.
+    // (2^23 until round 6: frames beyond 8192 pixels fell off the tuned path, profiles/r06_cv_shape_sweep.txt)
+    const int lim = 1 << 24;
     // (one test over all eight corners, no short circuit: the eight scalar loads then issue together and are waited for once)
     bool fits = max(max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))), max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB)))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
@@ -1564,7 +1567,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     const int bdA = bdp[0], bdB = bdp[nx - 1];
     const int XA = X0p[0], XB = X0p[ny - 1];
     const int YA = Y0p[0], YB = Y0p[ny - 1];
-    const int lim = 1 << 23;                                 // (as in the 8-bit kernel: every entry within 2^13 pixels, the sums inside 32 bits)
+    const int lim = 1 << 24;                                 // (as in the 8-bit kernel: every entry within 2^14 pixels, the sums and base8 << 7 inside 32 bits)
     bool fits = max(max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))), max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB)))) < lim;
     const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
     const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
