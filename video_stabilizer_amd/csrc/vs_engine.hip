@@ -1420,6 +1420,9 @@ struct vs_stabilizer {
     hipEvent_t down_ev[2] = {nullptr, nullptr};
     hipStream_t down_stream = nullptr, up_stream = nullptr;
     void* pipe_in[2] = {nullptr, nullptr}; size_t pipe_in_bytes = 0;     // upload areas of a pipelined host batch
+    // PITCHED host frames travel as ONE linear copy of their whole span (gaps included) into a device area and are made dense by device-to-device
+    // 2-D copies: the HIP runtime never gets a 2-D copy out of pageable caller memory (profiles/r06_flake.md); dense frames: one linear copy as ever
+    void* span_in[2] = {nullptr, nullptr}; size_t span_in_bytes[2] = {0, 0};
     // device-resident clip batches: the warps of clip group g run on warp_stream under the alignment of group g + 1 (stab_run)
     hipStream_t warp_stream = nullptr;
     hipEvent_t warp_ev = nullptr;
@@ -1471,6 +1474,7 @@ void vs_stabilizer_destroy(vs_stabilizer* s) {
     if (s->batch_in) (void)hipFree(s->batch_in);
     for (void* q : s->batch_out) if (q) (void)hipFree(q);
     for (void* q : s->pipe_in) if (q) (void)hipFree(q);
+    for (void* q : s->span_in) if (q) (void)hipFree(q);
     for (hipEvent_t e : s->down_ev) if (e) (void)hipEventDestroy(e);
     if (s->warp_stream) { (void)vsi::retire_stream(s->warp_stream); (void)hipStreamDestroy(s->warp_stream); }
     if (s->warp_ev) (void)hipEventDestroy(s->warp_ev);
@@ -1661,9 +1665,20 @@ static int stab_run_host_pipelined(vs_stabilizer* s, const void* frames, size_t 
         hipError_t e = hipSetDevice(a->device);
         const uint8_t* src = (const uint8_t*)frames + (size_t)off * frame_stride * esz;
         if (e == hipSuccess && dense) e = hipMemcpyAsync(s->pipe_in[c & 1], src, fbytes * m, hipMemcpyHostToDevice, s->up_stream);
-        for (int i = 0; e == hipSuccess && !dense && i < m; i++)
-            e = hipMemcpy2DAsync((uint8_t*)s->pipe_in[c & 1] + (size_t)i * fbytes, (size_t)w * 3 * esz, src + (size_t)i * frame_stride * esz,
-                                 (size_t)stride * esz, (size_t)w * 3 * esz, h, hipMemcpyHostToDevice, s->up_stream);
+        if (e == hipSuccess && !dense) {                     // pitched: the chunk's span in one linear copy, then dense by device-to-device 2-D copies
+            const size_t span = ((size_t)(m - 1) * frame_stride + (size_t)(h - 1) * stride + (size_t)3 * w) * esz;
+            void*& area = s->span_in[c & 1];
+            if (s->span_in_bytes[c & 1] < span) {
+                if (area) (void)hipFree(area);
+                area = nullptr; s->span_in_bytes[c & 1] = 0;
+                e = vsi::dev_alloc(&area, span);
+                if (e == hipSuccess) s->span_in_bytes[c & 1] = span;
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(area, src, span, hipMemcpyHostToDevice, s->up_stream);
+            for (int i = 0; e == hipSuccess && i < m; i++)
+                e = hipMemcpy2DAsync((uint8_t*)s->pipe_in[c & 1] + (size_t)i * fbytes, (size_t)w * 3 * esz, (const uint8_t*)area + (size_t)i * frame_stride * esz,
+                                     (size_t)stride * esz, (size_t)w * 3 * esz, h, hipMemcpyDeviceToDevice, s->up_stream);
+        }
         return e != hipSuccess ? e : hipStreamSynchronize(s->up_stream);
     };
     const int n_chunks = (n + chunk - 1) / chunk;
@@ -1731,10 +1746,22 @@ static int stab_run_impl_unguarded(vs_stabilizer* s, const void* frames, size_t 
         if (stride == 3 * w && (n == 1 || frame_stride == (size_t)h * stride)) {
             VS_HIP(hipMemcpyAsync(s->batch_in, frames, fbytes * n, kind, st));   // dense input: one linear copy at the full link rate
         } else {
+            const uint8_t* from = (const uint8_t*)frames;
+            if (mem == VS_MEM_HOST) {                       // pitched host frames: the span in one linear copy (see span_in), 2-D copies on the device only
+                const size_t span = ((size_t)(n - 1) * frame_stride + (size_t)(h - 1) * stride + (size_t)3 * w) * esz;
+                if (s->span_in_bytes[0] < span) {
+                    if (s->span_in[0]) (void)hipFree(s->span_in[0]);
+                    s->span_in[0] = nullptr; s->span_in_bytes[0] = 0;
+                    VS_HIP(vsi::dev_alloc(&s->span_in[0], span));
+                    s->span_in_bytes[0] = span;
+                }
+                VS_HIP(hipMemcpyAsync(s->span_in[0], frames, span, hipMemcpyHostToDevice, st));
+                from = (const uint8_t*)s->span_in[0];
+            }
             for (int i = 0; i < n; i++)
                 VS_HIP(hipMemcpy2DAsync((uint8_t*)s->batch_in + (size_t)i * fbytes, (size_t)w * 3 * esz,
-                                        (const uint8_t*)frames + (size_t)i * frame_stride * esz, (size_t)stride * esz,
-                                        (size_t)w * 3 * esz, h, kind, st));
+                                        from + (size_t)i * frame_stride * esz, (size_t)stride * esz,
+                                        (size_t)w * 3 * esz, h, hipMemcpyDeviceToDevice, st));
         }
         dense = (const uint8_t*)s->batch_in;
     }
