@@ -3,7 +3,7 @@
 // grid_search_align.cpp:159-210 -- independent workers, nothing shared but a work counter).
 //
 //   vs_many_clips [--devices a,b,...|all] [--clips 64] [--frames 120] [--size 1920x1080] [--steps 3] [--min-width 256]
-//                 [--warp-mode separable|contracted|exact] [--exact] [--no-warp] [--no-rccl]
+//                 [--warp-mode separable|contracted|exact|cv] [--solver shared|exclusive] [--exact] [--no-warp] [--no-rccl]
 // (--warp-mode: the member of the Lanczos2 sampler family, default separable = bench.py's `value`; --exact = --warp-mode exact.
 //  VS_MANY_CLIPS_TEST_FAIL_SLOT=g in the environment makes slot g fail on purpose: the exit code must say so, tests/test_apps_gpu.py.)
 //
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     std::vector<int> devices = {0};
     int clips = 64, frames = 120, w = 1920, h = 1080, steps = 3, min_width = 256;
     bool warp = true, use_rccl = true;
-    std::string warp_mode = "separable";
+    std::string warp_mode = "separable", solver = "shared";
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -87,13 +87,15 @@ int main(int argc, char** argv) {
         else if (a == "--size") { if (!(v = next()) || std::sscanf(v, "%dx%d", &w, &h) != 2) { std::fprintf(stderr, "Error: --size WxH\n"); return 1; } }
         else if (a == "--exact") warp_mode = "exact";
         else if (a == "--warp-mode") { if (!(v = next())) return 1; warp_mode = v; if (warp_mode == "sep") warp_mode = "separable"; if (warp_mode == "fast") warp_mode = "contracted"; }
+        else if (a == "--solver") { if (!(v = next())) return 1; solver = v; }
         else if (a == "--no-warp") warp = false;
         else if (a == "--no-rccl") use_rccl = false;
         else { std::fprintf(stderr, "Usage: %s [--devices a,b,...|all] [--clips N] [--frames M] [--size WxH] [--steps K] [--min-width P] [--warp-mode separable|contracted|exact] [--no-warp] [--no-rccl]\n", argv[0]); return 1; }
     }
     const int G = (int)devices.size();
     if (clips < 1 || frames < 2 || steps < 1 || w < 64 || h < 64) { std::fprintf(stderr, "Error: bad sizes\n"); return 1; }
-    if (warp_mode != "separable" && warp_mode != "contracted" && warp_mode != "exact") { std::fprintf(stderr, "Error: --warp-mode separable|contracted|exact\n"); return 1; }
+    if (warp_mode != "separable" && warp_mode != "contracted" && warp_mode != "exact" && warp_mode != "cv") { std::fprintf(stderr, "Error: --warp-mode separable|contracted|exact|cv\n"); return 1; }
+    if (solver != "shared" && solver != "exclusive") { std::fprintf(stderr, "Error: --solver shared|exclusive\n"); return 1; }
     const char* fail_env = std::getenv("VS_MANY_CLIPS_TEST_FAIL_SLOT");
     const int fail_slot = fail_env ? std::atoi(fail_env) : -1;
     for (int d : devices) if (d < 0 || d >= vs_device_count()) { std::fprintf(stderr, "Error: no HIP device %d\n", d); return 1; }
@@ -142,7 +144,9 @@ int main(int argc, char** argv) {
 
     std::vector<SlotResult> res((size_t)G);
     Barrier barrier(G);
-    const int mode = warp_mode == "exact" ? VS_WARP_LANCZOS2 : (warp_mode == "contracted" ? VS_WARP_LANCZOS2_FAST : VS_WARP_LANCZOS2_SEP);
+    // (cv = the reference's own per-frame warp: cv::warpAffine's fixed-point bilinear, constant border, the measured transform as the forward map)
+    const int mode = warp_mode == "cv" ? VS_WARP_BILINEAR_CV : (warp_mode == "exact" ? VS_WARP_LANCZOS2 : (warp_mode == "contracted" ? VS_WARP_LANCZOS2_FAST : VS_WARP_LANCZOS2_SEP));
+    const int border = warp_mode == "cv" ? VS_BORDER_CONSTANT : VS_BORDER_CLAMP;
     auto slot = [&](int g) {
         SlotResult& r = res[(size_t)g];
         const int dev = devices[(size_t)g];
@@ -166,13 +170,13 @@ int main(int argc, char** argv) {
             vs_aligner_params_default(&p);
             p.pyramid_min_width = min_width;
             if (r.error.empty() && !(a = vs_aligner_create(&p, dev))) fail(std::string("vs_aligner_create: ") + vs_last_error());
-            if (r.error.empty() && warp) vs_aligner_set_batch_mode(a, VS_BATCH_SHARED);
+            if (r.error.empty() && warp && solver == "shared") vs_aligner_set_batch_mode(a, VS_BATCH_SHARED);
             if (r.error.empty() && hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) != hipSuccess) fail("hipStreamCreate");
         }
         auto step = [&]() -> int {
             const int good = vs_aligner_align_clips(a, in, fs, mine, frames, w, h, 3 * w, VS_FMT_BGR8, VS_MEM_DEVICE, nullptr, t.data(), st.data());
             if (good < 0) { fail(std::string("vs_aligner_align_clips: ") + vs_last_error()); return -1; }
-            if (warp && vs_bgr_image_warp_batch(in, fs, n, w, h, 3 * w, 3, 8, t.data(), mode, VS_BORDER_CLAMP, 255, out, fs, 3 * w, VS_MEM_DEVICE, ws) < 0) {
+            if (warp && vs_bgr_image_warp_batch(in, fs, n, w, h, 3 * w, 3, 8, t.data(), mode, border, 255, out, fs, 3 * w, VS_MEM_DEVICE, ws) < 0) {
                 fail(std::string("vs_bgr_image_warp_batch: ") + vs_last_error());
                 return -1;
             }
@@ -246,7 +250,8 @@ int main(int argc, char** argv) {
     std::printf("{\"program\": \"vs_many_clips\", \"host\": \"C++ threads, one per device slot\", \"devices\": [");
     for (int g = 0; g < G; g++) std::printf("%s%d", g ? ", " : "", devices[(size_t)g]);
     std::printf("], \"clips\": %d, \"frames_per_clip\": %d, \"width\": %d, \"height\": %d, \"steps\": %d, \"warp\": \"%s\", \"scaling\": \"strong\", ", clips, frames, w, h,
-                steps, warp ? (warp_mode == "exact" ? "lanczos2" : (warp_mode == "contracted" ? "lanczos2 contracted" : "lanczos2 separable")) : "none");
+                steps, warp ? (warp_mode == "cv" ? "cv::warpAffine fixed-point bilinear, constant border" : (warp_mode == "exact" ? "lanczos2" : (warp_mode == "contracted" ? "lanczos2 contracted" : "lanczos2 separable"))) : "none");
+    std::printf("\"solver\": \"%s\", ", solver.c_str());
     std::printf("\"value\": %.2f, \"unit\": \"aligned frames/s\", \"frames_per_s\": %.2f, \"seconds\": %.5f, \"per_slot_seconds\": [", total_aligned / slowest,
                 total_frames / slowest, slowest);
     for (int g = 0; g < G; g++) std::printf("%s%.5f", g ? ", " : "", res[(size_t)g].seconds);

@@ -8,7 +8,8 @@
  *   - extern "C", plain pointers and sizes.  Return: 0 = ok (or a documented positive value),
  *     negative = error; vs_last_error() returns a thread-local message.  No exceptions cross.
  *   - `mem` says where the caller's buffers live: VS_MEM_HOST (the library stages them through
- *     device memory and synchronises; used by parity tests and one-off calls) or VS_MEM_DEVICE
+ *     a pooled pinned mirror + device memory and synchronises: any alignment and pitch, pageable
+ *     memory is fine; used by parity tests and one-off calls) or VS_MEM_DEVICE
  *     (device pointers; the call only enqueues work on `stream` and returns -- no sync).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *   - Images are row-major; strides are in ELEMENTS.  "planar (tx,ty,c)" tables are laid out

@@ -280,6 +280,13 @@ def test_many_clips_cpp_harness_splits_clips_over_device_slots(gpu_vs, clip):
     assert two["aggregate"] == "host-side sums" and "more than once" in two["aggregate_note"]
     for j in (one, two):
         assert j["value"] > 0 and j["scaling"] == "strong" and j["seconds"] == max(j["per_slot_seconds"]) and j["warp"] == "lanczos2 separable"
+        assert j["solver"] == "shared"
+    # the reference's own per-frame warp (cv::warpAffine's fixed-point bilinear, constant border) in the same harness, either solver build: the frames
+    # aligned do not depend on the warp or the build
+    for solver in ("shared", "exclusive"):
+        cv = json.loads(run("vs_many_clips", "--clips", 5, "--frames", 12, "--size", "640x360", "--steps", 2, "--min-width", 64, "--devices", "0,0",
+                            "--warp-mode", "cv", "--solver", solver).strip().splitlines()[-1])
+        assert cv["aligned_per_step"] == 5 * 11 and cv["solver"] == solver and cv["warp"].startswith("cv::warpAffine") and cv["value"] > 0
     # eight slots -- the shape of the driver's 8-GPU run -- on the one device: BASELINE configs[3]'s 64 clips, 8 per slot, eight per-slot
     # seconds, one JSON line; eight RCCL ranks cannot share a GPU, so the report falls back to the host-side sums and says so
     raw8 = run("vs_many_clips", "--clips", 64, "--frames", 3, "--size", "640x360", "--steps", 2, "--min-width", 64, "--devices", "0,0,0,0,0,0,0,0")
