@@ -983,6 +983,11 @@ def main():
                     out["roofline"]["traffic_source"] = how
                 else:
                     out["roofline"]["traffic_source"] += "; a live measurement was attempted and failed: " + how
+                if default_leg:
+                    # ... and of the reference's own warp (the `default_warp` leg's kernel), same launch shape
+                    live_cv, how_cv = measure_traffic_live(aw.W, aw.H, n * n_clips, aw.bits, mode="bilinear_cv")
+                    out["default_warp"]["roofline"]["traffic"] = live_cv
+                    out["default_warp"]["roofline"]["traffic_source"] = how_cv
 
     # ---- parity gate + CPU baseline (rank 0 of a one-GPU run; the oracle is the checker, never the thing measured) ----------
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -63,6 +63,9 @@ def test_bench_line_contract(gpu_vs):
     bm = dw["by_solver_mode"]
     assert set(bm) == {"shared", "exclusive"} and dw["value"] == max(bm.values()) == bm[dw["solver"]]
     assert dw["roofline"]["bytes_per_launch"] == 1920 * 1080 * 3 * 2 * 8 and abs(dw["roofline"]["frac"] - dw["roofline"]["achieved"] / 8000.0) < 1e-3
+    # ... its HBM-side bytes measured in the run too (the kernel-name filter of the counter passes takes vs_k_bgr_warp_cv_c3: ADVICE r05)
+    assert "measured in this run" in dw["roofline"]["traffic_source"], dw["roofline"]["traffic_source"]
+    assert 0.95 * dw["roofline"]["bytes_per_launch"] <= dw["roofline"]["traffic"] <= 1.15 * dw["roofline"]["bytes_per_launch"]
     # the record's tail: {mode: [us per 4K frame, fraction of the HBM peak]} as the LAST key of the line, and the `value` mode at 4K inside `roofline`
     assert list(j)[-1] == "roofline_4k_summary" and j["scaling_curve_measured"] is False
     sm = j["roofline_4k_summary"]

@@ -20,7 +20,7 @@ for spec in "sep 8" "fast 8" "lanczos2 8" "cv 8" "cv 16" "bilinear 8" "bilinear 
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/r4k_$1_$2 -- python3 tools/warp_bench.py --mode $1 --frames 32 --reps 20 --bits $2 > $O/r4k_$1_$2.log 2>&1
   f="$(find $O/r4k_$1_$2 -name '*kernel_stats.csv' | head -1)"
   [ -n "$f" ] && cp "$f" $O/keep/r06_roofline4k_$1_$2bit_kernel_stats.csv
-  tail -1 $O/r4k_$1_$2.log > $O/keep/r06_roofline4k_$1_$2bit_events.json
+  grep '^{"kernel"' $O/r4k_$1_$2.log | tail -1 > $O/keep/r06_roofline4k_$1_$2bit_events.json
   echo "roofline_4k stats $1 $2-bit done"
 done
 # (d) traffic + instruction counters of the fixed-point bilinear (8- and 10-bit), FETCH / WRITE on their own
@@ -62,7 +62,8 @@ with open(os.path.join(O, "keep", "r06_roofline4k.md"), "w") as out:
         e = ev.get(tag, {})
         out.write("| %s | `%s` | %d | %.0f | %.1f | %.4f | %s, %s |\n" % (tag, name, calls, avg, gbps, frac, e.get("us_per_frame_median"), e.get("frac_of_8TBps")))
     out.write("\nbytes = W*H*3*(in+out) per frame x 32 (SURVEY 8d); the stats rows pool the warm-up launches of tools/warp_bench.py with the timed ones (same shape).\n")
-    out.write("The fixed-point bilinear's launch is preceded by vs_k_cv_tables (its own row in the stats files); the HIP-event figure includes it.\n\n")
+    out.write("The fixed-point bilinear's launch is preceded by vs_k_cv_tables (its own row in the stats files: ~4 us per 32-frame launch); the HIP-event figure brackets the\n"
+              "whole call -- table kernel, the dependent-launch gap, warp kernel -- and is therefore ~3 % above the warp kernel's own AverageNs (tools/cv_kernel_vs_events.sh).\n\n")
     for bits in (8, 16):
         fz, wz = pmc("pmcF_cv%d" % bits, "FETCH_SIZE", 32), pmc("pmcW_cv%d" % bits, "WRITE_SIZE", 32)
         iv, wv = pmc("pmcA_cv%d" % bits, "SQ_INSTS_VALU", 4), pmc("pmcA_cv%d" % bits, "SQ_WAVES", 4)

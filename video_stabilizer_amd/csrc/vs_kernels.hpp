@@ -60,7 +60,7 @@ hipError_t bgr_warp_cv_generic(const void* src, int w, int h, int src_stride, in
 // kernel in front of the warp launch on the same stream (cv::warpAffine's adelta / bdelta / row origins, made once per frame as OpenCV makes them)
 // minv_host (n_frames x 6 doubles on the host) may stand in for minv_dev when n_frames <= kCvInlineFrames: the matrices then travel as kernel arguments
 size_t bgr_warp_cv_table_ints(int bits, Roi roi);
-constexpr int kCvInlineFrames = 4;
+constexpr int kCvInlineFrames = 64;          // 3 KiB of kernel arguments
 hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bits, const double* minv_dev, const double* minv_host, int* tab_dev, int border, int max_value,
                           void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi, hipStream_t s);
 // host side of the tuned kernel's tile prologue: per frame {lo_x, hi_x, lo_y, hi_y} from the kernel parameters {A, B, TX, TY}, for the

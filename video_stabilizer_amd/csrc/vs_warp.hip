@@ -1176,25 +1176,18 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 // The coordinate tables of a launch: per frame adelta[tab_w] | bdelta[tab_w] | X0[tab_h] | Y0[tab_h] (ints), tab_w / tab_h = the output window
 // rounded up to whole tiles; entries beyond the window repeat its last column / row.  One thread per entry: each is ONE double-precision
 // evaluation exactly as OpenCV's warpAffine makes it once per call (cvRound(m x 1024), cvRound((m y + t) 1024) + round_delta).
-// (calls of up to vsk::kCvInlineFrames frames hand their matrices to this kernel BY VALUE, as kernel arguments: no upload stands between the host's
-// numbers and the tables -- the per-frame drop-in call and the small batches of the parity tests; larger batches read them from the parameter ring)
+// (calls of up to vsk::kCvInlineFrames frames hand their matrices to this kernel BY VALUE, as kernel arguments -- 48 bytes per frame: no upload stands between
+// the host's numbers and the tables, and the call is two stream operations (tables, warp) instead of three; larger batches read them from the parameter ring)
 struct CvMatrices { double m[6 * vsk::kCvInlineFrames]; };
 template <bool INLINE>
 __global__ __launch_bounds__(256) void vs_k_cv_tables(const double* __restrict__ minv, CvMatrices inl, int* __restrict__ tab, int tab_w, int tab_h, vsk::Roi roi) {
     const int per = 2 * (tab_w + tab_h);
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= per) return;
+    // (the by-value matrices sit in the kernel-argument segment: indexing them by the frame is a scalar load at a computed offset)
     double Mv[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) Mv[k] = INLINE ? 0.0 : minv[6 * (size_t)blockIdx.y + k];
-    if (INLINE) {
-#pragma unroll
-        for (int f = 0; f < vsk::kCvInlineFrames; f++)           // (uniform select: kernel arguments cannot be indexed dynamically without scratch)
-            if ((int)blockIdx.y == f) {
-#pragma unroll
-                for (int k = 0; k < 6; k++) Mv[k] = inl.m[6 * f + k];
-            }
-    }
+    for (int k = 0; k < 6; k++) Mv[k] = INLINE ? inl.m[6 * blockIdx.y + k] : minv[6 * (size_t)blockIdx.y + k];
     const double* M = Mv;
     int v;
     if (i < 2 * tab_w) {
