@@ -740,13 +740,18 @@ def main():
         # collectives run over and the strong-scaling leg's clip split; two ranks on ONE physical device while the node shows a device for each
         # is a launch error (LOCAL_RANK ignored, a bad visible-devices mask) and ends the job with exit code 5 on every rank
         props = torch.cuda.get_device_properties(local_rank)
+        # (the key two ranks must not share is host + device INDEX: with every device visible to every rank -- the launch the contract describes -- ranks
+        # differ by index; a launcher that shows each rank one device makes them all index 0, and then there are fewer visible devices than ranks and the
+        # check below does not apply.  The uuid / PCI id ride along for the reader only: a runtime that reports the same uuid for every device must not
+        # be able to end the job)
         me = {"rank": rank, "local_rank": local_rank, "device": local_rank, "device_name": props.name,
-              "device_key": "%s/%s" % (socket.gethostname(), getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or local_rank),
+              "device_key": "%s/device%d" % (socket.gethostname(), local_rank),
+              "device_id": str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or ""),
               "backend": backend_used, "rccl_ranks": dist.get_world_size() if backend_used == "nccl" else 0,
               "c4_clips": vsdist.shard_clips(args.c4_clips, rank, world)}
         everyone = vsdist.roll_call(me)
         sys.stderr.write("bench.py rank %d/%d: device %d (%s, %s), report collectives over %s (%d RCCL ranks), strong-leg clips %s; no 1 -> 8 GPU curve has "
-                         "been measured in rounds 1-6\n" % (rank, world, local_rank, props.name, me["device_key"], backend_used, me["rccl_ranks"],
+                         "been measured in rounds 1-6\n" % (rank, world, local_rank, props.name, me["device_key"] + " " + me["device_id"], backend_used, me["rccl_ranks"],
                                                             me["c4_clips"] if len(me["c4_clips"]) <= 8 else "%d clips" % len(me["c4_clips"])))
         sys.stderr.flush()
         clash = vsdist.shared_devices(everyone, torch.cuda.device_count()) if args.device < 0 else []
@@ -908,7 +913,7 @@ def main():
         out = {
             "metric": "aligned frames/sec", "value": round((total_good if not wl["stabilizer"] else total_frames) / dt, 2), "unit": "frames/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
-            "ranks": ([{k: e[k] for k in ("rank", "device", "device_key", "backend")} for e in everyone] if dist is not None else None),
+            "ranks": ([{k: e[k] for k in ("rank", "device", "device_key", "device_id", "backend")} for e in everyone] if dist is not None else None),
             "scaling_curve_measured": False,
             "dist_backend": (backend_used if dist is not None else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
