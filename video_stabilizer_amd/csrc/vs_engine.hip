@@ -273,14 +273,19 @@ constexpr int kGnThreads = VS_NT_SMALL, kGnVirt = VS_NT_SMALL;
 // per-pair global scratch (introselect_block_g), up to 128 * 256 tiles.
 #if VS_NT_SMALL == 512
 namespace nt256v {
-constexpr int kGnThreads = 256, kGnVirt = 512;
+// (experiment, -DVS_SHARED_THREADS=512: the co-resident build with all 512 hardware threads at the same 128-VGPR cap -- two waves per SIMD of 128
+// registers each instead of one; profiles/r06_shared_solver_512.txt)
+#ifndef VS_SHARED_THREADS
+#define VS_SHARED_THREADS 256
+#endif
+constexpr int kGnThreads = VS_SHARED_THREADS, kGnVirt = 512;
 #ifndef VS_NT256_MINWAVES
 #define VS_NT256_MINWAVES 4
 #endif
 #ifdef VS_NT256_NUM_VGPR
-#define VS_GN_FUSED_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VS_NT256_NUM_VGPR)))
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(VS_SHARED_THREADS) __attribute__((amdgpu_num_vgpr(VS_NT256_NUM_VGPR)))
 #else
-#define VS_GN_FUSED_BOUNDS __launch_bounds__(256, VS_NT256_MINWAVES)
+#define VS_GN_FUSED_BOUNDS __launch_bounds__(VS_SHARED_THREADS, VS_NT256_MINWAVES)
 #endif
 #include "vs_align_kernels.inc"
 #undef VS_GN_FUSED_BOUNDS
@@ -880,7 +885,11 @@ int vs_aligner::chunk_begin(const void* frames, size_t frame_stride, int n, int 
 #else
             const auto kernel = small_wg ? nt512::vs_k_align_pairs : nt1024::vs_k_align_pairs;
 #endif
-            const int kthreads = cores ? 256 : (small_wg ? nt512::kGnThreads : nt1024::kGnThreads);
+#ifdef VS_HAVE_NT256V
+            const int kthreads = cores ? nt256v::kGnThreads : (small_wg ? nt512::kGnThreads : nt1024::kGnThreads);
+#else
+            const int kthreads = small_wg ? nt512::kGnThreads : nt1024::kGnThreads;
+#endif
             {   // The limit belongs to (kernel, device) and is shared by every handle of the process: it is only ever raised,
                 // and only when a launch needs more than was granted before (the call costs microseconds of host time).
                 static std::mutex dyn_mu;
