@@ -28,6 +28,14 @@ synchronize -- runs three times back to back: `value` / `ms_per_step` are the ME
 The JSON line also carries
   roofline      the dominant kernel of the timed region (bgr_image_warp): algorithmic bytes / mean launch time, HIP
                 events on the launch stream, against the 8 TB/s HBM peak; `traffic` scaled from the committed PMC passes
+  default_warp  (in the headline's object and in c3) the reference's OWN pipeline on the workload: align + cv::warpAffine's fixed-point bilinear
+                (VS_WARP_BILINEAR_CV), constant border, the measured transform as the forward map (stabilizer.cpp:97-99); both solver modes,
+                its own in-step roofline (+ live traffic) and stage table; never `value`
+  roofline.at_4k / roofline_4k_summary
+                the `value` warp mode at 4K inside the headline's roofline object; {mode: [us per 4K frame, fraction of 8 TB/s]} as the LAST
+                key of the line (a record that keeps only the tail still shows the north star's operating point)
+  ranks         (N > 1) the roll call made before anything is timed: every rank's device, backend and clip split; two ranks on one
+                device while the node shows a device for each end the job (exit code 5); "scaling_curve_measured": false
   roofline_4k   the same kernel where the north star quotes it: 32 x 4K frames per launch, isolated, after the timed
                 region (exact and contracted arithmetic), with the VALU / LDS busy fractions of the committed PMC passes --
                 the kernel is VALU-issue-bound, the HBM fraction is what that leaves
@@ -354,7 +362,7 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR, 10-bit)"}
             continue
         if name == "bilinear_cv_10bit":
-            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3_u16<clamp> (word tile, v_dot2_u32_u16 taps while the samples stay below 2^14)", "bound": "hbm",
+            out[name] = {"kernel": "vs_k_cv_tables + vs_k_bgr_warp_cv_c3_u16<clamp> (word tile, v_dot2_u32_u16 taps while the samples stay below 2^14)", "bound": "hbm",
                          "binding": "hbm + valu", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                          "traffic": None, "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR_CV on 16-bit containers: OpenCV's float-weight form)"}
@@ -362,10 +370,11 @@ def roofline_4k(torch, capi, dev, stream, frames=32, reps=7):
         if name == "bilinear_cv":
             # the stabilizer's DEFAULT sampler = the reference's own warp (cv::warpAffine INTER_LINEAR, stabilizer.cpp:97-99 -> imgproc.cpp:472):
             # OpenCV's fixed-point bilinear restated, integer work end to end; vector issue and the memory side together (profiles/r05_warp_cv.md)
-            pc, _ = load_profile("r05_pmc_bilinear_cv.json")
-            out[name] = {"kernel": "vs_k_bgr_warp_cv_c3<clamp> (byte tile, v_dot2_u32_u16 taps)", "bound": "hbm", "binding": "valu issue + memory: ~36 integer-class "
-                         "vector instructions per pixel row of a wave, and 56 MB per 4K frame with the tile halo = 5.4 TB/s of the 6.3 TB/s copy ceiling "
-                         "(profiles/r05_warp_cv.md)", "valu_instr_per_px": pc.get("valu_instr_per_px"),
+            pc, _ = load_profile("r06_pmc_bilinear_cv.json", "r05_pmc_bilinear_cv.json")
+            out[name] = {"kernel": "vs_k_cv_tables + vs_k_bgr_warp_cv_c3<clamp> (OpenCV's coordinate tables once per frame; byte tile, v_dot2_u32_u16 taps)", "bound": "hbm",
+                         "binding": "valu issue (~34 integer-class vector instructions per 64 pixels, ~80 % of a SIMD's issue time) and the memory side (56 MB per 4K frame through "
+                         "L2 with the tile halo) together; the events bracket the CALL (table kernel + dependent-launch gap + warp kernel): the warp kernel alone is ~3 % "
+                         "faster (profiles/r06_roofline4k.md, r06_warp_cv.md)", "valu_instr_per_px": pc.get("valu_instr_per_px"),
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                          "us_per_frame": round(1e3 * med / frames, 2), "frames_per_launch": frames, "bytes_per_launch": nbytes,
                          "parity": "np.array_equal with the CPU restatement (VSO_WARP_BILINEAR_CV: OpenCV 4.x's published fixed-point path, parity "
