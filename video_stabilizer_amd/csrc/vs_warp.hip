@@ -1496,203 +1496,9 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     }
 }
 
-#ifndef VS_WARP_CV_PAIR
-#define VS_WARP_CV_PAIR 0                // experiment: 128 x 64 output tiles, two 64-column halves per 512-thread workgroup on ONE staged window
-#endif
-#if VS_WARP_CV_PAIR
-// The 8-bit kernel above with the tile doubled sideways: eight waves, waves 0..3 sample the left 64 columns, waves 4..7 the right ones, from one window of
-// 144 x 72 staged pixels (halo 1.11x instead of 1.18x; 43 KB of LDS, 3 workgroups = 24 waves per CU as before).  Per-wave sampler, tables, stores: unchanged.
-// Interior fill: a wave-instruction stages groups 0..31 of TWO rows (lanes 0..31 / 32..63), slots sixteen rows apart; the four tail groups 32..35 of
-// sixteen rows at a time go to waves 0..4.
-constexpr int CVP_TW = 128, CVP_WSW = 144, CVP_RS = CVP_WSW + 8, CVP_G = CVP_WSW / 4;
-constexpr int CVP_MAIN_SLOTS = (CV_WS_H + 15) / 16, CVP_TAIL_WAVES = (CV_WS_H + 15) / 16, CVP_RIM_SLOTS = (CV_WS_H / 4 * CVP_G + 127) / 128;
-static_assert(CVP_TAIL_WAVES <= 8 && CV_WS_H / 4 * CVP_G <= 1100, "tail instructions fit the eight waves; fill_item_p's p / 36 is exact below 1100");
-__device__ __forceinline__ FillItem fill_item_p(int lane, int slot) {           // slot = wave + 8 s: sixteen 4-row items per wave slot
-    const int p = (lane >> 2) + 16 * slot;
-    const int rq = (p * 1821) >> 16;                         // p / 36
-    return FillItem{4 * rq + (lane & 3), p - CVP_G * rq};
-}
-template <int BORDER>
-__global__ __launch_bounds__(512, 6) void vs_k_bgr_warp_cv_c3_pair(const uint8_t* __restrict__ src, int w, int h, int src_stride,
-                                                                  const int* __restrict__ tab, int tab_w, int tab_h, uint8_t* __restrict__ dst, int dst_stride,
-                                                                  size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
-                                                                  int chunk, vsk::Roi roi) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV_WS_H * CVP_RS];
-    const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
-    const int frame = blockIdx.y;
-    src += (size_t)frame * src_fs;
-    dst += (size_t)frame * dst_fs;
-    const int lane = threadIdx.x & 63, wv8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), half = wv8 >> 2, wv = wv8 & 3;
-    const int tyi = tiles_x == 1 ? tl : (int)__umulhi((uint32_t)tl, tiles_x_magic);
-    const int txi = tl - tyi * tiles_x;
-    const int x0 = txi * CVP_TW, y0 = tyi * CV_TH;
-    const int nx = min(CVP_TW, roi.w - x0), ny = min(CV_TH, roi.h - y0);           // live columns / rows of this tile (>= 1)
-    const int xh0 = x0 + 64 * half, x = xh0 + lane;                               // this wave's half of the tile, this lane's column
-    const int* __restrict__ const adp = tab + (size_t)frame * (size_t)(2 * (tab_w + tab_h)) + x0;
-    const int* __restrict__ const bdp = adp + tab_w;
-    const int* __restrict__ const X0p = adp + (2 * tab_w - x0) + y0;
-    const int* __restrict__ const Y0p = X0p + tab_h;
-    const int ad = adp[64 * half + lane], bd = bdp[64 * half + lane];
-    const int adA = adp[0], adB = adp[nx - 1];
-    const int bdA = bdp[0], bdB = bdp[nx - 1];
-    const int XA = X0p[0], XB = X0p[ny - 1];
-    const int YA = Y0p[0], YB = Y0p[ny - 1];
-    const int lim = 1 << 24;
-    bool fits = max(max(max(abs(adA), abs(adB)), max(abs(bdA), abs(bdB))), max(max(abs(XA), abs(XB)), max(abs(YA), abs(YB)))) < lim;
-    const int mnX = min(XA, XB) + min(adA, adB), mxX = max(XA, XB) + max(adA, adB);
-    const int mnY = min(YA, YB) + min(bdA, bdB), mxY = max(YA, YB) + max(bdA, bdB);
-    int sx_lo = 0, sy_lo = 0, rows = 0, groups = 0;
-    if (fits) {
-        sx_lo = (mnX >> 10) & ~3;
-        const int sx_hi = (mxX >> 10) + 1;
-        sy_lo = mnY >> 10;
-        const int sy_hi = (mxY >> 10) + 1;
-        rows = sy_hi - sy_lo + 1;
-        groups = (sx_hi - sx_lo + 4) >> 2;
-        fits = groups <= CVP_G && rows <= CV_WS_H;
-    }
-    const bool src_aligned = ((((uintptr_t)src) | (uintptr_t)src_stride) & 3) == 0;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const bool interior = fits && src_aligned && sx_lo >= 0 && sx_lo + 4 * groups <= w && sy_lo >= 0 && sy_lo + rows <= h &&
-                          (size_t)h * (size_t)src_stride < (1ull << 32) && src_stride < (1 << 24);
-    auto format = [](const u32x3 q) -> u32x4 {               // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3  ->  four dwords B G R 0
-        u32x4 px;
-        px.x = q.x & 0x00ffffffu;
-        px.y = __builtin_amdgcn_perm(q.y, q.x, 0x0c050403u);
-        px.z = __builtin_amdgcn_perm(q.z, q.y, 0x0c040302u);
-        px.w = q.z >> 8;
-        return px;
-    };
-    if (interior) {
-        const uint8_t* base = src + ((size_t)sy_lo * src_stride + (size_t)sx_lo * 3);
-        const uint32_t g = (uint32_t)lane & 31u, row0 = 2u * (uint32_t)wv8 + ((uint32_t)lane >> 5);
-        const bool col_live = (int)g < groups;
-        const uint32_t goff = __umul24(row0, (uint32_t)src_stride) + 12u * g;
-        uint32_t* const tp = tile_raw + (row0 * (uint32_t)CVP_RS + 4u * g);
-        u32x3 q[CVP_MAIN_SLOTS], qt;
-        bool live[CVP_MAIN_SLOTS];
-#pragma unroll
-        for (int s = 0; s < CVP_MAIN_SLOTS; s++) {            // every load is issued before the first tile write
-            live[s] = col_live && (int)row0 < rows - 16 * s;
-            if (live[s]) q[s] = *(const u32x3*)(base + (size_t)(16 * s) * (size_t)src_stride + goff);
-        }
-        const uint32_t trow = 16u * (uint32_t)wv8 + ((uint32_t)lane >> 2), tg = 32u + ((uint32_t)lane & 3u);
-        const bool tlive = wv8 < CVP_TAIL_WAVES && (int)trow < rows && (int)tg < groups;
-        if (tlive) qt = *(const u32x3*)(base + (__umul24(trow, (uint32_t)src_stride) + 12u * tg));
-#pragma unroll
-        for (int s = 0; s < CVP_MAIN_SLOTS; s++) {
-            if (!live[s]) continue;
-            VS_BOUNDS_CHECK((int)((row0 + 16u * s) * CVP_RS + 4u * g) + 3, CV_WS_H * CVP_RS, 221);
-            *(u32x4*)(tp + 16 * s * CVP_RS) = format(q[s]);
-        }
-        if (tlive) {
-            VS_BOUNDS_CHECK((int)(trow * CVP_RS + 4u * tg) + 3, CV_WS_H * CVP_RS, 222);
-            *(u32x4*)(tile_raw + (trow * (uint32_t)CVP_RS + 4u * tg)) = format(qt);
-        }
-    } else if (fits) {
-        u32x3 q[CVP_RIM_SLOTS];
-        FillItem it[CVP_RIM_SLOTS];
-        bool live[CVP_RIM_SLOTS], direct[CVP_RIM_SLOTS];
-#pragma unroll
-        for (int s = 0; s < CVP_RIM_SLOTS; s++) {
-            it[s] = fill_item_p(lane, wv8 + 8 * s);
-            live[s] = it[s].row < rows && it[s].g < groups;
-            const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
-            direct[s] = live[s] && src_aligned && sx >= 0 && sx + 3 < w && sy >= 0 && sy < h;
-            if (direct[s]) q[s] = *(const u32x3*)(src + (size_t)sy * src_stride + (size_t)sx * 3);
-        }
-#pragma unroll
-        for (int s = 0; s < CVP_RIM_SLOTS; s++) {
-            if (!live[s]) continue;
-            u32x4 px;
-            if (direct[s]) px = format(q[s]);
-            else {                                              // the frame's rim, an unaligned frame: pixel by pixel, the border rule applied here
-                const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
-                uint32_t d[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int pxi = sx + k;
-                    if (BORDER == 1 && (sy < 0 || sy >= h || pxi < 0 || pxi >= w)) d[k] = 0u;
-                    else {
-                        const uint8_t* qq = src + (size_t)clampi(sy, 0, h - 1) * src_stride + (size_t)clampi(pxi, 0, w - 1) * 3;
-                        d[k] = (uint32_t)qq[0] | ((uint32_t)qq[1] << 8) | ((uint32_t)qq[2] << 16);
-                    }
-                }
-                px = u32x4{d[0], d[1], d[2], d[3]};
-            }
-            VS_BOUNDS_CHECK(it[s].row * CVP_RS + 4 * it[s].g + 3, CV_WS_H * CVP_RS, 223);
-            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * CVP_RS + 4 * it[s].g, CV_WS_H * CVP_RS - 3)) = px;
-        }
-    }
-    __syncthreads();
-
-    const int yw = y0 + wv * CV_RPW;                         // first row of this wave
-    if (xh0 >= roi.w || yw >= roi.h) return;                 // wave-uniform (behind the barrier)
-    const int nxh = min(WT_W, roi.w - xh0);                  // live columns of this half
-    const int m = lane & 3;
-    const bool rows_aligned = ((((uintptr_t)dst) | (uintptr_t)dst_stride) & 3) == 0;
-    const bool lane_in = x < roi.w, quad_in = (x | 3) < roi.w;
-    const uint32_t sel = quad_sel(m);
-    const uint32_t loff = (uint32_t)(x & ~3) * 3u + 4u * (uint32_t)m;
-    // (the window's origin goes into BOTH lane deltas -- x into adw, y into bdw: the relative coordinates then stay below 2^18 whatever the frame's size and
-    // the row pitch of the tile; the 64-column kernel folds both parts into adw, which with this kernel's 152-dword pitch would overflow beyond row ~13 800)
-    const uint32_t adw = (uint32_t)ad - ((uint32_t)sx_lo << 10), bdw = (uint32_t)bd - ((uint32_t)sy_lo << 10);
-    auto sample = [&](uint32_t Xs, uint32_t Ys) -> uint32_t {
-        const uint32_t fx = (Xs >> 5) & 31u, fy32 = Ys & 0x3e0u;
-        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * CVP_RS) + (((int)Xs >> 8) & ~3), 4 * (CV_WS_H * CVP_RS - (CVP_RS + 2)), 224);
-        const __attribute__((address_space(3))) uint32_t* t = (const __attribute__((address_space(3))) uint32_t*)((const __attribute__((address_space(3))) char*)tile_raw + off);
-        const uint32_t p00 = t[0], p01 = t[1], p10 = t[CVP_RS], p11 = t[CVP_RS + 1];
-        const uint32_t apair = fx * 0x1fffeu + 64u;
-        const uint32_t wb = pk_mul_lo_u16_lo(apair, fy32), wt = pk_mul_lo_u16_lo_sat(apair, 1024u - fy32);
-        constexpr uint32_t kHalf = 1u << 15;
-        uint32_t o[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const uint32_t selc = 0x0c040c00u + 0x00010001u * (uint32_t)c;
-            const uint32_t top = __builtin_amdgcn_perm(p01, p00, selc), bot = __builtin_amdgcn_perm(p11, p10, selc);
-            o[c] = udot2(bot, wb, udot2(top, wt, kHalf));
-        }
-        return __builtin_amdgcn_perm(o[2], __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u), 0x0c060100u);
-    };
-    if (fits && rows_aligned && nxh == WT_W && yw + CV_RPW <= roi.h && (size_t)roi.h * (size_t)dst_stride < (1ull << 32)) {
-        uint32_t roff = (uint32_t)yw * (uint32_t)dst_stride + loff;
-#pragma unroll 1
-        for (int k0 = 0; k0 < CV_RPW; k0 += CV_RBK) {
-            uint32_t d[CV_RBK];
-#pragma unroll
-            for (int k = 0; k < CV_RBK; k++)
-                d[k] = quad_pack_bgr(sample((uint32_t)X0p[wv * CV_RPW + k0 + k] + adw, (uint32_t)Y0p[wv * CV_RPW + k0 + k] + bdw), sel);
-            if (m < 3) {
-#pragma unroll
-                for (int k = 0; k < CV_RBK; k++, roff += (uint32_t)dst_stride) VS_STORE32((uint32_t*)(dst + roff), d[k]);
-            } else roff += (uint32_t)CV_RBK * (uint32_t)dst_stride;
-        }
-        return;
-    }
-#pragma unroll 1
-    for (int k = 0; k < CV_RPW; k++) {
-        const int y = yw + k;
-        if (y >= roi.h) break;
-        const uint32_t Xs = (uint32_t)X0p[wv * CV_RPW + k] + (uint32_t)ad, Ys = (uint32_t)Y0p[wv * CV_RPW + k] + (uint32_t)bd;
-        uint32_t p = 0u;
-        if (!fits) {
-            uint32_t o[3] = {0u, 0u, 0u};
-            if (lane_in) cv_pixel_global<BORDER>(src, w, h, src_stride, (int)Xs >> 5, (int)Ys >> 5, o);
-            p = o[0] | (o[1] << 8) | (o[2] << 16);
-        } else p = sample((uint32_t)X0p[wv * CV_RPW + k] + adw, (uint32_t)Y0p[wv * CV_RPW + k] + bdw);
-        const uint32_t d = quad_pack_bgr(p, sel);
-        uint8_t* orow = dst + (size_t)y * dst_stride;
-        if (rows_aligned && quad_in) {
-            if (m < 3) VS_STORE32((uint32_t*)(orow + loff), d);
-        } else if (lane_in) {
-            orow[(size_t)x * 3] = (uint8_t)p;
-            orow[(size_t)x * 3 + 1] = (uint8_t)(p >> 8);
-            orow[(size_t)x * 3 + 2] = (uint8_t)(p >> 16);
-        }
-    }
-}
-#endif
+// (Measured and dropped, round 6 -- commit a01891c, profiles/r06_warp_cv.md section 4: 128 x 64 output tiles, two 64-column halves per 512-thread workgroup on ONE
+// staged window of 144 x 72 pixels -- halo 1.11x instead of 1.18x, 43 KB of LDS, 24 waves per CU as before, the per-wave sampler unchanged.  Bit-identical,
+// 11.7 us per 4K frame against 10.9: the wider workgroup's fill (eight waves behind one barrier) is covered worse by three workgroups per CU than by six.)
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // VS_WARP_BILINEAR_CV on interleaved 16-bit containers (10 / 12 / 16-bit BGR): OpenCV's remapBilinear<Cast<float, ushort>> -- the same
@@ -2032,8 +1838,7 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
 }
 
 // ints of table per frame for (bits, window): what bgr_warp_cv_c3's caller reserves (n_frames times) for `tab_dev`
-// (output tile width of the 8-bit kernel: 64, or 128 in the pair-kernel experiment)
-static inline int cv_tile_w(int bits) { return VS_WARP_CV_PAIR && bits == 8 ? 128 : WT_W; }
+static inline int cv_tile_w(int) { return WT_W; }           // (output tile width; the 128-wide experiment of round 6 varied it)
 size_t bgr_warp_cv_table_ints(int bits, Roi roi) {
     const int th = bits == 16 ? CV16_TH : CV_TH, twid = cv_tile_w(bits);
     const size_t tw = (size_t)((roi.w + twid - 1) / twid) * twid, tt = (size_t)((roi.h + th - 1) / th) * th;
@@ -2074,15 +1879,6 @@ hipError_t bgr_warp_cv_c3(const void* src, int w, int h, int src_stride, int bit
                 hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_u16<1>), grid, block, 0, s, (const uint16_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint16_t*)dp, dst_stride, src_fs, dst_fs,
                                    tiles_x, magic, (int)tpf, chunk, max_value, roi);
         } else {
-#if VS_WARP_CV_PAIR
-            if (border == 0)
-                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_pair<0>), grid, dim3(512), 0, s, (const uint8_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint8_t*)dp, dst_stride, src_fs, dst_fs,
-                                   tiles_x, magic, (int)tpf, chunk, roi);
-            else
-                hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3_pair<1>), grid, dim3(512), 0, s, (const uint8_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint8_t*)dp, dst_stride, src_fs, dst_fs,
-                                   tiles_x, magic, (int)tpf, chunk, roi);
-            continue;
-#endif
             if (border == 0)
                 hipLaunchKernelGGL((vs_k_bgr_warp_cv_c3<0>), grid, block, 0, s, (const uint8_t*)sp, w, h, src_stride, tp, tab_w, tab_h, (uint8_t*)dp, dst_stride, src_fs, dst_fs,
                                    tiles_x, magic, (int)tpf, chunk, roi);
