@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
 // matrix inverted in double precision, source coordinates in 1/32 pixel from integer adds (AB_BITS 10, INTER_BITS 5), four 15-bit integer
 // weights 32 a b (a, b in 0..32), result = (sum + 2^14) >> 15.  Integer work end to end:
 //   * one workgroup = one 64 x 64 output tile; the source footprint goes into LDS as BYTES, one dword {B,G,R,0} per pixel (the byte tile of
-//     the float bilinear kernel: 26 KB, 6 workgroups per CU), borders resolved in the copy;
+//     the float bilinear kernel: 23 KB at its own 80-dword pitch, 7 workgroups per CU), borders resolved in the copy;
 //   * per tile the column deltas adelta / bdelta (two double products, cvRound) and the row origins X0 / Y0 are computed ONCE per workgroup
 //     (one wave each) into LDS tables: per pixel the position is two integer adds;
 //   * per pixel and channel: two v_perm_b32 put the channel's bytes of a window row side by side as a u16 pair {v(x), v(x + 1)}, two
@@ -1150,6 +1150,14 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
                                          // prologue and halo shares but leaves 3 workgroups per CU (48 KB of LDS) and the fill of one is no longer covered by the others' sampling
 #endif
 constexpr int CV_TH = VS_WARP_CV_TILE_H, CV_RPW = CV_TH / 4, CV_WS_H = CV_TH + 8;
+#ifndef VS_WARP_CV_RS
+#define VS_WARP_CV_RS WS_W               // row pitch of the 8-bit kernel's byte tile in dwords (>= WS_W, a multiple of 4).  80: 23.0 KB of LDS, SEVEN workgroups per CU (round 6);
+                                         // 88 (the pitch of the float-bilinear byte tile, the 8-bit kernel's until round 6): 25.3 KB, six -- 10.7 us per 4K frame against 10.4.
+                                         // A compact window (72-dword pitch, 68 rows: 19.6 KB, eight workgroups per CU) for stabilisation-sized transforms was built too:
+                                         // equal to seven (profiles/r06_warp_cv.md section 5), not kept.
+#endif
+constexpr int CV_RS = VS_WARP_CV_RS;
+static_assert(CV_RS >= WS_W && CV_RS % 4 == 0, "tile pitch");
 static_assert(CV_TH % 64 == 0 || CV_TH == 32, "row-origin table: waves 2 and 3 fill it 32 rows per pass each (X0 in lanes 0..31, Y0 in lanes 32..63)");
 constexpr int CV_RBK = CV_RPW < 16 ? CV_RPW : 16;          // rows of a wave sampled in one basic block
 static_assert(CV_RPW % CV_RBK == 0, "whole row blocks");
@@ -1221,11 +1229,11 @@ __device__ __forceinline__ void cv_pixel_global(const uint8_t* __restrict__ src,
 // scheduling fences the kernel spills 17 registers at the 80 the occupancy allows and takes 17-22 us.  Fill items dealt over the tile's own
 // column groups instead of the window's 20, non-temporal stores: no change.)
 template <int BORDER>
-__global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
+__global__ __launch_bounds__(256, 7) void vs_k_bgr_warp_cv_c3(const uint8_t* __restrict__ src, int w, int h, int src_stride,
                                                              const int* __restrict__ tab, int tab_w, int tab_h, uint8_t* __restrict__ dst, int dst_stride,
                                                              size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
                                                              int chunk, vsk::Roi roi) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV_WS_H * WS_RS8];     // B | G << 8 | R << 16 per staged source pixel
+    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV_WS_H * CV_RS];     // B | G << 8 | R << 16 per staged source pixel
     // The fixed-point coordinate tables -- adelta[tab_w] | bdelta[tab_w] | X0[tab_h] | Y0[tab_h] per frame -- are made ONCE PER FRAME by
     // vs_k_cv_tables in front of this launch, as cv::warpAffine makes them once per call (until round 5 every workgroup rebuilt its 64 + 64 +
     // 2 x 64 entries in fp64 and shared them through LDS behind a barrier: 29 % of a wave's life, profiles/r05_cv_stamps_final.json).  A tile
@@ -1304,7 +1312,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
         const uint32_t row0 = 3u * (uint32_t)wv + r3;
         const bool col_live = r3 < 3u && (int)g < groups;
         const uint32_t goff = __umul24(row0, (uint32_t)src_stride) + 12u * g;
-        uint32_t* const tp = tile_raw + (row0 * (uint32_t)WS_RS8 + 4u * g);
+        uint32_t* const tp = tile_raw + (row0 * (uint32_t)CV_RS + 4u * g);
         u32x3 q[CV_FILL_SLOTS];
         bool live[CV_FILL_SLOTS];
 #pragma unroll
@@ -1323,8 +1331,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
             px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
             px.w = q[s].z >> 8;
-            VS_BOUNDS_CHECK((int)((row0 + 12u * s) * WS_RS8 + 4u * g) + 3, CV_WS_H * WS_RS8, 217);
-            *(u32x4*)(tp + 12 * s * WS_RS8) = px;
+            VS_BOUNDS_CHECK((int)((row0 + 12u * s) * CV_RS + 4u * g) + 3, CV_WS_H * CV_RS, 217);
+            *(u32x4*)(tp + 12 * s * CV_RS) = px;
         }
 #else
         u32x3 q[CV_FILL_SLOTS];
@@ -1335,7 +1343,7 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             const FillItem it = fill_item(lane, wv + 4 * s);
             live[s] = it.row < rows && it.g < groups;
             if (live[s]) q[s] = *(const u32x3*)(base + (__umul24((uint32_t)it.row, (uint32_t)src_stride) + 12u * (uint32_t)it.g));
-            toff[s] = (uint32_t)it.row * (uint32_t)WS_RS8 + 4u * (uint32_t)it.g;
+            toff[s] = (uint32_t)it.row * (uint32_t)CV_RS + 4u * (uint32_t)it.g;
         }
         VS_STAMP(2);
         VS_STAMP_DRAIN();
@@ -1348,8 +1356,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
             px.y = __builtin_amdgcn_perm(q[s].y, q[s].x, 0x0c050403u);
             px.z = __builtin_amdgcn_perm(q[s].z, q[s].y, 0x0c040302u);
             px.w = q[s].z >> 8;
-            VS_BOUNDS_CHECK((int)toff[s] + 3, CV_WS_H * WS_RS8, 217);
-            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV_WS_H * WS_RS8 - 3)) = px;
+            VS_BOUNDS_CHECK((int)toff[s] + 3, CV_WS_H * CV_RS, 217);
+            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV_WS_H * CV_RS - 3)) = px;
         }
 #endif
     } else if (fits && !(VS_WARP_WHATIF & 2)) {
@@ -1387,8 +1395,8 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
                 }
                 px = u32x4{d[0], d[1], d[2], d[3]};
             }
-            VS_BOUNDS_CHECK(it[s].row * WS_RS8 + 4 * it[s].g + 3, CV_WS_H * WS_RS8, 211);
-            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, CV_WS_H * WS_RS8 - 3)) = px;
+            VS_BOUNDS_CHECK(it[s].row * CV_RS + 4 * it[s].g + 3, CV_WS_H * CV_RS, 211);
+            *(u32x4*)(tile_raw + VS_DEBUG_CLAMP(it[s].row * CV_RS + 4 * it[s].g, CV_WS_H * CV_RS - 3)) = px;
         }
     }
     VS_STAMP(4);
@@ -1403,21 +1411,21 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
     const bool lane_in = x < roi.w, quad_in = (x | 3) < roi.w;
     const uint32_t sel = quad_sel(m);
     const uint32_t loff = (uint32_t)(x & ~3) * 3u + 4u * (uint32_t)m;
-    // one output pixel from the byte tile: LDS byte address of staged pixel (sy, sx) = 4 * ((sy - sy_lo) * WS_RS8 + (sx - sx_lo)).
+    // one output pixel from the byte tile: LDS byte address of staged pixel (sy, sx) = 4 * ((sy - sy_lo) * CV_RS + (sx - sx_lo)).
     // Instruction diet (tools/ubench_int.hip, profiles/r05_ubench_int.txt: three-operand integer instructions -- v_perm, v_dot2, v_mad_u32_u24,
     // v_bfe, v_add3, v_lshl_or, and v_mul_u32_u24 -- issue at 4.2-4.35 cycles per wave per SIMD, two-operand shifts / and / add at 2.3-2.6): the
     // weights are OpenCV's own 15-bit ones, 32 a b (<= 32768: a u16), so that fy enters as (Ys & 0x3e0) = 32 fy without a bit-field extract
     // and the top row's pair is (apair << 10) - bottom pair instead of a second multiply; result = (sum + 2^14) >> 15 as in the source.
     // (the window's origin is folded into the lane's column delta once per tile: base4 is a multiple of 4, so base4 << 8 leaves the ten
     // fraction bits of X alone and ((X + (base4 << 8)) >> 8) & ~3 = 4 sx + base4: the tile offset is one multiply-add per pixel)
-    const int base4 = -4 * (sy_lo * WS_RS8 + sx_lo);
+    const int base4 = -4 * (sy_lo * CV_RS + sx_lo);
     const uint32_t adw = (uint32_t)ad + ((uint32_t)base4 << 8);
     auto sample = [&](uint32_t Xs, uint32_t Ys) -> uint32_t {                   // Xs = X0 + adw (fits tiles), Ys = Y0 + bd
         const uint32_t fx = (Xs >> 5) & 31u, fy32 = Ys & 0x3e0u;
-        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * WS_RS8) + (((int)Xs >> 8) & ~3), 4 * (CV_WS_H * WS_RS8 - (WS_RS8 + 2)), 212);
+        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (4 * CV_RS) + (((int)Xs >> 8) & ~3), 4 * (CV_WS_H * CV_RS - (CV_RS + 2)), 212);
         const __attribute__((address_space(3))) uint32_t* t = (const __attribute__((address_space(3))) uint32_t*)((const __attribute__((address_space(3))) char*)tile_raw + off);
         if (VS_WARP_WHATIF & 1) return t[0] + fx + fy32;                    // (analysis: one LDS read, no arithmetic)
-        const uint32_t p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+        const uint32_t p00 = t[0], p01 = t[1], p10 = t[CV_RS], p11 = t[CV_RS + 1];
 #if VS_WARP_CV_W16
         // 16-bit weights 64 a b = twice OpenCV's: (2 S + 2^15) >> 16 is (S + 2^14) >> 15, and the sample is byte 2 of the sum -- no shifts in front
         // of the pack.  Only the top-left weight can reach 2^16 (fx = fy = 0: the other three are 0); the packed multiply saturates it to 65535, and
@@ -1516,6 +1524,11 @@ __global__ __launch_bounds__(256, 6) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
 #define VS_WARP_CV16_MINWAVES 5
 #endif
 constexpr int CV16_TH = VS_WARP_CV16_TILE_H, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
+#ifndef VS_WARP_CV16_RS
+#define VS_WARP_CV16_RS WS_RS8           // row pitch of the word tile in staged pixels (8 bytes each; >= WS_W, a multiple of 4)
+#endif
+constexpr int CV16_RS = VS_WARP_CV16_RS;
+static_assert(CV16_RS >= WS_W && CV16_RS % 4 == 0, "tile pitch");
 static_assert(CV16_TH % 4 == 0 && CV16_TH >= 16, "four waves share a tile's rows");
 constexpr int CV16_FILL_SLOTS = (CV16_WS_H / 4 * (WS_W / 4) + 63) / 64;
 
@@ -1542,7 +1555,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
                                                                  const int* __restrict__ tab, int tab_w, int tab_h, uint16_t* __restrict__ dst, int dst_stride,
                                                                  size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame,
                                                                  int chunk, int maxv, vsk::Roi roi) {
-    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV16_WS_H * WS_RS8 * 2];      // {B | G << 16, R} per staged source pixel
+    __shared__ __attribute__((aligned(16))) uint32_t tile_raw[CV16_WS_H * CV16_RS * 2];      // {B | G << 16, R} per staged source pixel
     const int tl = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (tl >= min(tiles_per_frame, (int)((blockIdx.x & 7) + 1) * chunk)) return;
     const int frame = blockIdx.y;
@@ -1592,7 +1605,7 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
         const uint32_t row0 = 3u * (uint32_t)wv + r3;
         const bool col_live = r3 < 3u && (int)g < groups;
         const uint32_t goff = __umul24(row0, 2u * (uint32_t)src_stride) + 24u * g;
-        uint32_t* const tp = tile_raw + 2u * (row0 * (uint32_t)WS_RS8 + 4u * g);
+        uint32_t* const tp = tile_raw + 2u * (row0 * (uint32_t)CV16_RS + 4u * g);
         u32x3 qa[CV16_FILL_SLOTS], qb[CV16_FILL_SLOTS];
         bool live[CV16_FILL_SLOTS];
 #pragma unroll
@@ -1609,8 +1622,8 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
             if (!live[s]) continue;
             const u32x3 a = qa[s], b = qb[s];                   // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
             seen |= a.x | a.y | a.z | b.x | b.y | b.z;
-            VS_BOUNDS_CHECK((int)(2u * ((row0 + 12u * s) * WS_RS8 + 4u * g)) + 7, CV16_WS_H * WS_RS8 * 2, 218);
-            u32x4* dstp = (u32x4*)(tp + 2 * 12 * s * WS_RS8);
+            VS_BOUNDS_CHECK((int)(2u * ((row0 + 12u * s) * CV16_RS + 4u * g)) + 7, CV16_WS_H * CV16_RS * 2, 218);
+            u32x4* dstp = (u32x4*)(tp + 2 * 12 * s * CV16_RS);
             dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
             dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
         }
@@ -1627,15 +1640,15 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
                 qa[s] = *(const u32x3*)gp;
                 qb[s] = *(const u32x3*)(gp + 12);
             }
-            toff[s] = 2u * ((uint32_t)it.row * (uint32_t)WS_RS8 + 4u * (uint32_t)it.g);
+            toff[s] = 2u * ((uint32_t)it.row * (uint32_t)CV16_RS + 4u * (uint32_t)it.g);
         }
 #pragma unroll
         for (int s = 0; s < CV16_FILL_SLOTS; s++) {
             if (!live[s]) continue;
             const u32x3 a = qa[s], b = qb[s];                   // a = B0G0 R0B1 G1R1 ; b = B2G2 R2B3 G3R3
             seen |= a.x | a.y | a.z | b.x | b.y | b.z;
-            VS_BOUNDS_CHECK((int)toff[s] + 7, CV16_WS_H * WS_RS8 * 2, 218);
-            u32x4* dstp = (u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV16_WS_H * WS_RS8 * 2 - 7));
+            VS_BOUNDS_CHECK((int)toff[s] + 7, CV16_WS_H * CV16_RS * 2, 218);
+            u32x4* dstp = (u32x4*)(tile_raw + VS_DEBUG_CLAMP((int)toff[s], CV16_WS_H * CV16_RS * 2 - 7));
             dstp[0] = u32x4{a.x, a.y & 0xffffu, __builtin_amdgcn_alignbyte(a.z, a.y, 2), a.z >> 16};
             dstp[1] = u32x4{b.x, b.y & 0xffffu, __builtin_amdgcn_alignbyte(b.z, b.y, 2), b.z >> 16};
         }
@@ -1682,8 +1695,8 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
                 lo = u32x4{d[0][0], d[0][1], d[1][0], d[1][1]};
                 hi = u32x4{d[2][0], d[2][1], d[3][0], d[3][1]};
             }
-            VS_BOUNDS_CHECK((it[s].row * WS_RS8 + 4 * it[s].g + 3) * 2 + 1, CV16_WS_H * WS_RS8 * 2, 215);
-            u32x4* dstp = (u32x4*)(tile_raw + 2 * VS_DEBUG_CLAMP(it[s].row * WS_RS8 + 4 * it[s].g, CV16_WS_H * WS_RS8 - 3));
+            VS_BOUNDS_CHECK((it[s].row * CV16_RS + 4 * it[s].g + 3) * 2 + 1, CV16_WS_H * CV16_RS * 2, 215);
+            u32x4* dstp = (u32x4*)(tile_raw + 2 * VS_DEBUG_CLAMP(it[s].row * CV16_RS + 4 * it[s].g, CV16_WS_H * CV16_RS - 3));
             dstp[0] = lo;
             dstp[1] = hi;
         }
@@ -1695,14 +1708,14 @@ __global__ __launch_bounds__(256, VS_WARP_CV16_MINWAVES) void vs_k_bgr_warp_cv_c
     if (yw >= roi.h) return;                                 // wave-uniform
     const bool rows_aligned = ((((uintptr_t)dst) | ((uintptr_t)dst_stride * 2)) & 3) == 0;               // uniform
     const bool lane_in = x < roi.w, pair_in = (x | 1) < roi.w;
-    const int base8 = -8 * (sy_lo * WS_RS8 + sx_lo);       // LDS byte address of staged pixel (sy, sx) = 8 * ((sy - sy_lo) * WS_RS8 + (sx - sx_lo))
+    const int base8 = -8 * (sy_lo * CV16_RS + sx_lo);       // LDS byte address of staged pixel (sy, sx) = 8 * ((sy - sy_lo) * CV16_RS + (sx - sx_lo))
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     // one output pixel of a tile that fits (Xs carries the window origin: base8 is a multiple of 8, base8 << 7 leaves X's fraction bits alone)
     auto sample = [&](uint32_t Xs, uint32_t Ys, uint32_t (&o)[3]) {
         const uint32_t fx = (Xs >> 5) & 31u, fy = (Ys >> 5) & 31u;
-        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (8 * WS_RS8) + (((int)Xs >> 7) & ~7), 8 * (CV16_WS_H * WS_RS8 - (WS_RS8 + 2)), 216);
+        const int off = VS_DEBUG_CLAMP_BYTES(((int)Ys >> 10) * (8 * CV16_RS) + (((int)Xs >> 7) & ~7), 8 * (CV16_WS_H * CV16_RS - (CV16_RS + 2)), 216);
         const __attribute__((address_space(3))) u32x2* t = (const __attribute__((address_space(3))) u32x2*)((const __attribute__((address_space(3))) char*)tile_raw + off);
-        const u32x2 p00 = t[0], p01 = t[1], p10 = t[WS_RS8], p11 = t[WS_RS8 + 1];
+        const u32x2 p00 = t[0], p01 = t[1], p10 = t[CV16_RS], p11 = t[CV16_RS + 1];
         if (!wide) {                                         // (uniform) every sample < 2^14: the integer form of the same value
             const uint32_t apair = fx * 0xffffu + 32u;                      // (32 - fx) | fx << 16
             const uint32_t wb = apair * (fy << 5), wt = (apair << 10) - wb; // {32 a0 b | 32 a1 b << 16}
