@@ -44,6 +44,10 @@ using namespace vsd;
 namespace {
 
 // tuning knobs (tools/build_variant.sh builds the library with other values to compare them on the GPU)
+#ifndef VS_WARP_WS_EXTRA
+#define VS_WARP_WS_EXTRA 8               // staged rows beyond the tile's own in the float-tile (Lanczos2) kernels: 8 -> 24 rows, 31 KB of LDS, 5 workgroups per CU (experiment: 4 ->
+                                         // 20 rows, 25.9 KB, 6 workgroups with VS_WARP_FAST_MINWAVES=6; rotations beyond ~0.9 degrees then leave the window: profiles/r06_warp_sep_occupancy.txt)
+#endif
 #ifndef VS_WARP_FAST_MINWAVES
 #define VS_WARP_FAST_MINWAVES 4          // __launch_bounds__ waves per SIMD of the fast Lanczos2 kernels
 #endif
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
     constexpr bool RAWTILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
     constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
-    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + 8;
+    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + (RAWTILE ? 8 : VS_WARP_WS_EXTRA);
     constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
     static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
     __shared__ f4 tile[RAWTILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
