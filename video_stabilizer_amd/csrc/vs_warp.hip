@@ -1525,11 +1525,16 @@ __global__ __launch_bounds__(256, 7) void vs_k_bgr_warp_cv_c3(const uint8_t* __r
 #define VS_WARP_CV16_TILE_H 32           // output rows per workgroup of the 16-bit kernel (a multiple of 4)
 #endif
 #ifndef VS_WARP_CV16_MINWAVES
-#define VS_WARP_CV16_MINWAVES 5
+#define VS_WARP_CV16_MINWAVES 6
 #endif
-constexpr int CV16_TH = VS_WARP_CV16_TILE_H, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + 8;
+#ifndef VS_WARP_CV16_WS_EXTRA
+#define VS_WARP_CV16_WS_EXTRA 8          // staged rows beyond the tile's own (a multiple of 4)
+#endif
+constexpr int CV16_TH = VS_WARP_CV16_TILE_H, CV16_RPW = CV16_TH / 4, CV16_WS_H = CV16_TH + VS_WARP_CV16_WS_EXTRA;
 #ifndef VS_WARP_CV16_RS
-#define VS_WARP_CV16_RS WS_RS8           // row pitch of the word tile in staged pixels (8 bytes each; >= WS_W, a multiple of 4)
+#define VS_WARP_CV16_RS WS_W             // row pitch of the word tile in staged pixels (8 bytes each; >= WS_W, a multiple of 4).  80: 25.6 KB of LDS, SIX workgroups per CU (round 6);
+                                         // 88 (until round 6): 28.2 KB, five -- 20.27 us per 4K 10-bit frame against 19.89 (four alternating passes, profiles/r06_ab_cv16_pitch.txt);
+                                         // seven (36 staged rows) 20.03: not kept
 #endif
 constexpr int CV16_RS = VS_WARP_CV16_RS;
 static_assert(CV16_RS >= WS_W && CV16_RS % 4 == 0, "tile pitch");
