@@ -393,6 +393,8 @@ TableRing* table_ring() { Rings* r = thread_rings(); return r ? &r->tables : nul
 
 // A stream is about to be destroyed (a handle's own stream: ~vs_aligner; a caller's stream: vs_stream_retire): nothing in the
 // library may refer to it afterwards.
+bool& vsi::warp_keeps_solver_slot() { thread_local bool v = false; return v; }
+
 hipError_t vsi::retire_stream(hipStream_t s) {
     std::vector<Rings*> rings;
     {
@@ -771,6 +773,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     std::vector<float> P((size_t)n_frames * (with_extents ? 8 : 4));
     for (int i = 0; i < n_frames; i++) vs_ul_params_warp(&t[i], w, h, &P[(size_t)i * 4]);
     if (with_extents) vsk::bgr_warp_c3_extents(P.data(), n_frames, roi, bits, mode, P.data() + (size_t)n_frames * 4);
+    const bool compact = with_extents && !vsi::warp_keeps_solver_slot() && vsk::bgr_warp_c3_rows_fit_compact(P.data() + (size_t)n_frames * 4, n_frames);
     // Per-frame kernel parameters travel host -> device through a pinned ring (ParamRing below), so a
     // VS_MEM_DEVICE call stays asynchronous and never reads a host buffer that has gone out of scope.
     float4* pdev = nullptr;
@@ -784,7 +787,7 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     hipError_t e = hipErrorNotSupported;
     if (tuned)
         e = vsk::bgr_warp_c3(a.dev, w, h, src_stride, bits, pdev, with_extents ? pdev + n_frames : nullptr, mode, border, max_value, o.dev,
-                             dst_stride, n_frames, src_fs, dst_fs, roi, s);
+                             dst_stride, n_frames, src_fs, dst_fs, roi, compact, s);
     if (e == hipErrorNotSupported)   // layouts without a tuned kernel (other channel counts, float output): one thread per pixel, same arithmetic
         e = vsk::bgr_warp_generic(a.dev, w, h, src_stride, channels, bits, pdev, mode, border, max_value,
                                   o.dev, dst_stride, f32out, n_frames, src_fs, dst_fs, roi, s);

@@ -1885,6 +1885,8 @@ static int stab_run_impl_unguarded(vs_stabilizer* s, const void* frames, size_t 
             const size_t dst_fs = to_host ? (size_t)ow * oh * 3 : out_frame_stride;
             // (device output of an overlapped clip batch: the warps go to warp_stream and run under the next group's alignment)
             hipStream_t ws = (s->overlap_warps && !to_host) ? s->warp_stream : st;
+            // (beside the next group's alignment the Lanczos2 warp keeps its standard window: see vsi::warp_keeps_solver_slot)
+            struct SlotHint { bool& f; bool old; SlotHint(bool on) : f(vsi::warp_keeps_solver_slot()), old(f) { f = on; } ~SlotHint() { f = old; } } hint(s->overlap_warps);
             int wr = vs_bgr_image_warp_roi_batch(jobs[j].src, (size_t)w * h * 3, (int)(e - j), w, h, w * 3, 3, (int)esz * 8, ts.data(),
                                                  s->params.warp_mode, s->params.warp_border, vs_format_max_value(format), crop, crop, ow, oh,
                                                  dst, dst_fs, ow * 3, VS_MEM_DEVICE, ws);

@@ -102,6 +102,11 @@ private:
 int finish_outputs(int mem, hipStream_t s, std::initializer_list<Staged*> outs);
 
 bool device_ready();   // true when a HIP device is usable (sets last error otherwise)
+// Set by the engine around warp launches that run beside the NEXT group's alignment (vs_stabilizer_process_batch / _clips, overlapped): the small-footprint
+// solver build moves into a CU as soon as ONE warp workgroup leaves it, which needs the warp's workgroup to hold at least the solver's 35 KB of LDS -- the
+// standard 31 KB window does (with the CU's slack), the COMPACT six-wave instantiation's 26 KB does not (c5: 20.3 k -> 18.4 k frames/s with it).  Thread-local:
+// a handle is used by one thread at a time, and the hint must not reach another thread's calls.
+bool& warp_keeps_solver_slot();
 // `s` is about to be destroyed: wait for and drop everything the library still tracks on it (bgr_image_warp's parameter ring
 // keeps an event per in-flight call; an event must not outlive the stream it was recorded on)
 hipError_t retire_stream(hipStream_t s);   // first error of the waits (the references are dropped either way)

@@ -82,6 +82,9 @@ namespace {
 #ifndef VS_WARP_PIPE_AHEAD
 #define VS_WARP_PIPE_AHEAD 6             // ... tap reads in flight ahead of the tap being consumed (< 8: the ring has eight slots)
 #endif
+#ifndef VS_WARP_PIPE_AHEAD_COMPACT
+#define VS_WARP_PIPE_AHEAD_COMPACT 2     // ... in the COMPACT instantiation (six waves per SIMD: 2 -> 72 VGPRs, 3 -> 75, 4 and more spill at the 85-register cap)
+#endif
 constexpr int WT_W = 64, WT_H = VS_WARP_TILE_H;      // output tile
 constexpr int RPW = WT_H / 4;            // output rows per wave
 constexpr int RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW;
@@ -323,10 +326,10 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
 // to do it lost: two copies of this function behind a wave-uniform branch took the kernel from 78 to 128 VGPRs with 9 spilled (42.1 us per
 // 4K frame instead of 38.3), scalar branches over the select slices cut the straight-line block into pieces the register allocator
 // handles far worse (135 spilled VGPRs).  profiles/r05_warp_sep.md.)
-template <int NPX>
+template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD>
 __device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
                                                     uint32_t (&o)[NPX][3], bool& all_ok) {
-    constexpr int NV = 8, AHEAD = VS_WARP_PIPE_AHEAD;
+    constexpr int NV = 8;
     static_assert(AHEAD >= 1 && AHEAD < NV && 16 % NV == 0, "ring of eight tap registers");
     const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
     f4 vals[NV];
@@ -446,10 +449,10 @@ __device__ __forceinline__ void sep_pixel(const lds_f4 t, const f2 fr, float num
 // contracted form's 179 -- bit-identical to lanczos_separable_combine / the oracle's
 // VSO_WARP_LANCZOS2_SEPARABLE (the pipelining only decides WHEN an instruction issues).  num[k] = {numB, numG, numR, den}; all_ok is
 // not touched (rcp_rn: den cannot leave its range).
-template <int NPX>
+template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD>
 __device__ __forceinline__ void sep_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
                                                    uint32_t (&o)[NPX][3], bool& all_ok) {
-    constexpr int NV = 8, AHEAD = VS_WARP_PIPE_AHEAD;
+    constexpr int NV = 8;
     static_assert(AHEAD >= 1 && AHEAD < NV && 16 % NV == 0, "ring of eight tap registers");
     const float C[6] = {-0.0158853f, 0.128693f, -0.583468f, 1.52229f, -2.05238f, 0.999861f};
     f4 vals[NV];
@@ -658,15 +661,20 @@ __device__ __forceinline__ FillItem fill_item(int lane, int slot) {
     return FillItem{4 * rq + (lane & 3), p - 20 * rq};
 }
 
-template <typename T, int MODE, int BORDER>
-__global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAVES : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
+// COMPACT (round 6, the contracted and separable Lanczos2 forms): a 20-row window instead of 24 (25.9 KB of LDS instead of 31.1), at most 85 VGPRs and tap reads two ahead
+// instead of six -- SIX waves per SIMD instead of five on this issue-bound kernel: 34.1 us per 4K frame against 35.1 (profiles/r06_warp_sep_occupancy.txt).  The launcher
+// takes it when every frame's rows fit (the host-side extents say the tile's footprint spans under 16 source rows: rotations up to ~0.9 degrees at unit scale); a tile that
+// does not fit its window takes the per-pixel path in either instantiation, so the choice is about speed only -- same arithmetic, same bits.
+template <typename T, int MODE, int BORDER, bool COMPACT = false>
+__global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_WARP_FAST_MINWAVES) : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
     constexpr bool RAWTILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
     constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
-    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + (RAWTILE ? 8 : VS_WARP_WS_EXTRA);
+    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + (RAWTILE ? 8 : (COMPACT ? 4 : VS_WARP_WS_EXTRA));
+    static_assert(!COMPACT || (!RAWTILE && (MODE == 2 || MODE == 3)), "the compact window belongs to the float-tile Lanczos2 forms");
     constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
     static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
     __shared__ f4 tile[RAWTILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
@@ -977,9 +985,9 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? VS_WARP_FAST_MINWAV
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (MODE == 2 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
-        fast_rows_pipelined<RB>(t_all, fr_all, maxv, num, o, all_ok);
+        fast_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD>(t_all, fr_all, maxv, num, o, all_ok);
     } else if (MODE == 3 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
-        sep_rows_pipelined<RB>(t_all, fr_all, maxv, num, o, all_ok);
+        sep_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD>(t_all, fr_all, maxv, num, o, all_ok);
     } else
 #pragma unroll
     for (int kp = 0; kp < RB; kp += 2) {
@@ -1816,7 +1824,7 @@ namespace vsk {
 
 template <typename T>
 static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, const float4* extents_dev, int mode,
-                            int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, hipStream_t s) {
+                            int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, bool compact, hipStream_t s) {
     const int th = tile_h_of((int)sizeof(T) * 8, mode);
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + th - 1) / th;
     const long long tpf = (long long)tiles_x * tiles_y;
@@ -1838,6 +1846,13 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
                            tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
         if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
         else if (mode == 0) VS_LAUNCH(0, 1);
+#define VS_LAUNCH_C(M, Bd) \
+        hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd, true>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
+                           tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
+        else if (mode == 2 && compact && border == 0) VS_LAUNCH_C(2, 0);
+        else if (mode == 2 && compact) VS_LAUNCH_C(2, 1);
+        else if (mode == 3 && compact && border == 0) VS_LAUNCH_C(3, 0);
+        else if (mode == 3 && compact) VS_LAUNCH_C(3, 1);
         else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
         else if (mode == 2) VS_LAUNCH(2, 1);
         else if (mode == 3 && border == 0) VS_LAUNCH(3, 0);
@@ -1846,17 +1861,28 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
         else VS_LAUNCH(1, 1);
     }
 #undef VS_LAUNCH
+#undef VS_LAUNCH_C
     return hipGetLastError();
 }
 
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, const float4* extents_dev,
                        int mode, int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi,
-                       hipStream_t s) {
+                       bool compact, hipStream_t s) {
+    static const int compact_env = []() { const char* e = getenv("VS_WARP_COMPACT"); return e ? atoi(e) : -1; }();       // (A/B switch: 0 never, 1 whenever the extents allow)
+    compact = compact && extents_dev != nullptr && (mode == 2 || mode == 3) && compact_env != 0;
     if (bits == 8)
         return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint8_t*)dst, dst_stride,
-                                  n_frames, src_fs, dst_fs, (float)max_value, roi, s);
+                                  n_frames, src_fs, dst_fs, (float)max_value, roi, compact, s);
     return launch_c3<uint16_t>((const uint16_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint16_t*)dst, dst_stride,
-                               n_frames, src_fs, dst_fs, (float)max_value, roi, s);
+                               n_frames, src_fs, dst_fs, (float)max_value, roi, compact, s);
+}
+
+// true when every frame's tile footprint stays under 16 source rows (E4 = bgr_warp_c3_extents' output): the COMPACT instantiation's 20-row window then holds
+// floor(max) - floor(min) + 4 <= 20 rows for every tile
+bool bgr_warp_c3_rows_fit_compact(const float* E4, int n_frames) {
+    for (int f = 0; f < n_frames; f++)
+        if (!((double)E4[4 * f + 3] - (double)E4[4 * f + 2] < 15.999)) return false;
+    return true;
 }
 
 // ints of table per frame for (bits, window): what bgr_warp_cv_c3's caller reserves (n_frames times) for `tab_dev`
