@@ -109,3 +109,35 @@ def test_sep_mode_4k_frame_equals_the_separable_twin_and_passes_the_gate(gpu_vs,
             assert ok, (bits, info)
     finally:
         oracle.set_threads(1)
+
+
+def test_compact_six_wave_instantiation_equals_the_standard_one():
+    """round 6: the contracted / separable forms run a COMPACT instantiation (20-row window, six waves per SIMD) when the host-side extents say every tile's footprint
+    spans under 16 source rows, the standard one (24 rows) otherwise or with VS_WARP_COMPACT=0 (read once per process: child processes).  Same arithmetic, same bits:
+    transforms either side of the threshold (rotation ~0.9 degrees), 8- and 10-bit, both borders, a batch that mixes fitting and non-fitting frames."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from video_stabilizer_amd import capi\n"
+            "rng = np.random.default_rng(9)\n"
+            "h = hashlib.sha256()\n"
+            "for bits in (8, 10):\n"
+            "    mv = 255 if bits == 8 else 1023\n"
+            "    src = rng.integers(0, mv + 1, (3, 150, 333, 3)).astype(np.uint8 if bits == 8 else np.uint16)\n"
+            "    for mode in (capi.WARP_LANCZOS2_SEP, capi.WARP_LANCZOS2_FAST):\n"
+            "        for border in (0, 1):\n"
+            "            for trs in ([(0.002, -0.0015, 3.3, -2.7)] * 3, [(0.001, 0.014, 1.0, 2.0), (0.0, 0.0155, -3.0, 0.5), (0.0, 0.0165, 0.25, 0.75)],\n"
+            "                        [(0.03, 0.02, 5.0, -4.0), (0.0, 0.0, 0.5, 0.5), (-0.05, 0.1, 0.0, 0.0)]):\n"
+            "                out = capi.bgr_image_warp_batch(src, [capi.Transform.of(*t) for t in trs], mode, border, max_value=mv)\n"
+            "                h.update(out.tobytes())\n"
+            "print('DIGEST', h.hexdigest())\n") % root
+    digests = []
+    for env in ({}, {"VS_WARP_COMPACT": "0"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(out.stdout.strip().split("DIGEST")[-1].strip())
+    assert digests[0] == digests[1] and len(digests[0]) == 64

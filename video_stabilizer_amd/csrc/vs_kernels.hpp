@@ -48,11 +48,11 @@ hipError_t bgr_warp_generic(const void* src, int w, int h, int src_stride, int c
                             const float4* params_dev, int mode, int border, int max_value, void* dst, int dst_stride,
                             bool f32out, int n_frames, size_t src_frame_stride, size_t dst_frame_stride, Roi roi, hipStream_t s);
 // tuned interleaved 3-channel path, u8 or u16 (vs_warp.hip); hipErrorNotSupported when the grid would overflow
-// compact: every frame's rows fit the 20-row window of the contracted / separable forms' six-wave instantiation (bgr_warp_c3_rows_fit_compact on the extents)
+// compact: 0 the standard window; 1 / 2: every frame fits the 20-row windows of the contracted / separable forms' six- / seven-wave instantiations (bgr_warp_c3_compact_shape on the extents)
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, const float4* extents_dev,
                        int mode, int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi,
-                       bool compact, hipStream_t s);
-bool bgr_warp_c3_rows_fit_compact(const float* E4, int n_frames);
+                       int compact, hipStream_t s);
+int bgr_warp_c3_compact_shape(const float* E4, int n_frames);
 // VS_WARP_BILINEAR_CV (cv::warpAffine's fixed-point bilinear): minv_dev = n_frames x 6 doubles, the output -> source matrix of each frame
 // (vs_cv_inverse_matrix).  Generic: any channel count, u8 / u16 containers; tuned (vs_warp.hip): interleaved 8-bit BGR saturating at 255,
 // hipErrorNotSupported for anything else

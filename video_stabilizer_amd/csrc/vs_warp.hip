@@ -326,7 +326,7 @@ __device__ __forceinline__ void fast_pair(const lds_f4 t[2], const f2 fr[2], flo
 // to do it lost: two copies of this function behind a wave-uniform branch took the kernel from 78 to 128 VGPRs with 9 spilled (42.1 us per
 // 4K frame instead of 38.3), scalar branches over the select slices cut the straight-line block into pieces the register allocator
 // handles far worse (135 spilled VGPRs).  profiles/r05_warp_sep.md.)
-template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD>
+template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD, int RS = WS_RS>
 __device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
                                                     uint32_t (&o)[NPX][3], bool& all_ok) {
     constexpr int NV = 8;
@@ -377,11 +377,11 @@ __device__ __forceinline__ void fast_rows_pipelined(const lds_f4 (&t)[NPX], cons
     // the tap read that is AHEAD slices in front of tap j of pixel kk (it may belong to pixel kk + 1)
     auto issue = [&](int j, int kk) {
         const int jj = j + AHEAD, kt = kk + (jj >> 4), tj = jj & 15;
-        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * WS_RS + (tj & 3)];
+        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * RS + (tj & 3)];
     };
     // ---- prologue: the first reads of pixel 0 in flight under its weight chains ----
 #pragma unroll
-    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * WS_RS + (j & 3)];
+    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * RS + (j & 3)];
 #pragma unroll
     for (int j = 0; j < 16; j++) w_slice(j, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -449,7 +449,7 @@ __device__ __forceinline__ void sep_pixel(const lds_f4 t, const f2 fr, float num
 // contracted form's 179 -- bit-identical to lanczos_separable_combine / the oracle's
 // VSO_WARP_LANCZOS2_SEPARABLE (the pipelining only decides WHEN an instruction issues).  num[k] = {numB, numG, numR, den}; all_ok is
 // not touched (rcp_rn: den cannot leave its range).
-template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD>
+template <int NPX, int AHEAD = VS_WARP_PIPE_AHEAD, int RS = WS_RS>
 __device__ __forceinline__ void sep_rows_pipelined(const lds_f4 (&t)[NPX], const f2 (&fr)[NPX], float maxv, float (&num)[NPX][4],
                                                    uint32_t (&o)[NPX][3], bool& all_ok) {
     constexpr int NV = 8;
@@ -506,10 +506,10 @@ __device__ __forceinline__ void sep_rows_pipelined(const lds_f4 (&t)[NPX], const
     };
     auto issue = [&](int j, int kk) {
         const int jj = j + AHEAD, kt = kk + (jj >> 4), tj = jj & 15;
-        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * WS_RS + (tj & 3)];
+        if (kt < NPX) vals[jj % NV] = t[kt][(tj >> 2) * RS + (tj & 3)];
     };
 #pragma unroll
-    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * WS_RS + (j & 3)];
+    for (int j = 0; j < AHEAD; j++) vals[j % NV] = t[0][(j >> 2) * RS + (j & 3)];
 #pragma unroll
     for (int j = 0; j < 16; j++) w_slice(j, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -660,24 +660,35 @@ __device__ __forceinline__ FillItem fill_item(int lane, int slot) {
     const int rq = (p * 205) >> 12;                          // p / 20
     return FillItem{4 * rq + (lane & 3), p - 20 * rq};
 }
+template <int G>
+__device__ __forceinline__ FillItem fill_item_g(int lane, int slot) {      // the same map over G column groups per row (G = 18: p / 18 = (p * 3641) >> 16, exact below 2000)
+    if (G == 20) return fill_item(lane, slot);
+    const int p = (lane >> 2) + 16 * slot;
+    const int rq = (p * 3641) >> 16;
+    return FillItem{4 * rq + (lane & 3), p - G * rq};
+}
 
 // COMPACT (round 6, the contracted and separable Lanczos2 forms): a 20-row window instead of 24 (25.9 KB of LDS instead of 31.1), at most 85 VGPRs and tap reads two ahead
 // instead of six -- SIX waves per SIMD instead of five on this issue-bound kernel: 34.1 us per 4K frame against 35.1 (profiles/r06_warp_sep_occupancy.txt).  The launcher
 // takes it when every frame's rows fit (the host-side extents say the tile's footprint spans under 16 source rows: rotations up to ~0.9 degrees at unit scale); a tile that
 // does not fit its window takes the per-pixel path in either instantiation, so the choice is about speed only -- same arithmetic, same bits.
-template <typename T, int MODE, int BORDER, bool COMPACT = false>
-__global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_WARP_FAST_MINWAVES) : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
+template <typename T, int MODE, int BORDER, int SHAPE = 0>
+__global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (SHAPE == 2 ? 7 : SHAPE == 1 ? 6 : VS_WARP_FAST_MINWAVES) : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
     const T* __restrict__ src, int w, int h, int src_stride, const float4* __restrict__ params, T* __restrict__ dst,
     int dst_stride, size_t src_fs, size_t dst_fs, int tiles_x, uint32_t tiles_x_magic, int tiles_per_frame, int chunk,
     float maxv, vsk::Roi roi, const float4* __restrict__ extents) {
     constexpr bool RAWTILE = raw_tile_of((int)sizeof(T) * 8, MODE);       // the tile holds source bytes / words, not floats (both depths)
     constexpr int PXD = sizeof(T) == 1 ? 1 : 2;                          // ... dwords per staged pixel
     // this kernel's tile height and what follows from it (the namespace-scope values are those of the 16-row kernels)
-    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + (RAWTILE ? 8 : (COMPACT ? 4 : VS_WARP_WS_EXTRA));
-    static_assert(!COMPACT || (!RAWTILE && (MODE == 2 || MODE == 3)), "the compact window belongs to the float-tile Lanczos2 forms");
-    constexpr int FILL_SLOTS = (WS_H / 4 * (WS_W / 4) + 63) / 64;
+    constexpr int WT_H = tile_h_of((int)sizeof(T) * 8, MODE), RPW = WT_H / 4, RB = VS_WARP_ROW_BLOCK < RPW ? VS_WARP_ROW_BLOCK : RPW, WS_H = WT_H + (RAWTILE ? 8 : (SHAPE ? 4 : VS_WARP_WS_EXTRA));
+    constexpr bool COMPACT = SHAPE != 0;
+    constexpr int KG = SHAPE == 2 ? 18 : WS_W / 4, KRS = SHAPE == 2 ? 4 * KG + 1 : WS_RS;      // column groups per staged row, float-tile row pitch (73 slots = 1168 bytes = 16 (mod 128), like 81)
+    static_assert(!COMPACT || (!RAWTILE && (MODE == 2 || MODE == 3)), "the compact windows belong to the float-tile Lanczos2 forms");
+    static_assert(SHAPE != 2 || MODE == 3, "seven waves per SIMD: the separable form only (the contracted one needs 77 registers)");
+    static_assert(SHAPE != 2 || (VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF), "the 73-slot pitch is known to the pipelined sampler only");
+    constexpr int FILL_SLOTS = (WS_H / 4 * KG + 63) / 64;
     static_assert(RPW % RB == 0 && RB % 2 == 0, "rows per wave: a whole number of row blocks, rows in pairs");
-    __shared__ f4 tile[RAWTILE ? 1 : WS_H * WS_RS];         // {B,G,R,1} per staged source pixel
+    __shared__ f4 tile[RAWTILE ? 1 : WS_H * KRS];         // {B,G,R,1} per staged source pixel
     __shared__ __attribute__((aligned(16))) uint32_t tile_raw[RAWTILE ? WS_H * WS_RS8 * PXD : 4];    // bilinear: B | G << 8 | R << 16 (8-bit frames), {B | G << 16, R} (16-bit containers)
 #ifdef VS_WARP_LDS_PAD
     __shared__ uint32_t lds_pad[VS_WARP_LDS_PAD / 4];       // occupancy experiments only: fewer workgroups per CU
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
         const int sy_hi = (int)floorf(mxy) + 2;
         rows = sy_hi - sy_lo + 1;
         groups = (sx_hi - sx_lo + 4) >> 2;                 // column groups of 4 pixels
-        fits = groups <= WS_W / 4 && rows <= WS_H;
+        fits = groups <= KG && rows <= WS_H;
     }
     // interior tiles (the whole staged window lies inside an aligned frame: all but the frame's rim): no clamps and no border
     // tests per item, one offset from a uniform base
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
     const int rf_r3 = (int)(((uint32_t)lane * 13u) >> 8), rf_g = lane - 20 * rf_r3, rf_row0 = 3 * wv + rf_r3;      // lane / 20, lane % 20
     auto item_of = [&](int s, bool interior) -> FillItem {
         if (ROWFILL && interior) return FillItem{rf_r3 < 3 ? rf_row0 + 12 * s : WS_H, rf_g};                // (lanes 60..63 carry no item: a row beyond every tile)
-        return fill_item(lane, wv + 4 * s);
+        return fill_item_g<KG>(lane, wv + 4 * s);
     };
     // the loads of an interior tile: into q0 / q1, which the fill converts -- right away, or (VS_WARP_TILES_PER_WG > 1) after the
     // previous tile's sampler blocks, so that a tile's memory latency lies under the tile before it
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
         } else {
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
-            it[s] = fill_item(lane, wv + 4 * s);
+            it[s] = fill_item_g<KG>(lane, wv + 4 * s);
             live[s] = it[s].row < rows && it[s].g < groups;
             const int sy = sy_lo + it[s].row, sx = sx_lo + 4 * it[s].g;
             rowp[s] = src + (size_t)clampi(sy, 0, h - 1) * src_stride;
@@ -880,8 +891,8 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
 #pragma unroll
         for (int s = 0; s < FILL_SLOTS; s++) {
             if (!live[s]) continue;
-            VS_BOUNDS_CHECK(it[s].row * WS_RS + 4 * it[s].g + 3, WS_H * WS_RS, 201);     // four staged pixels of one fill item
-            f4* t = tile + VS_DEBUG_CLAMP(it[s].row * WS_RS + 4 * it[s].g, WS_H * WS_RS - 3);
+            VS_BOUNDS_CHECK(it[s].row * KRS + 4 * it[s].g + 3, WS_H * KRS, 201);     // four staged pixels of one fill item
+            f4* t = tile + VS_DEBUG_CLAMP(it[s].row * KRS + 4 * it[s].g, WS_H * KRS - 3);
             if (direct[s]) {
                 if (sizeof(T) == 1) {
                     const u32x3 q = q0[s];                   // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
@@ -950,7 +961,7 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
     const float A1x = A1 * fx, Bx = B * fx;
     // LDS byte offset of the window origin = 16 * ((fly - oy) * WS_RS + (flx - ox)); all terms are small integers, exact in fp32
     constexpr int org = (MODE == 1) ? 0 : 1;                 // Lanczos windows start one pixel up / left of floor()
-    const float c0 = RAWTILE ? -4.0f * PXD * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * WS_RS + (sx_lo + org));
+    const float c0 = RAWTILE ? -4.0f * PXD * (float)(sy_lo * WS_RS8 + sx_lo) : -16.0f * (float)((sy_lo + org) * KRS + (sx_lo + org));
     const bool lane_in = x < roi.w;
     const int yw_first = yw;
 #pragma unroll 1
@@ -976,8 +987,8 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
         fr_all[k] = f2{Wx - flx, Wy - fly};
         // (the whole tap window of the pixel -- 4 x 4 staged pixels from boff, 2 x 2 for the bilinear mode -- lies inside the tile)
         const int boff = RAWTILE ? VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 4.0f * PXD * WS_RS8, __builtin_fmaf(flx, 4.0f * PXD, c0)), 4 * PXD * (WS_H * WS_RS8 - (WS_RS8 + 1)), 205)
-                                : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * WS_RS, __builtin_fmaf(flx, 16.0f, c0)),
-                                                       16 * (WS_H * WS_RS - (MODE == 1 ? WS_RS + 1 : 3 * WS_RS + 3)), 202);
+                                : VS_DEBUG_CLAMP_BYTES((int)__builtin_fmaf(fly, 16.0f * KRS, __builtin_fmaf(flx, 16.0f, c0)),
+                                                       16 * (WS_H * KRS - (MODE == 1 ? KRS + 1 : 3 * KRS + 3)), 202);
         t_all[k] = RAWTILE ? (lds_f4)((const __attribute__((address_space(3))) char*)tile_raw + boff)
                           : (lds_f4)((const __attribute__((address_space(3))) char*)tile + boff);
     }
@@ -985,9 +996,9 @@ __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (COMPACT ? 6 : VS_W
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (MODE == 2 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
-        fast_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD>(t_all, fr_all, maxv, num, o, all_ok);
+        fast_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD, KRS>(t_all, fr_all, maxv, num, o, all_ok);
     } else if (MODE == 3 && VS_WARP_FAST_PIPE && RB == 4 && !VS_WARP_WHATIF) {
-        sep_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD>(t_all, fr_all, maxv, num, o, all_ok);
+        sep_rows_pipelined<RB, COMPACT ? VS_WARP_PIPE_AHEAD_COMPACT : VS_WARP_PIPE_AHEAD, KRS>(t_all, fr_all, maxv, num, o, all_ok);
     } else
 #pragma unroll
     for (int kp = 0; kp < RB; kp += 2) {
@@ -1824,7 +1835,7 @@ namespace vsk {
 
 template <typename T>
 static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const float4* params_dev, const float4* extents_dev, int mode,
-                            int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, bool compact, hipStream_t s) {
+                            int border, T* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, float maxv, Roi roi, int compact, hipStream_t s) {
     const int th = tile_h_of((int)sizeof(T) * 8, mode);
     const int tiles_x = (roi.w + WT_W - 1) / WT_W, tiles_y = (roi.h + th - 1) / th;
     const long long tpf = (long long)tiles_x * tiles_y;
@@ -1846,13 +1857,15 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
                            tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
         if (mode == 0 && border == 0) VS_LAUNCH(0, 0);
         else if (mode == 0) VS_LAUNCH(0, 1);
-#define VS_LAUNCH_C(M, Bd) \
-        hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd, true>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
+#define VS_LAUNCH_C(M, Bd, Sh) \
+        hipLaunchKernelGGL((vs_k_bgr_warp_c3<T, M, Bd, Sh>), grid, block, 0, s, sp, w, h, src_stride, pp, dp, dst_stride, src_fs, dst_fs, \
                            tiles_x, magic, (int)tpf, chunk, maxv, roi, ep)
-        else if (mode == 2 && compact && border == 0) VS_LAUNCH_C(2, 0);
-        else if (mode == 2 && compact) VS_LAUNCH_C(2, 1);
-        else if (mode == 3 && compact && border == 0) VS_LAUNCH_C(3, 0);
-        else if (mode == 3 && compact) VS_LAUNCH_C(3, 1);
+        else if (mode == 2 && compact && border == 0) VS_LAUNCH_C(2, 0, 1);
+        else if (mode == 2 && compact) VS_LAUNCH_C(2, 1, 1);
+        else if (mode == 3 && compact == 2 && border == 0) VS_LAUNCH_C(3, 0, 2);
+        else if (mode == 3 && compact == 2) VS_LAUNCH_C(3, 1, 2);
+        else if (mode == 3 && compact && border == 0) VS_LAUNCH_C(3, 0, 1);
+        else if (mode == 3 && compact) VS_LAUNCH_C(3, 1, 1);
         else if (mode == 2 && border == 0) VS_LAUNCH(2, 0);
         else if (mode == 2) VS_LAUNCH(2, 1);
         else if (mode == 3 && border == 0) VS_LAUNCH(3, 0);
@@ -1867,9 +1880,10 @@ static hipError_t launch_c3(const T* src, int w, int h, int src_stride, const fl
 
 hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, const float4* params_dev, const float4* extents_dev,
                        int mode, int border, int max_value, void* dst, int dst_stride, int n_frames, size_t src_fs, size_t dst_fs, Roi roi,
-                       bool compact, hipStream_t s) {
-    static const int compact_env = []() { const char* e = getenv("VS_WARP_COMPACT"); return e ? atoi(e) : -1; }();       // (A/B switch: 0 never, 1 whenever the extents allow)
-    compact = compact && extents_dev != nullptr && (mode == 2 || mode == 3) && compact_env != 0;
+                       int compact, hipStream_t s) {
+    static const int compact_env = []() { const char* e = getenv("VS_WARP_COMPACT"); return e ? atoi(e) : -1; }();       // (A/B switch: 0 never, 1 the six-wave shape at most, 2 / unset: whatever the extents allow)
+    if (extents_dev == nullptr || !(mode == 2 || mode == 3)) compact = 0;
+    if (compact_env >= 0) compact = std::min(compact, compact_env);
     if (bits == 8)
         return launch_c3<uint8_t>((const uint8_t*)src, w, h, src_stride, params_dev, extents_dev, mode, border, (uint8_t*)dst, dst_stride,
                                   n_frames, src_fs, dst_fs, (float)max_value, roi, compact, s);
@@ -1877,12 +1891,15 @@ hipError_t bgr_warp_c3(const void* src, int w, int h, int src_stride, int bits, 
                                n_frames, src_fs, dst_fs, (float)max_value, roi, compact, s);
 }
 
-// true when every frame's tile footprint stays under 16 source rows (E4 = bgr_warp_c3_extents' output): the COMPACT instantiation's 20-row window then holds
-// floor(max) - floor(min) + 4 <= 20 rows for every tile
-bool bgr_warp_c3_rows_fit_compact(const float* E4, int n_frames) {
-    for (int f = 0; f < n_frames; f++)
-        if (!((double)E4[4 * f + 3] - (double)E4[4 * f + 2] < 15.999)) return false;
-    return true;
+// -> 0: the standard window; 1: every frame's tile footprint stays under 16 source rows (E4 = bgr_warp_c3_extents' output): the 20-row windows hold floor(max) - floor(min) + 4 <= 20
+// rows for every tile; 2: ... and under 65 source columns: floor(max) - floor(min) + 4 taps + 3 of alignment <= 72 = the 18 column groups of the seven-wave shape
+int bgr_warp_c3_compact_shape(const float* E4, int n_frames) {
+    int shape = 2;
+    for (int f = 0; f < n_frames; f++) {
+        if (!((double)E4[4 * f + 3] - (double)E4[4 * f + 2] < 15.999)) return 0;
+        if (!((double)E4[4 * f + 1] - (double)E4[4 * f + 0] < 64.99)) shape = 1;
+    }
+    return shape;
 }
 
 // ints of table per frame for (bits, window): what bgr_warp_cv_c3's caller reserves (n_frames times) for `tab_dev`
