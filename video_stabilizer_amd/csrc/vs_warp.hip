@@ -668,9 +668,10 @@ __device__ __forceinline__ FillItem fill_item_g(int lane, int slot) {      // th
     return FillItem{4 * rq + (lane & 3), p - G * rq};
 }
 
-// COMPACT (round 6, the contracted and separable Lanczos2 forms): a 20-row window instead of 24 (25.9 KB of LDS instead of 31.1), at most 85 VGPRs and tap reads two ahead
-// instead of six -- SIX waves per SIMD instead of five on this issue-bound kernel: 34.1 us per 4K frame against 35.1 (profiles/r06_warp_sep_occupancy.txt).  The launcher
-// takes it when every frame's rows fit (the host-side extents say the tile's footprint spans under 16 source rows: rotations up to ~0.9 degrees at unit scale); a tile that
+// SHAPE 1 / 2 = the COMPACT windows (round 6, the contracted and separable Lanczos2 forms): 20 staged rows instead of 24 (25.9 KB of LDS instead of 31.1), at most 85 VGPRs and tap
+// reads two ahead instead of six -- SIX waves per SIMD instead of five on this issue-bound kernel -- and, separable form only, 18 column groups at a 73-slot pitch (23.4 KB, <= 73
+// VGPRs): SEVEN.  34.9 -> 34.2 -> 33.9 us per 4K frame isolated, `value` +3.3 % (profiles/r06_warp_sep_occupancy.txt).  The launcher
+// takes them when every frame's rows (and, for shape 2, columns) fit (the host-side extents say the tile's footprint spans under 16 source rows: rotations up to ~0.9 degrees at unit scale); a tile that
 // does not fit its window takes the per-pixel path in either instantiation, so the choice is about speed only -- same arithmetic, same bits.
 template <typename T, int MODE, int BORDER, int SHAPE = 0>
 __global__ __launch_bounds__(256, (MODE == 2 || MODE == 3) ? (SHAPE == 2 ? 7 : SHAPE == 1 ? 6 : VS_WARP_FAST_MINWAVES) : (raw_tile_of((int)sizeof(T) * 8, MODE) ? 8 : VS_WARP_EXACT_MINWAVES)) void vs_k_bgr_warp_c3(
