@@ -773,7 +773,8 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     std::vector<float> P((size_t)n_frames * (with_extents ? 8 : 4));
     for (int i = 0; i < n_frames; i++) vs_ul_params_warp(&t[i], w, h, &P[(size_t)i * 4]);
     if (with_extents) vsk::bgr_warp_c3_extents(P.data(), n_frames, roi, bits, mode, P.data() + (size_t)n_frames * 4);
-    const int compact = with_extents && !vsi::warp_keeps_solver_slot() ? vsk::bgr_warp_c3_compact_shape(P.data() + (size_t)n_frames * 4, n_frames) : 0;
+    static const bool slot_hint = []() { const char* e = getenv("VS_WARP_SLOT_HINT"); return e ? atoi(e) != 0 : true; }();     // (A/B switch: 0 = the engine's overlapped warps may go compact too)
+    const int compact = with_extents && !(slot_hint && vsi::warp_keeps_solver_slot()) ? vsk::bgr_warp_c3_compact_shape(P.data() + (size_t)n_frames * 4, n_frames) : 0;
     // Per-frame kernel parameters travel host -> device through a pinned ring (ParamRing below), so a
     // VS_MEM_DEVICE call stays asynchronous and never reads a host buffer that has gone out of scope.
     float4* pdev = nullptr;
