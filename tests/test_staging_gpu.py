@@ -53,8 +53,9 @@ def test_every_allocation_of_a_first_staged_call_can_fail():
             k += 1
             assert k < 30, "the walk does not terminate"
         fired.append(k - 1)
-    # the fixed-point bilinear: 2 staging blocks x (device + pinned) + the table ring; the Lanczos2 forms: + the parameter ring's two halves instead
-    assert fired[0] >= 5 and fired[1] >= 6, fired
+    # 2 staging blocks x (device + pinned) + the table ring (fixed-point bilinear) / the parameter ring's device half (Lanczos2: a small call's parameters
+    # travel as kernel arguments, so the ring's pinned half is not made)
+    assert fired[0] >= 5 and fired[1] >= 5, fired
 
 
 def test_threads_lease_and_release_concurrently(gpu_vs, oracle):

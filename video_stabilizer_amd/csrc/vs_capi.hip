@@ -335,8 +335,29 @@ struct ParamRing : SpanRing {
         *out = dev + b;
         return VS_OK;
     }
+    // a span of the DEVICE half only (the caller fills it with a kernel: see param_block_to_device)
+    int take(size_t n, hipStream_t s, float4** out) {
+        std::lock_guard<std::mutex> g(mu);
+        if (n == 0 || n > kSlots / 2) return vsi::set_error(VS_ERR_ARG, "parameter block of %zu frames is too large", n);
+        if (!dev) VS_HIP(vsi::dev_alloc((void**)&dev, kSlots * sizeof(float4)));
+        size_t b = 0;
+        VS_TRY_RING(reserve(n, &b));
+        VS_TRY_RING(commit(b, n, s, hipSuccess));
+        *out = dev + b;
+        return VS_OK;
+    }
     int fence(float4* p, hipStream_t s) { return fence_span((size_t)(p - dev), s); }
 };
+// Small parameter blocks (up to kParamBlockSlots float4: the per-frame parameters + extents of up to 64 frames) reach the device as KERNEL ARGUMENTS of a
+// one-workgroup kernel that writes them into the ring's span: no host-to-device copy stands between the host's numbers and the warp kernel for the
+// per-frame drop-in call and the small batches of the parity tests (round 6, profiles/r06_flake.md: the matrix upload was the second of the two
+// runtime-ordered transfers the round-5 failure could have come from).
+constexpr int kParamBlockSlots = 128;
+struct ParamBlock { float4 v[kParamBlockSlots]; };
+__global__ __launch_bounds__(kParamBlockSlots) void vs_k_param_block(ParamBlock b, float4* __restrict__ dst, int n) {
+    const int i = (int)threadIdx.x;
+    if (i < n) dst[i] = b.v[i];
+}
 // Device-only scratch for VS_WARP_BILINEAR_CV's per-frame coordinate tables (vs_k_cv_tables writes them, the warp kernel of the same
 // call reads them): 48 KiB per 4K frame.  take() hands out n ints; the caller enqueues the table kernel and the warp kernel, then fence()s.
 struct TableRing : SpanRing {
@@ -780,7 +801,14 @@ static int bgr_warp_common(const void* src, size_t src_fs, int n_frames, int w, 
     float4* pdev = nullptr;
     ParamRing* ring = param_ring();
     if (!ring) return set_error(VS_ERR_UNSUPPORTED, "no current HIP device with index < 16");
-    VS_TRY(ring->upload(P.data(), P.size() / 4, s, &pdev));
+    if (P.size() / 4 <= (size_t)kParamBlockSlots) {          // small calls: by value through a one-workgroup kernel (see vs_k_param_block)
+        ParamBlock blk{};
+        memcpy(blk.v, P.data(), P.size() * sizeof(float));
+        VS_TRY(ring->take(P.size() / 4, s, &pdev));
+        hipLaunchKernelGGL(vs_k_param_block, dim3(1), dim3(kParamBlockSlots), 0, s, blk, pdev, (int)(P.size() / 4));
+        VS_HIP(hipGetLastError());
+    } else
+        VS_TRY(ring->upload(P.data(), P.size() / 4, s, &pdev));
     Staged a, o;
     const size_t in_bytes = ((size_t)(n_frames - 1) * src_fs + img_span(w, h, src_stride, channels)) * esz;
     VS_TRY(a.in(src, in_bytes, mem, s));
